@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4f|cfg4b|cfg5]
+
+A "step" is ONE pass of the hot path over one batch of synthetic input that is already resident
+in HBM (packed chars + offsets on the device, output preallocated): for the default workload
+(BASELINE.json configs[2], "cfg3") that is `batch_onehot_encode` of 65 536 AMINO20 sequences,
+len ~ U(50,1024), padlen 1024 -> float32 (1024, 65536, 20) = 5.37 GB, through the C ABI entry
+point bsq_onehot_device.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank encodes its own 65 536-sequence shard of an N x 65 536 batch -- sequences are independent, so
+there is no data-path collective (weak scaling) -- and `value` is the whole-job rate.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      algorithmic bytes per launch / average kernel duration (HIP events on the launch
+                stream) against the 8 TB/s HBM3E peak; `traffic` = measured HBM bytes per launch
+                from the committed rocprofv3 PMC pass (profiles/traffic.json) or null.
+  cpu_baseline  the reference's CPU path on this box's host cores, same batch (N=1, rank 0 only):
+                oracle/_ref (the reference's own C++ compiled in place, kind "reference") when that
+                prebuilt module is present, else the C port in oracle/ (kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    #        synth config, op, destchar, batch_first
+    "cfg3": ("cfg3", "onehot", "f", False),
+    "cfg2": ("cfg2", "tokenize", "B", True),
+    "cfg4f": ("cfg4", "onehot", "f", False),
+    "cfg4b": ("cfg4", "onehot", "B", False),
+    "cfg5": ("cfg5", "tokenize", "B", True),
+}
+
+
+def cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, cap_threads=None):
+    """Time the reference CPU path once on the full batch (bounded: one call)."""
+    from bioseq_amd import synth
+    from oracle import oracle as O  # checker / baseline only -- never on the product path
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, cap_threads) if cap_threads else cores
+    P = cfg["padlen"]
+    ref = O.load_reference()
+    total = int(offsets[-1])
+    if ref is not None:
+        kind = "reference"
+        tok = ref.Tokenizer(cfg["key"], bool(cfg["eos"]), bool(cfg["bos"]), bool(cfg["padchar"]))
+        seqs = synth.unpack(chars, offsets)
+        t0 = time.perf_counter()
+        if op == "onehot":
+            out = tok.batch_onehot_encode(seqs, padlen=P, destchar=destchar, nthreads=nthreads)
+        else:
+            out = tok.batch_tokenize(seqs, padlen=P, destchar=destchar, batch_first=batch_first, nthreads=nthreads)
+        dt = time.perf_counter() - t0
+    else:
+        kind = "port"
+        O.build()
+        tok = O.OracleTokenizer(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
+        t0 = time.perf_counter()
+        if op == "onehot":
+            out = tok.onehot_packed(chars, offsets, P, destchar, nthreads)
+        else:
+            out = tok.tokenize_packed(chars, offsets, P, destchar, batch_first, nthreads)
+        dt = time.perf_counter() - t0
+    nbytes = out.nbytes
+    del out
+    return {"value": total / dt / 1e9, "unit": "Gseq-chars/s", "cores": nthreads, "kind": kind,
+            "gb_per_s_written": nbytes / dt / 1e9, "seconds": dt, "host_cpus": cores,
+            "sample": "the full batch of this workload (%d sequences, %d chars, %.2f GB output), one call incl. "
+                      "result allocation as the reference does per call, nthreads=%d"
+                      % (len(offsets) - 1, total, nbytes / 1e9, nthreads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="cap the CPU baseline's thread count")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import ctypes
+    import torch
+    import bioseq_amd
+    from bioseq_amd import capi, synth
+
+    if not torch.cuda.is_available() or bioseq_amd.device_count() < 1:
+        sys.exit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    cfg_name, op, destchar, batch_first = WORKLOADS[args.workload]
+    cfg = synth.CONFIGS[cfg_name]
+    n, P = cfg["n"], cfg["padlen"]
+    # rank r owns sequences [r*n, (r+1)*n) of the N*n-sequence stream (weak scaling)
+    chars, offsets = synth.synth_packed(cfg["seed"], n, cfg["lo"], cfg["hi"], cfg["letters"], first=rank * n)
+    total = int(offsets[-1])
+
+    lib = capi.load()
+    desc = capi.make_desc(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
+    C = lib.bsq_alphabet_size(ctypes.byref(desc))
+    dt_code = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt_code)))
+    sz = lib.bsq_dtype_size(dt_code)
+    tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt_code.value]
+
+    d_chars = torch.from_numpy(chars).to(dev)
+    d_offs = torch.from_numpy(offsets).to(dev)
+    if op == "onehot":
+        out = torch.empty((P, n, C), dtype=tdt, device=dev)
+        out_bytes = P * n * C * sz
+    else:
+        out = torch.empty((n, P) if batch_first else (P, n), dtype=tdt, device=dev)
+        out_bytes = P * n * sz
+    algo_bytes = total + 8 * (n + 1) + out_bytes  # chars + offsets read once, output written once
+
+    stream = torch.cuda.current_stream()
+    sh = ctypes.c_void_p(stream.cuda_stream)
+
+    def step():
+        if op == "onehot":
+            st = lib.bsq_onehot_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), None, n, P,
+                                       dt_code, out.data_ptr(), sh)
+        else:
+            st = lib.bsq_tokenize_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), n, P,
+                                         int(batch_first), dt_code, out.data_ptr(), sh)
+        if st:
+            capi.check(st)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed sanity: validate lengths, run once, check a size-independent property
+    bad = ctypes.c_int64(-1)
+    capi.check(lib.bsq_validate_lengths_device(d_offs.data_ptr(), n, P, desc.bos, desc.eos, ctypes.byref(bad), sh))
+    out.fill_(7)
+    step()
+    torch.cuda.synchronize()
+    if op == "onehot":
+        ones = int(out.sum(dtype=torch.float64).item())
+        expect = total + (n if desc.bos else 0) + (n if desc.eos else 0)
+        if desc.padchar:
+            expect = P * n
+        assert ones == expect, ("one-hot sanity failed", ones, expect)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg_ms = float(np.mean(kern_ms))
+
+    # write-bandwidth yardstick: plain 16-byte streaming fill of the same output buffer
+    fill_bytes = (out_bytes // 16) * 16
+    for _ in range(2):
+        capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh))
+    fa, fb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fa.record(stream)
+    for _ in range(5):
+        capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh))
+    fb.record(stream)
+    torch.cuda.synchronize()
+    fill_gbps = fill_bytes * 5 / (fa.elapsed_time(fb) * 1e-3) / 1e9
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    tot_t = torch.tensor([float(total), float(out_bytes)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot_t, op=dist.ReduceOp.SUM)
+    wall_max = float(wall_t.item())
+    job_chars, job_out_bytes = float(tot_t[0].item()), float(tot_t[1].item())
+
+    if rank == 0:
+        achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        kernel_name = {"onehot": "k_onehot_tile", "tokenize": "k_tokenize_rows" if batch_first else "k_tokenize_tile"}[op]
+        res = {
+            "metric": "Gseq-chars/s + GB/s one-hot written, 64k x 1024 AMINO20" if args.workload == "cfg3"
+                      else "Gseq-chars/s + GB/s written (%s)" % args.workload,
+            "value": job_chars * args.steps / wall_max / 1e9,
+            "unit": "Gseq-chars/s",
+            "gb_per_s_written": job_out_bytes * args.steps / wall_max / 1e9,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f": "f32", "B": "u8"}.get(destchar, destchar), "data": "synthetic",
+            "config": {"workload": "%s: %s %s, %d seqs/GPU len~U(%d,%d), padlen %d, C=%d, %s output %s" % (
+                args.workload, cfg["key"], "batch_onehot_encode" if op == "onehot" else "batch_tokenize", n,
+                cfg["lo"], cfg["hi"], P, C, str(tdt).replace("torch.", ""),
+                "(P,B,C)" if op == "onehot" else ("(B,P)" if batch_first else "(P,B)")),
+                "sequences_per_gpu": n, "padlen": P, "channels": C, "input_chars_per_gpu": total,
+                "output_bytes_per_gpu": out_bytes, "sharding": "by sequence, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel_name,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_avg_ms": kern_avg_ms,
+                         "kernel_min_ms": float(np.min(kern_ms)), "kernel_median_ms": float(np.median(kern_ms)),
+                         "fill_yardstick_gbps": fill_gbps,
+                         "frac_of_fill": (out_bytes / (kern_avg_ms * 1e-3) / 1e9) / fill_gbps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, args.cpu_threads or None)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""In-tree build of the native pieces (no setuptools, no JIT cache):
+
+    bioseq_amd/libbsq_hip.so                      C-ABI library: HIP kernels for gfx950 + host staging
+    bioseq_amd/cbioseq.cpython-*.so               pybind11 host layer (links libbsq_hip.so, rpath $ORIGIN)
+
+`python -m bioseq_amd.build` or `bioseq_amd.build.build_all()`.  hipcc cross-compiles gfx950 code
+objects without a GPU, so this runs in the build container; the .so files travel to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB = os.path.join(HERE, "libbsq_hip.so")
+EXT = os.path.join(HERE, "cbioseq" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+LIB_SRCS = ["bsq_kernels.hip", "bsq_host.cpp", "bsq_alphabet.cpp"]
+LIB_DEPS = LIB_SRCS + ["bsq_internal.h"]
+EXT_SRCS = ["cbioseq_module.cpp"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_lib(force=False):
+    deps = [os.path.join(CSRC, f) for f in LIB_DEPS] + [os.path.join(INCLUDE, "bsq.h")]
+    if force or _newer(LIB, deps):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+              "-I" + INCLUDE, "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, f) for f in LIB_SRCS])
+    return LIB
+
+
+def build_ext(force=False):
+    import pybind11
+    deps = [os.path.join(CSRC, f) for f in EXT_SRCS] + [os.path.join(INCLUDE, "bsq.h"), LIB]
+    if force or _newer(EXT, deps):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra",
+              "-I" + INCLUDE, "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+              "-o", EXT] + [os.path.join(CSRC, f) for f in EXT_SRCS] +
+             ["-L" + HERE, "-lbsq_hip", "-Wl,-rpath,$ORIGIN"])
+    return EXT
+
+
+def build_all(force=False):
+    return build_lib(force), build_ext(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,91 @@
+"""ctypes binding of the C ABI (include/bsq.h) -- the same entry points the pybind11 layer calls.
+
+Used by bench.py (kernel-only timing on raw device pointers), by the tests that exercise the ABI
+directly, and as the worked example of INTEGRATION.md.  Raises if libbsq_hip.so is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbsq_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bsq.h")
+
+I8, I16, I32, U64, F32, F64 = range(6)
+SPACE_HOST, SPACE_DEVICE = 0, 1
+OK, ERR_INVALID_KEY, ERR_INVALID_ARG, ERR_DTYPE, ERR_SEQ_TOO_LONG, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = range(8)
+
+
+class Desc(ctypes.Structure):
+    """struct bsq_desc"""
+    _fields_ = [("lut", ctypes.c_int8 * 256), ("nchars", ctypes.c_int32), ("eos", ctypes.c_int32),
+                ("bos", ctypes.c_int32), ("padchar", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def declared_symbols(header: str = HEADER_PATH):
+    """Every function name declared in include/bsq.h."""
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bsq_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m bioseq_amd.build`")
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, i32, i64, vp, sz = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+    dp = ctypes.POINTER(Desc)
+    i64p = ctypes.POINTER(i64)
+    sig = {
+        "bsq_abi_version": (i32, []),
+        "bsq_strerror": (ctypes.c_char_p, [i32]),
+        "bsq_last_error": (ctypes.c_char_p, []),
+        "bsq_device_count": (i32, []),
+        "bsq_num_keys": (i32, []),
+        "bsq_key_name": (ctypes.c_char_p, [i32]),
+        "bsq_lut_get": (i32, [ctypes.c_char_p, vp, ctypes.POINTER(i32)]),
+        "bsq_desc_init": (i32, [dp, ctypes.c_char_p, i32, i32, i32]),
+        "bsq_bos_id": (i32, [dp]),
+        "bsq_eos_id": (i32, [dp]),
+        "bsq_pad_id": (i32, [dp]),
+        "bsq_alphabet_size": (i32, [dp]),
+        "bsq_dtype_from_destchar": (i32, [ctypes.c_char, ctypes.POINTER(c_int)]),
+        "bsq_dtype_size": (sz, [c_int]),
+        "bsq_validate_lengths": (i32, [vp, i64, i64, i32, i32, i64p]),
+        "bsq_validate_lengths_device": (i32, [vp, i64, i64, i32, i32, i64p, vp]),
+        "bsq_tokenize_device": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, vp]),
+        "bsq_onehot_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
+        "bsq_tokenize_device_generic": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, vp]),
+        "bsq_onehot_device_generic": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
+        "bsq_fill_device": (i32, [vp, sz, ctypes.c_uint32, vp]),
+        "bsq_tokenize_host": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, c_int, vp, i64p]),
+        "bsq_onehot_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),
+        "bsq_pinned_scratch": (vp, [sz]),
+        "bsq_release_staging": (None, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status: int):
+    if status != OK:
+        L = load()
+        raise RuntimeError(f"bsq status {status}: {L.bsq_strerror(status).decode()} -- {L.bsq_last_error().decode()}")
+
+
+def make_desc(key: str, eos=False, bos=False, padchar=False) -> Desc:
+    d = Desc()
+    check(load().bsq_desc_init(ctypes.byref(d), key.encode(), int(bool(eos)), int(bool(bos)), int(bool(padchar))))
+    return d

@@ -1,0 +1,274 @@
+// Host side of libbsq_hip.so: error reporting, device queries and the *_host entry points that
+// stage a packed batch from host memory through pinned + device buffers.
+//
+// Replaces, on the reference side, the allocate + memset + OpenMP-loop body of
+// Tokenizer::transencode<T> / Tokenizer::tokenize<T> (/root/reference/src/tokenize.h:420-427,
+// :326-333) and the numpy -> torch -> .to(device) hand-off of bioseq/__init__.py:58-65: the
+// encoded batch is produced on the accelerator instead of being copied to it.
+//
+// There is deliberately NO CPU implementation here: without a HIP device every compute entry
+// point returns BSQ_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "bsq.h"
+#include "bsq_internal.h"
+
+namespace {
+
+thread_local std::string t_last_error;
+
+// Grow-only staging buffers of one process (per HIP device).  All *_host calls are serialised by
+// g_mu; `busy` marks the point after which the buffers may be reused.
+struct Staging {
+    int device = -1;
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    void *d_in = nullptr;  // offsets | chars | mask
+    size_t d_in_cap = 0;
+    void *d_out = nullptr;
+    size_t d_out_cap = 0;
+    hipEvent_t busy = nullptr;
+    bool busy_pending = false;
+};
+constexpr int kMaxDevices = 16;
+Staging g_staging[kMaxDevices];
+std::mutex g_mu;
+
+size_t round_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
+
+bsq_status wait_idle(Staging &s) {
+    if (s.busy_pending) {
+        const hipError_t e = hipEventSynchronize(s.busy);
+        s.busy_pending = false;
+        if (e != hipSuccess) return bsq_internal::set_hip_error("hipEventSynchronize", e);
+    }
+    return BSQ_OK;
+}
+
+bsq_status current_staging(Staging **out) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return bsq_internal::set_error(BSQ_ERR_NO_DEVICE, bsq_strerror(BSQ_ERR_NO_DEVICE));
+    }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipGetDevice", e);
+    if (dev < 0 || dev >= kMaxDevices) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "device ordinal out of range");
+    Staging &s = g_staging[dev];
+    if (s.device < 0) {
+        e = hipEventCreateWithFlags(&s.busy, hipEventDisableTiming);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("hipEventCreate", e);
+        s.device = dev;
+    }
+    *out = &s;
+    return BSQ_OK;
+}
+
+bsq_status grow_device(void **buf, size_t *cap, size_t need) {
+    if (need <= *cap) return BSQ_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    const size_t want = round_up(need + need / 4, size_t(1) << 20);
+    hipError_t e = hipMalloc(buf, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(buf, round_up(need, 4096));
+        if (e != hipSuccess) return bsq_internal::set_hip_error("hipMalloc(staging)", e);
+        *cap = round_up(need, 4096);
+        return BSQ_OK;
+    }
+    *cap = want;
+    return BSQ_OK;
+}
+
+bool in_pinned(const Staging &s, const void *p) {
+    const char *c = static_cast<const char *>(p), *b = static_cast<const char *>(s.pinned);
+    return b && c >= b && c < b + s.pinned_cap;
+}
+
+struct DeviceBatch {
+    const uint8_t *chars = nullptr;
+    const int64_t *offsets = nullptr;
+    const uint8_t *mask = nullptr;
+};
+
+// Copy offsets | chars | mask to the device staging buffer on `stream`.
+bsq_status upload(Staging &s, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask, int64_t B,
+                  hipStream_t stream, DeviceBatch *db) {
+    const size_t total = static_cast<size_t>(offsets[B]);
+    const size_t off_bytes = round_up(size_t(B + 1) * 8, 256);
+    const size_t chr_bytes = round_up(total + 8, 256);  // +8: slack so the tail word is always mapped
+    const size_t need = off_bytes + chr_bytes + (mask ? chr_bytes : 0);
+    bsq_status st = grow_device(&s.d_in, &s.d_in_cap, need);
+    if (st != BSQ_OK) return st;
+    char *base = static_cast<char *>(s.d_in);
+    hipError_t e = hipMemcpyAsync(base, offsets, size_t(B + 1) * 8, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(base + off_bytes, chars, total, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess && mask && total)
+        e = hipMemcpyAsync(base + off_bytes + chr_bytes, mask, total, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipMemcpyAsync(H2D)", e);
+    db->offsets = reinterpret_cast<const int64_t *>(base);
+    db->chars = reinterpret_cast<const uint8_t *>(base + off_bytes);
+    db->mask = mask ? reinterpret_cast<const uint8_t *>(base + off_bytes + chr_bytes) : nullptr;
+    return BSQ_OK;
+}
+
+template <typename Launch>
+bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask,
+                    int64_t B, int64_t P, int32_t bos, int32_t eos, size_t out_bytes, void *out,
+                    bsq_space out_space, void *hip_stream, int64_t *first_bad, Launch launch) {
+    if (first_bad) *first_bad = -1;
+    if (!d || !offsets || !out || B < 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer or B < 0");
+    if (P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "batch tokenize requires padlen is provded.");
+    int64_t bad = -1;
+    bsq_status st = bsq_validate_lengths(offsets, B, P, bos, eos, &bad);
+    if (first_bad) *first_bad = bad;
+    if (st != BSQ_OK) return bsq_internal::set_error(st, bsq_strerror(st));
+    if (B > 0 && offsets[B] > 0 && !chars) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "chars is null");
+
+    std::lock_guard<std::mutex> lock(g_mu);
+    Staging *sp = nullptr;
+    st = current_staging(&sp);
+    if (st != BSQ_OK) return st;
+    Staging &s = *sp;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (out_bytes == 0 || B == 0) return BSQ_OK;
+    // Wait for the previous call that used the staging buffers -- unless the caller packed this
+    // batch into the pinned scratch itself, in which case bsq_pinned_scratch() already waited.
+    if (!in_pinned(s, offsets)) {
+        st = wait_idle(s);
+        if (st != BSQ_OK) return st;
+    }
+    DeviceBatch db;
+    st = upload(s, chars, offsets, mask, B, stream, &db);
+    if (st != BSQ_OK) return st;
+    void *dev_out = out;
+    if (out_space == BSQ_SPACE_HOST) {
+        st = grow_device(&s.d_out, &s.d_out_cap, out_bytes);
+        if (st != BSQ_OK) return st;
+        dev_out = s.d_out;
+    }
+    st = launch(db, dev_out, stream);
+    if (st != BSQ_OK) return st;
+    hipError_t e = hipSuccess;
+    if (out_space == BSQ_SPACE_HOST) {
+        e = hipMemcpyAsync(out, dev_out, out_bytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("D2H copy of the result", e);
+    } else {
+        e = hipEventRecord(s.busy, stream);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("hipEventRecord", e);
+        s.busy_pending = true;
+    }
+    return BSQ_OK;
+}
+
+}  // namespace
+
+namespace bsq_internal {
+
+bsq_status set_error(bsq_status st, const char *msg) {
+    t_last_error = msg ? msg : "";
+    return st;
+}
+
+bsq_status set_hip_error(const char *what, hipError_t e) {
+    t_last_error = std::string(what ? what : "HIP") + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? BSQ_ERR_NO_DEVICE : BSQ_ERR_HIP;
+}
+
+bool nontemporal_stores() {
+    static const bool v = [] {
+        const char *e = std::getenv("BSQ_NT_STORES");
+        return e && *e && *e != '0';
+    }();
+    return v;
+}
+
+}  // namespace bsq_internal
+
+extern "C" {
+
+const char *bsq_last_error(void) { return t_last_error.c_str(); }
+
+int32_t bsq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void *bsq_pinned_scratch(size_t nbytes) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Staging *sp = nullptr;
+    if (current_staging(&sp) != BSQ_OK) return nullptr;
+    Staging &s = *sp;
+    if (wait_idle(s) != BSQ_OK) return nullptr;
+    if (nbytes > s.pinned_cap) {
+        if (s.pinned) (void)hipHostFree(s.pinned);
+        s.pinned = nullptr;
+        s.pinned_cap = 0;
+        const size_t want = round_up(nbytes + nbytes / 4, size_t(1) << 20);
+        const hipError_t e = hipHostMalloc(&s.pinned, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            bsq_internal::set_hip_error("hipHostMalloc", e);
+            return nullptr;
+        }
+        s.pinned_cap = want;
+    }
+    return s.pinned;
+}
+
+void bsq_release_staging(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (Staging &s : g_staging) {
+        if (s.device < 0) continue;
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(s.device);
+        if (s.busy_pending) (void)hipEventSynchronize(s.busy);
+        if (s.pinned) (void)hipHostFree(s.pinned);
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.busy) (void)hipEventDestroy(s.busy);
+        (void)hipSetDevice(prev);
+        s = Staging();
+    }
+}
+
+bsq_status bsq_tokenize_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B,
+                             int64_t P, int32_t batch_first, bsq_dtype t, void *out, bsq_space out_space,
+                             void *hip_stream, int64_t *first_bad) {
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    const size_t out_bytes = (B > 0 && P > 0) ? size_t(B) * size_t(P) * sz : 0;
+    return run_host(d, chars, offsets, nullptr, B, P, d ? d->bos : 0, d ? d->eos : 0, out_bytes, out, out_space,
+                    hip_stream, first_bad, [&](const DeviceBatch &db, void *dev_out, hipStream_t s) {
+                        return bsq_tokenize_device(d, db.chars, db.offsets, B, P, batch_first, t, dev_out, s);
+                    });
+}
+
+bsq_status bsq_onehot_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                           const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                           bsq_space out_space, void *hip_stream, int64_t *first_bad) {
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    const size_t C = d ? size_t(bsq_alphabet_size(d)) : 0;
+    const size_t out_bytes = (B > 0 && P > 0) ? size_t(P) * size_t(B) * C * sz : 0;
+    return run_host(d, chars, offsets, mask_or_null, B, P, d ? d->bos : 0, d ? d->eos : 0, out_bytes, out,
+                    out_space, hip_stream, first_bad, [&](const DeviceBatch &db, void *dev_out, hipStream_t s) {
+                        return bsq_onehot_device(d, db.chars, db.offsets, db.mask, B, P, t, dev_out, s);
+                    });
+}
+
+}  // extern "C"

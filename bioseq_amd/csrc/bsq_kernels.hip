@@ -1,0 +1,682 @@
+// HIP kernels of libbsq_hip.so, written for gfx950 (MI355X / CDNA4) only.
+//
+// The path is byte-LUT + streaming stores: HBM-bound, no MFMA.  Traffic per call is
+//     sum(L) chars + 8(B+1) offsets  read once,   P*B*C'*sizeof(T) output  written once
+// and the one-hot output is ~150x the input, so everything is organised around the WRITE side:
+// every output element is produced exactly once by a 16-byte coalesced store, there is no
+// memset pass and no scattered store to global memory (the reference's structure,
+// /root/reference/src/tokenize.h:332 + :342-369, is memset + one 4-byte scattered store per
+// residue at stride B*C*sizeof(T)).
+//
+// Kernel inventory
+//   k_onehot_tile      (P,B,C) one-hot.  A workgroup owns a tile of TB sequences x 64 positions:
+//                      phase 1 resolves the tile's tokens into LDS (coalesced uint32 reads of the
+//                      packed characters, alphabet LUT in LDS, BOS/EOS/PAD/mask folded in);
+//                      phase 2: each wave owns 16 of the 64 rows and a private LDS image of one
+//                      output row segment (TB*C elements).  Per row it scatters TB "ones" into the
+//                      image (one ds_write per sequence), streams the image out with ds_read_b128 ->
+//                      global_store_dwordx4, and clears the TB ones again.  No per-element VALU.
+//   k_tokenize_rows    (B,P) tokens: one wave per sequence row, 4 characters per lane per step.
+//   k_tokenize_tile    (P,B) tokens: same phase 1 as k_onehot_tile, transposed write through LDS.
+//   k_*_generic        one thread per output element; any shape / alignment / alphabet (BYTES has
+//                      ids > 255).  Fallback and in-library cross-check of the tiled kernels.
+//   k_fill             write-bandwidth yardstick.
+//   k_first_too_long   device-side length validation.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bsq.h"
+#include "bsq_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;         // 4 waves of 64
+constexpr int kTT = 64;               // positions per tile
+constexpr int kTokStride = kTT + 4;   // bytes per sequence row of the LDS token tile (17 dwords:
+                                      // odd dword stride -> column reads hit 32 distinct banks)
+constexpr uint32_t kNone = 0xFFu;     // "no token": all-zero one-hot row / token value 0
+
+struct KParams {
+    int8_t lut[256];
+    const uint8_t *chars;
+    const int64_t *offsets;
+    const uint8_t *mask;  // may be null
+    void *out;
+    int64_t B;
+    int64_t P;
+    int32_t C;        // one-hot channels
+    int32_t bos;      // 0/1
+    int32_t eos;      // 0/1
+    int32_t bos_id;
+    int32_t eos_id;
+    int32_t fill_id;  // token of positions >= L+bos+eos: pad id, or kNone without padchar
+    int32_t ntb;      // number of sequence tiles
+    int32_t aligned;  // 1: every output row segment is 16-byte aligned -> vector stores
+    uint64_t one_bits;
+};
+
+// Aligned dword load through the GLOBAL address space (a pointer rebuilt from an integer would
+// otherwise be a flat pointer and cost a flat_load + lgkmcnt wait).
+typedef const __attribute__((address_space(1))) uint32_t *global_u32_ptr;
+__device__ __forceinline__ uint32_t load_u32_aligned(uintptr_t addr) {
+    return *reinterpret_cast<global_u32_ptr>(addr);
+}
+
+// Four consecutive bytes starting at the arbitrary address `x`, of which only [lo, hi) are
+// needed (and valid).  Reads at most the two naturally aligned words that contain a needed byte,
+// so it never touches a word that lies wholly outside the caller's buffer.
+__device__ __forceinline__ uint32_t load4_unaligned(uintptr_t x, uintptr_t lo, uintptr_t hi) {
+    const uintptr_t w0 = x & ~uintptr_t(3);
+    uint32_t a = 0, b = 0;
+    if (lo < w0 + 4) a = load_u32_aligned(w0);
+    if (hi > w0 + 4) b = load_u32_aligned(w0 + 4);
+    return __builtin_amdgcn_alignbyte(b, a, static_cast<uint32_t>(x & 3));
+}
+
+// Tokens of positions tpos..tpos+3 of one sequence, packed little-endian into a dword.
+// s_lut holds the alphabet table with unmapped == kNone.  Semantics follow
+// /root/reference/src/tokenize.h:342-369 (one-hot) and :454-479 (tokens):
+//   pos 0 -> BOS (if bos); pos bos+j -> lut[s[j]] (mask==0 or unmapped -> none);
+//   pos bos+L -> EOS (if eos); later positions -> PAD id (if padchar) or none.
+struct TokenRule {
+    uintptr_t chars, mask;  // mask == 0: none
+    int32_t bos;
+    uint32_t bos_id, at_len_id, fill_id;  // ids at position 0 (BOS), bos+L (EOS or fill) and beyond
+};
+__device__ __forceinline__ TokenRule make_rule(const KParams &k) {
+    TokenRule r;
+    r.chars = reinterpret_cast<uintptr_t>(k.chars);
+    r.mask = reinterpret_cast<uintptr_t>(k.mask);
+    r.bos = k.bos;
+    r.bos_id = static_cast<uint32_t>(k.bos_id);
+    r.fill_id = static_cast<uint32_t>(k.fill_id);
+    r.at_len_id = k.eos ? static_cast<uint32_t>(k.eos_id) : r.fill_id;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t resolve4(const TokenRule p, const uint8_t *s_lut, int64_t start, int32_t L,
+                                             int32_t tpos) {
+    const int32_t j0 = tpos - p.bos;  // character index of the first position (-1 only for BOS)
+    uint32_t cw = 0, mw = 0xFFFFFFFFu;
+    if (j0 + 4 > 0 && j0 < L) {
+        const uintptr_t base = p.chars + static_cast<uintptr_t>(start);
+        const int32_t jlo = j0 < 0 ? 0 : j0;
+        const int32_t jhi = (j0 + 4 < L) ? j0 + 4 : L;
+        cw = load4_unaligned(base + j0, base + jlo, base + jhi);
+        if (p.mask) {
+            const uintptr_t mbase = p.mask + static_cast<uintptr_t>(start);
+            mw = load4_unaligned(mbase + j0, mbase + jlo, mbase + jhi);
+        }
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int32_t j = j0 + i;
+        uint32_t tk = s_lut[(cw >> (8 * i)) & 0xFFu];
+        if (((mw >> (8 * i)) & 0xFFu) == 0) tk = kNone;
+        if (j >= L) tk = (j == L) ? p.at_len_id : p.fill_id;
+        if (j < 0) tk = p.bos_id;
+        packed |= (tk & 0xFFu) << (8 * i);
+    }
+    return packed;
+}
+
+__device__ __forceinline__ void stage_lut(const KParams &p, uint8_t *s_lut) {
+    // bytes >= 0x80 and negative table entries are unmapped
+    const int i = threadIdx.x;
+    if (i < 256) {
+        const int8_t v = p.lut[i];
+        s_lut[i] = (i < 128 && v >= 0) ? static_cast<uint8_t>(v) : static_cast<uint8_t>(kNone);
+    }
+}
+
+__device__ __forceinline__ int32_t clamp_len(const KParams &p, int64_t len) {
+    const int64_t room = p.P - p.bos - p.eos;  // memory safety only; callers validate beforehand
+    return static_cast<int32_t>(len < 0 ? 0 : (len > room ? (room < 0 ? 0 : room) : len));
+}
+
+// Phase 1 shared by the tiled kernels: s_tok[sb * kTokStride + tl] = token of sequence b0+sb at
+// position t0+tl, for sb < TB, tl < 64.  Sequences past the end of the batch get kNone.
+template <int TB>
+__device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, int32_t t0, uint8_t *s_lut,
+                                                 int64_t *s_off, uint8_t *s_tok) {
+    const int tid = threadIdx.x;
+    const TokenRule rule = make_rule(p);
+    stage_lut(p, s_lut);
+    for (int i = tid; i <= TB; i += kThreads) {
+        const int64_t b = b0 + i;
+        s_off[i] = p.offsets[b <= p.B ? b : p.B];
+    }
+    __syncthreads();
+    const int g = tid & 15;  // 16 lanes x 4 characters cover the 64 positions of one sequence
+    for (int sb = tid >> 4; sb < TB; sb += kThreads / 16) {
+        uint32_t packed = kNone * 0x01010101u;
+        if (b0 + sb < p.B) {
+            const int64_t start = s_off[sb];
+            const int32_t L = clamp_len(p, s_off[sb + 1] - start);
+            packed = resolve4(rule, s_lut, start, L, t0 + 4 * g);
+        }
+        *reinterpret_cast<uint32_t *>(s_tok + sb * kTokStride + 4 * g) = packed;
+    }
+    __syncthreads();
+}
+
+template <bool NT>
+__device__ __forceinline__ void store16(void *dst, const uint4 &v) {
+    if constexpr (NT) {
+        __builtin_nontemporal_store(v.x, reinterpret_cast<uint32_t *>(dst) + 0);
+        __builtin_nontemporal_store(v.y, reinterpret_cast<uint32_t *>(dst) + 1);
+        __builtin_nontemporal_store(v.z, reinterpret_cast<uint32_t *>(dst) + 2);
+        __builtin_nontemporal_store(v.w, reinterpret_cast<uint32_t *>(dst) + 3);
+    } else {
+        *reinterpret_cast<uint4 *>(dst) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One-hot, tiled.  Dynamic LDS layout:
+//   [0, off_bytes)              int64 offsets of the tile's sequences (+1)
+//   [.., +256)                  alphabet LUT
+//   [.., +TB*kTokStride)        token tile
+//   [.., +4*row_pad)            one row image per wave (row_pad = TB*C*sizeof(ST) rounded to 16)
+// ------------------------------------------------------------------------------------------
+template <int TB>
+__host__ __device__ constexpr int tile_off_bytes() {
+    return ((TB + 1) * 8 + 15) & ~15;
+}
+template <int TB>
+__host__ __device__ constexpr int tile_fixed_bytes() {
+    return tile_off_bytes<TB>() + 256 + TB * kTokStride;
+}
+
+template <typename ST, int TB, bool NT>
+__global__ __launch_bounds__(kThreads) void k_onehot_tile(const KParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    int64_t *s_off = reinterpret_cast<int64_t *>(smem);
+    uint8_t *s_lut = smem + tile_off_bytes<TB>();
+    uint8_t *s_tok = s_lut + 256;
+    uint8_t *s_rows = s_tok + TB * kTokStride;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int32_t tb = static_cast<int32_t>(blockIdx.x % static_cast<uint32_t>(p.ntb));
+    const int32_t tt = static_cast<int32_t>(blockIdx.x / static_cast<uint32_t>(p.ntb));
+    const int64_t b0 = static_cast<int64_t>(tb) * TB;
+    const int32_t t0 = tt * kTT;
+
+    const int32_t C = p.C;
+    const int32_t row_pad = (TB * C * static_cast<int32_t>(sizeof(ST)) + 15) & ~15;
+    uint8_t *row = s_rows + wave * row_pad;
+    // zero this wave's row image while the tile's characters are in flight
+    for (int32_t o = lane * 16; o < row_pad; o += 64 * 16) *reinterpret_cast<uint4 *>(row + o) = uint4{0, 0, 0, 0};
+
+    build_token_tile<TB>(p, b0, t0, s_lut, s_off, s_tok);
+
+    const int64_t nb64 = p.B - b0;
+    const int32_t nb = nb64 < TB ? static_cast<int32_t>(nb64) : TB;
+    const int32_t seg = nb * C * static_cast<int32_t>(sizeof(ST));  // bytes of one output row segment
+    const ST one = static_cast<ST>(p.one_bits);
+    const int64_t row_pitch = p.B * C * static_cast<int64_t>(sizeof(ST));
+    uint8_t *gtile = static_cast<uint8_t *>(p.out) + b0 * C * static_cast<int64_t>(sizeof(ST));
+
+    constexpr int kRowsPerWave = kTT / 4;
+    constexpr int kSeqPerLane = TB / 64;
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const int32_t tl = wave * kRowsPerWave + r;
+        const int64_t t = static_cast<int64_t>(t0) + tl;
+        if (t >= p.P) break;  // wave-uniform
+        // 1. scatter the ones of this row into the wave's LDS image
+        int32_t hot[kSeqPerLane];
+#pragma unroll
+        for (int q = 0; q < kSeqPerLane; ++q) {
+            const int32_t sb = lane + 64 * q;
+            const uint32_t tk = s_tok[sb * kTokStride + tl];
+            hot[q] = (tk != kNone) ? (sb * C + static_cast<int32_t>(tk)) * static_cast<int32_t>(sizeof(ST)) : -1;
+            if (hot[q] >= 0) *reinterpret_cast<ST *>(row + hot[q]) = one;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 2. stream the image to global memory
+        uint8_t *grow = gtile + t * row_pitch;
+        if (p.aligned) {
+            for (int32_t o = lane * 16; o < seg; o += 4 * 1024) {  // up to 4 x 1 KiB per wave per step
+                const bool c1 = o + 1024 < seg, c2 = o + 2048 < seg, c3 = o + 3072 < seg;
+                const uint4 z{0, 0, 0, 0};
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(row + o);
+                const uint4 v1 = c1 ? *reinterpret_cast<const uint4 *>(row + o + 1024) : z;
+                const uint4 v2 = c2 ? *reinterpret_cast<const uint4 *>(row + o + 2048) : z;
+                const uint4 v3 = c3 ? *reinterpret_cast<const uint4 *>(row + o + 3072) : z;
+                store16<NT>(grow + o, v0);
+                if (c1) store16<NT>(grow + o + 1024, v1);
+                if (c2) store16<NT>(grow + o + 2048, v2);
+                if (c3) store16<NT>(grow + o + 3072, v3);
+            }
+        } else {
+            for (int32_t o = lane * static_cast<int32_t>(sizeof(ST)); o < seg; o += 64 * static_cast<int32_t>(sizeof(ST)))
+                *reinterpret_cast<ST *>(grow + o) = *reinterpret_cast<const ST *>(row + o);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 3. clear the ones again
+#pragma unroll
+        for (int q = 0; q < kSeqPerLane; ++q)
+            if (hot[q] >= 0) *reinterpret_cast<ST *>(row + hot[q]) = ST(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tokens, (P,B) layout, tiled: phase 1 as above, then a transposed read of the token tile.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T token_value(uint32_t tk) {
+    return tk == kNone ? T(0) : static_cast<T>(tk);  // unmapped / unpadded positions keep the memset 0
+}
+
+template <typename T, int TB>
+__global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    int64_t *s_off = reinterpret_cast<int64_t *>(smem);
+    uint8_t *s_lut = smem + tile_off_bytes<TB>();
+    uint8_t *s_tok = s_lut + 256;
+
+    const int tid = threadIdx.x;
+    const int32_t tb = static_cast<int32_t>(blockIdx.x % static_cast<uint32_t>(p.ntb));
+    const int32_t tt = static_cast<int32_t>(blockIdx.x / static_cast<uint32_t>(p.ntb));
+    const int64_t b0 = static_cast<int64_t>(tb) * TB;
+    const int32_t t0 = tt * kTT;
+    build_token_tile<TB>(p, b0, t0, s_lut, s_off, s_tok);
+
+    constexpr int EPC = 16 / static_cast<int>(sizeof(T));  // elements per 16-byte chunk
+    constexpr int CPR = TB / EPC;                          // chunks per row segment
+    T *out = static_cast<T *>(p.out);
+    for (int f = tid; f < kTT * CPR; f += kThreads) {
+        const int32_t tl = f / CPR, q = f % CPR;
+        const int64_t t = static_cast<int64_t>(t0) + tl;
+        if (t >= p.P) continue;
+        const int32_t sb0 = q * EPC;
+        alignas(16) T vals[EPC];
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) vals[i] = token_value<T>(s_tok[(sb0 + i) * kTokStride + tl]);
+        T *dst = out + t * p.B + b0 + sb0;
+        if (p.aligned && b0 + sb0 + EPC <= p.B) {
+            *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(vals);
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPC; ++i)
+                if (b0 + sb0 + i < p.B) dst[i] = vals[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tokens, (B,P) layout: one wave per sequence, 4 positions per lane per step, no transpose.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_tokenize_rows(const KParams p) {
+    __shared__ __align__(16) uint8_t s_lut[256];
+    const TokenRule rule = make_rule(p);
+    stage_lut(p, s_lut);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (b >= p.B) return;
+    const int64_t start = p.offsets[b];
+    const int32_t L = clamp_len(p, p.offsets[b + 1] - start);
+    T *orow = static_cast<T *>(p.out) + b * p.P;
+    const int32_t P = static_cast<int32_t>(p.P);
+    for (int32_t tpos = 4 * lane; tpos < P; tpos += 256) {
+        const uint32_t packed = resolve4(rule, s_lut, start, L, tpos);
+        alignas(16) T vals[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vals[i] = token_value<T>((packed >> (8 * i)) & 0xFFu);
+        if (p.aligned && tpos + 4 <= P) {
+            if constexpr (sizeof(T) == 1) {
+                *reinterpret_cast<uint32_t *>(orow + tpos) = *reinterpret_cast<const uint32_t *>(vals);
+            } else if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint2 *>(orow + tpos) = *reinterpret_cast<const uint2 *>(vals);
+            } else if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<uint4 *>(orow + tpos) = *reinterpret_cast<const uint4 *>(vals);
+            } else {
+                reinterpret_cast<uint4 *>(orow + tpos)[0] = reinterpret_cast<const uint4 *>(vals)[0];
+                reinterpret_cast<uint4 *>(orow + tpos)[1] = reinterpret_cast<const uint4 *>(vals)[1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tpos + i < P) orow[tpos + i] = vals[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic one-thread-per-element kernels (ids up to 258, any alignment).
+// ------------------------------------------------------------------------------------------
+struct GParams {
+    int8_t lut[256];
+    const uint8_t *chars;
+    const int64_t *offsets;
+    const uint8_t *mask;
+    void *out;
+    int64_t B, P;
+    int32_t C, bos, eos, bos_id, eos_id, pad_id, padchar, batch_first;
+};
+
+__device__ __forceinline__ int32_t token_at(const GParams &p, int64_t b, int64_t t) {
+    const int64_t start = p.offsets[b];
+    int64_t L = p.offsets[b + 1] - start;
+    const int64_t room = p.P - p.bos - p.eos;
+    if (L > room) L = room;
+    if (L < 0) L = 0;
+    if (p.bos && t == 0) return p.bos_id;
+    const int64_t j = t - p.bos;
+    if (j < L) {
+        if (p.mask && p.mask[start + j] == 0) return -1;
+        const uint8_t c = p.chars[start + j];
+        return c < 128 ? static_cast<int32_t>(p.lut[c]) : -1;  // negative == unmapped
+    }
+    if (p.eos && j == L) return p.eos_id;
+    return p.padchar ? p.pad_id : -1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_onehot_generic(const GParams p) {
+    const int64_t n = p.P * p.B * p.C;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    T *out = static_cast<T *>(p.out);
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; e < n; e += stride) {
+        const int64_t r = e / p.C;
+        const int32_t c = static_cast<int32_t>(e - r * p.C);
+        const int64_t t = r / p.B, b = r - t * p.B;
+        const int32_t tk = token_at(p, b, t);
+        out[e] = (tk == c) ? T(1) : T(0);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_tokenize_generic(const GParams p) {
+    const int64_t n = p.P * p.B;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    T *out = static_cast<T *>(p.out);
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; e < n; e += stride) {
+        int64_t b, t;
+        if (p.batch_first) {
+            b = e / p.P;
+            t = e - b * p.P;
+        } else {
+            t = e / p.B;
+            b = e - t * p.B;
+        }
+        const int32_t tk = token_at(p, b, t);
+        out[e] = tk >= 0 ? static_cast<T>(tk) : T(0);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_fill(uint4 *dst, size_t n16, uint32_t pattern) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    const uint4 v{pattern, pattern, pattern, pattern};
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n16; i += stride) dst[i] = v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offsets, int64_t B, int64_t room,
+                                                             unsigned long long *first_bad) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < B; i += stride)
+        if (offsets[i + 1] - offsets[i] > room) atomicMin(first_bad, static_cast<unsigned long long>(i));
+}
+
+// ------------------------------------------------------------------------------------------
+// Launch helpers
+// ------------------------------------------------------------------------------------------
+bsq_status check_launch(const char *what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return bsq_internal::set_hip_error(what, e);
+    return BSQ_OK;
+}
+
+uint64_t one_bits_of(bsq_dtype t) {
+    switch (t) {
+    case BSQ_F32: return 0x3F800000ull;
+    case BSQ_F64: return 0x3FF0000000000000ull;
+    default: return 1ull;
+    }
+}
+
+bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                       const uint8_t *mask, int64_t B, int64_t P, void *out) {
+    if (!d || !offsets || !out || B < 0 || P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
+    if (P > (int64_t(1) << 30)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "padlen > 2^30 is not supported");
+    for (int i = 0; i < 256; ++i) k.lut[i] = d->lut[i];
+    k.chars = chars;
+    k.offsets = offsets;
+    k.mask = mask;
+    k.out = out;
+    k.B = B;
+    k.P = P;
+    k.C = bsq_alphabet_size(d);
+    k.bos = d->bos;
+    k.eos = d->eos;
+    k.bos_id = bsq_bos_id(d);
+    k.eos_id = bsq_eos_id(d);
+    k.fill_id = d->padchar ? bsq_pad_id(d) : static_cast<int32_t>(kNone);
+    k.ntb = 1;
+    k.aligned = 0;
+    k.one_bits = 1;
+    return BSQ_OK;
+}
+
+void fill_generic(GParams &g, const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask,
+                  int64_t B, int64_t P, int batch_first, void *out) {
+    for (int i = 0; i < 256; ++i) g.lut[i] = d->lut[i];
+    g.chars = chars;
+    g.offsets = offsets;
+    g.mask = mask;
+    g.out = out;
+    g.B = B;
+    g.P = P;
+    g.C = bsq_alphabet_size(d);
+    g.bos = d->bos;
+    g.eos = d->eos;
+    g.bos_id = bsq_bos_id(d);
+    g.eos_id = bsq_eos_id(d);
+    g.pad_id = bsq_pad_id(d);
+    g.padchar = d->padchar;
+    g.batch_first = batch_first;
+}
+
+unsigned generic_grid(int64_t n) {
+    const int64_t blocks = (n + kThreads - 1) / kThreads;
+    const int64_t cap = 256 * 32;
+    return static_cast<unsigned>(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+template <typename ST, int TB>
+bsq_status launch_onehot_tile(const KParams &k, hipStream_t s) {
+    const int row_pad = (TB * k.C * int(sizeof(ST)) + 15) & ~15;
+    const size_t smem = tile_fixed_bytes<TB>() + 4 * size_t(row_pad);
+    const int64_t ntt = (k.P + kTT - 1) / kTT;
+    const int64_t grid = int64_t(k.ntb) * ntt;
+    if (bsq_internal::nontemporal_stores())
+        hipLaunchKernelGGL((k_onehot_tile<ST, TB, true>), dim3(unsigned(grid)), dim3(kThreads), smem, s, k);
+    else
+        hipLaunchKernelGGL((k_onehot_tile<ST, TB, false>), dim3(unsigned(grid)), dim3(kThreads), smem, s, k);
+    return check_launch("k_onehot_tile");
+}
+
+template <typename ST>
+bsq_status dispatch_onehot_tile(KParams &k, hipStream_t s) {
+    // Row segment = TB*C*sizeof(ST) bytes of contiguous output per (tile,row): keep it >= 2 KiB.
+    const int seg64 = 64 * k.C * int(sizeof(ST));
+    if (seg64 >= 2048) {
+        k.ntb = int32_t((k.B + 63) / 64);
+        return launch_onehot_tile<ST, 64>(k, s);
+    }
+    k.ntb = int32_t((k.B + 255) / 256);
+    return launch_onehot_tile<ST, 256>(k, s);
+}
+
+template <typename T, int TB>
+bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
+    k.ntb = int32_t((k.B + TB - 1) / TB);
+    const int64_t ntt = (k.P + kTT - 1) / kTT;
+    const size_t smem = tile_fixed_bytes<TB>();
+    hipLaunchKernelGGL((k_tokenize_tile<T, TB>), dim3(unsigned(int64_t(k.ntb) * ntt)), dim3(kThreads), smem, s, k);
+    return check_launch("k_tokenize_tile");
+}
+
+}  // namespace
+
+extern "C" {
+
+bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                             const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                             void *hip_stream) {
+    KParams k;
+    bsq_status st = fill_common(k, d, chars, offsets, mask_or_null, B, P, out);
+    if (st != BSQ_OK) return st;
+    if (B == 0) return BSQ_OK;
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    // Tiled kernel limits: 8-bit token ids, 32-bit tile arithmetic, row images must fit in LDS.
+    const int64_t ntiles = ((B + 63) / 64) * ((P + kTT - 1) / kTT);
+    const bool tiled_ok = k.C <= 250 && 4 * (64 * k.C * int64_t(sz) + 16) + tile_fixed_bytes<64>() <= 60 * 1024 &&
+                          ntiles < (int64_t(1) << 31) && B < (int64_t(1) << 31) - 256;
+    if (!tiled_ok) return bsq_onehot_device_generic(d, chars, offsets, mask_or_null, B, P, t, out, hip_stream);
+    k.one_bits = one_bits_of(t);
+    const int64_t pitch = B * k.C * int64_t(sz);
+    k.aligned = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (pitch % 16 == 0);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    switch (sz) {
+    case 1: return dispatch_onehot_tile<uint8_t>(k, s);
+    case 2: return dispatch_onehot_tile<uint16_t>(k, s);
+    case 4: return dispatch_onehot_tile<uint32_t>(k, s);
+    default: return dispatch_onehot_tile<uint64_t>(k, s);
+    }
+}
+
+bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B,
+                               int64_t P, int32_t batch_first, bsq_dtype t, void *out, void *hip_stream) {
+    KParams k;
+    bsq_status st = fill_common(k, d, chars, offsets, nullptr, B, P, out);
+    if (st != BSQ_OK) return st;
+    if (B == 0) return BSQ_OK;
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    if (k.C > 250 || B >= (int64_t(1) << 31) - 1024)
+        return bsq_tokenize_device_generic(d, chars, offsets, B, P, batch_first, t, out, hip_stream);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(out);
+    if (batch_first) {
+        const size_t vec = sz * 4 > 16 ? 16 : sz * 4;  // widest store used by k_tokenize_rows
+        k.aligned = (addr % vec == 0) && ((P * int64_t(sz)) % int64_t(vec) == 0);
+        const unsigned grid = unsigned((B + 3) / 4);
+#define BSQ_ROWS(T) hipLaunchKernelGGL((k_tokenize_rows<T>), dim3(grid), dim3(kThreads), 0, s, k)
+        switch (t) {
+        case BSQ_I8: BSQ_ROWS(int8_t); break;
+        case BSQ_I16: BSQ_ROWS(int16_t); break;
+        case BSQ_I32: BSQ_ROWS(int32_t); break;
+        case BSQ_U64: BSQ_ROWS(uint64_t); break;
+        case BSQ_F32: BSQ_ROWS(float); break;
+        case BSQ_F64: BSQ_ROWS(double); break;
+        }
+#undef BSQ_ROWS
+        return check_launch("k_tokenize_rows");
+    }
+    k.aligned = (addr % 16 == 0) && ((B * int64_t(sz)) % 16 == 0);
+    switch (t) {
+    case BSQ_I8: return launch_tokenize_tile<int8_t, 256>(k, s);
+    case BSQ_I16: return launch_tokenize_tile<int16_t, 128>(k, s);
+    case BSQ_I32: return launch_tokenize_tile<int32_t, 64>(k, s);
+    case BSQ_U64: return launch_tokenize_tile<uint64_t, 64>(k, s);
+    case BSQ_F32: return launch_tokenize_tile<float, 64>(k, s);
+    case BSQ_F64: return launch_tokenize_tile<double, 64>(k, s);
+    }
+    return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+}
+
+bsq_status bsq_onehot_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                     const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                                     void *hip_stream) {
+    if (!d || !offsets || !out || B < 0 || P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
+    if (B == 0) return BSQ_OK;
+    GParams g;
+    fill_generic(g, d, chars, offsets, mask_or_null, B, P, 0, out);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const unsigned grid = generic_grid(P * B * g.C);
+#define BSQ_GEN(T) hipLaunchKernelGGL((k_onehot_generic<T>), dim3(grid), dim3(kThreads), 0, s, g)
+    switch (t) {
+    case BSQ_I8: BSQ_GEN(int8_t); break;
+    case BSQ_I16: BSQ_GEN(int16_t); break;
+    case BSQ_I32: BSQ_GEN(int32_t); break;
+    case BSQ_U64: BSQ_GEN(uint64_t); break;
+    case BSQ_F32: BSQ_GEN(float); break;
+    case BSQ_F64: BSQ_GEN(double); break;
+    default: return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    }
+#undef BSQ_GEN
+    return check_launch("k_onehot_generic");
+}
+
+bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                       int64_t B, int64_t P, int32_t batch_first, bsq_dtype t, void *out,
+                                       void *hip_stream) {
+    if (!d || !offsets || !out || B < 0 || P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
+    if (B == 0) return BSQ_OK;
+    GParams g;
+    fill_generic(g, d, chars, offsets, nullptr, B, P, batch_first != 0, out);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const unsigned grid = generic_grid(P * B);
+#define BSQ_GEN(T) hipLaunchKernelGGL((k_tokenize_generic<T>), dim3(grid), dim3(kThreads), 0, s, g)
+    switch (t) {
+    case BSQ_I8: BSQ_GEN(int8_t); break;
+    case BSQ_I16: BSQ_GEN(int16_t); break;
+    case BSQ_I32: BSQ_GEN(int32_t); break;
+    case BSQ_U64: BSQ_GEN(uint64_t); break;
+    case BSQ_F32: BSQ_GEN(float); break;
+    case BSQ_F64: BSQ_GEN(double); break;
+    default: return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    }
+#undef BSQ_GEN
+    return check_launch("k_tokenize_generic");
+}
+
+bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip_stream) {
+    if (!dst || nbytes % 16 || reinterpret_cast<uintptr_t>(dst) % 16)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "fill needs a 16-byte aligned pointer and size");
+    if (nbytes == 0) return BSQ_OK;
+    const size_t n16 = nbytes / 16;
+    const size_t blocks = (n16 + kThreads - 1) / kThreads;
+    const unsigned grid = unsigned(blocks > 256 * 16 ? 256 * 16 : blocks);
+    hipLaunchKernelGGL(k_fill, dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(hip_stream),
+                       static_cast<uint4 *>(dst), n16, pattern);
+    return check_launch("k_fill");
+}
+
+bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos,
+                                       int32_t eos, int64_t *first_bad, void *hip_stream) {
+    if (!offsets_dev || B < 0 || P <= 0 || !first_bad) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
+    *first_bad = -1;
+    if (B == 0) return BSQ_OK;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    unsigned long long *flag = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&flag), sizeof(*flag));
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipMalloc", e);
+    e = hipMemsetAsync(flag, 0xFF, sizeof(*flag), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_first_too_long, dim3(generic_grid(B)), dim3(kThreads), 0, s, offsets_dev, B,
+                           P - (bos != 0) - (eos != 0), flag);
+        e = hipGetLastError();
+    }
+    unsigned long long host = ~0ull;
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(flag);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("bsq_validate_lengths_device", e);
+    if (host != ~0ull) {
+        *first_bad = static_cast<int64_t>(host);
+        return BSQ_ERR_SEQ_TOO_LONG;
+    }
+    return BSQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,619 @@
+// pybind11 host layer: the Python class `Tokenizer` with the surface of the reference's
+// `cbioseq.Tokenizer` (/root/reference/src/tokenize.cpp:22-112) and the thread knobs of
+// /root/reference/src/omp.cpp:27-32, implemented on top of the C ABI in include/bsq.h.
+//
+// All encoding work happens in libbsq_hip.so on the GPU.  This file only
+//   * gathers the str/bytes/bytearray items of a batch (GIL held, as in tokenize.h:389-419),
+//   * packs them into the library's pinned scratch as  offsets | chars | mask,
+//   * allocates the result (numpy array, or a torch tensor on `device=`) and calls the C ABI,
+//   * keeps the small host-only pieces of the class (ids, decode tables, pickle).
+// It does not link HIP or torch; torch is reached through its Python API for device memory and
+// the current stream only.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cctype>
+#include <cstring>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "bsq.h"
+
+namespace py = pybind11;
+
+namespace {
+
+std::atomic<int> g_threads{0};  // 0: hardware concurrency
+std::mutex g_pack_mu;           // pinned scratch is one buffer per device: pack + launch atomically
+
+// Take g_pack_mu with the GIL released (a thread that waits for the mutex while holding the GIL would
+// deadlock against the owner, which re-acquires the GIL after its GPU work).
+struct PackLock {
+    std::unique_lock<std::mutex> l;
+    PackLock() : l(g_pack_mu, std::defer_lock) {
+        py::gil_scoped_release nogil;
+        l.lock();
+    }
+};
+
+int default_threads() {
+    const int t = g_threads.load();
+    if (t > 0) return t;
+    const unsigned hc = std::thread::hardware_concurrency();
+    return hc ? int(hc) : 1;
+}
+
+[[noreturn]] void throw_status(bsq_status st, const std::string &extra = std::string()) {
+    std::string msg = extra.empty() ? std::string(bsq_strerror(st)) : extra;
+    const char *detail = bsq_last_error();
+    if (extra.empty() && detail && *detail && msg != detail) msg += std::string(": ") + detail;
+    switch (st) {
+    case BSQ_ERR_INVALID_ARG:
+    case BSQ_ERR_DTYPE:
+    case BSQ_ERR_SEQ_TOO_LONG: throw std::invalid_argument(msg);  // -> ValueError
+    default: throw std::runtime_error(msg);                       // -> RuntimeError
+    }
+}
+
+struct Item {
+    const char *ptr;
+    size_t len;
+};
+
+struct Gathered {
+    std::vector<Item> items;
+    std::vector<const uint8_t *> masks;  // empty when no mask list was given
+    std::vector<py::object> keep;        // temporaries that own converted buffers
+    size_t total = 0;
+    bool has_mask = false;
+};
+
+// Item acceptance of tokenize.h:292-322 / :389-419.  (The reference means to accept 8-bit numpy
+// arrays too but falls through to its error label; they are accepted here.)
+void gather(py::sequence batch, const py::object &mask, Gathered &g) {
+    py::object fast = py::reinterpret_steal<py::object>(PySequence_Fast(batch.ptr(), "batch must be a sequence"));
+    if (!fast) throw py::error_already_set();
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast.ptr());
+    PyObject **objs = PySequence_Fast_ITEMS(fast.ptr());
+    g.keep.push_back(fast);
+    g.items.reserve(size_t(n));
+    const bool mask_is_list = py::isinstance<py::list>(mask);  // anything else is ignored (tokenize.h:294)
+    py::list mlist;
+    if (mask_is_list) {
+        mlist = py::reinterpret_borrow<py::list>(mask);
+        g.masks.reserve(size_t(n));
+        g.has_mask = true;
+    }
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *o = objs[i];
+        Item it{nullptr, 0};
+        if (PyUnicode_Check(o)) {
+            Py_ssize_t sz = 0;
+            const char *s = PyUnicode_AsUTF8AndSize(o, &sz);
+            if (!s) throw py::error_already_set();
+            it = {s, size_t(sz)};
+        } else if (PyBytes_Check(o)) {
+            char *s = nullptr;
+            Py_ssize_t sz = 0;
+            if (PyBytes_AsStringAndSize(o, &s, &sz)) throw py::error_already_set();
+            it = {s, size_t(sz)};
+        } else if (PyByteArray_Check(o)) {
+            it = {PyByteArray_AS_STRING(o), size_t(PyByteArray_GET_SIZE(o))};
+        } else if (py::isinstance<py::array>(py::handle(o))) {
+            py::array a = py::reinterpret_borrow<py::array>(o);
+            if (a.itemsize() != 1 || (a.dtype().kind() != 'i' && a.dtype().kind() != 'u' && a.dtype().kind() != 'S'))
+                throw std::invalid_argument("item was none of string, bytes, or numpy array of 8-bit integers. ");
+            py::array c = py::array::ensure(a, py::array::c_style);
+            g.keep.push_back(c);
+            it = {static_cast<const char *>(c.data()), size_t(c.size())};
+        } else {
+            throw std::invalid_argument("item was none of string, bytes, or numpy array of 8-bit integers. ");
+        }
+        if (mask_is_list) {
+            const uint8_t *mp = nullptr;
+            if (size_t(i) >= mlist.size()) throw py::index_error("list index out of range");
+            py::object m = mlist[size_t(i)];
+            if (py::isinstance<py::array>(m)) {  // tokenize.h:372-380; other entries: sequence unmasked
+                py::array_t<uint8_t, py::array::forcecast | py::array::c_style> arr(m);
+                if (size_t(arr.size()) < it.len)
+                    throw std::invalid_argument("mask entry " + std::to_string(i) + " is shorter than its sequence");
+                g.keep.push_back(arr);
+                mp = arr.data();
+            }
+            g.masks.push_back(mp);
+        }
+        g.total += it.len;
+        g.items.push_back(it);
+    }
+}
+
+// Layout inside the pinned scratch.
+struct Packed {
+    int64_t *offsets = nullptr;
+    uint8_t *chars = nullptr;
+    uint8_t *mask = nullptr;
+    int64_t B = 0;
+};
+
+size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
+
+Packed pack(const Gathered &g, int nthreads) {
+    Packed p;
+    p.B = int64_t(g.items.size());
+    const size_t off_bytes = align_up(size_t(p.B + 1) * 8, 64);
+    const size_t chr_bytes = align_up(g.total + 8, 64);
+    const size_t need = off_bytes + chr_bytes * (g.has_mask ? 2 : 1);
+    char *base = static_cast<char *>(bsq_pinned_scratch(need));
+    if (!base) throw_status(bsq_device_count() > 0 ? BSQ_ERR_ALLOC : BSQ_ERR_NO_DEVICE);
+    p.offsets = reinterpret_cast<int64_t *>(base);
+    p.chars = reinterpret_cast<uint8_t *>(base + off_bytes);
+    p.mask = g.has_mask ? p.chars + chr_bytes : nullptr;
+    int64_t acc = 0;
+    for (int64_t i = 0; i < p.B; ++i) {
+        p.offsets[i] = acc;
+        acc += int64_t(g.items[size_t(i)].len);
+    }
+    p.offsets[p.B] = acc;
+    auto copy_range = [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const Item &it = g.items[size_t(i)];
+            if (it.len) std::memcpy(p.chars + p.offsets[i], it.ptr, it.len);
+            if (p.mask && it.len) {
+                if (g.masks[size_t(i)])
+                    std::memcpy(p.mask + p.offsets[i], g.masks[size_t(i)], it.len);
+                else
+                    std::memset(p.mask + p.offsets[i], 1, it.len);
+            }
+        }
+    };
+    if (nthreads <= 1 || g.total < (size_t(1) << 20) || p.B < 2 * nthreads) {
+        copy_range(0, p.B);
+    } else {  // workers touch raw bytes only; the caller keeps the GIL so the items stay alive
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back(copy_range, p.B * t / nthreads, p.B * (t + 1) / nthreads);
+        for (auto &x : th) x.join();
+    }
+    return p;
+}
+
+const char *numpy_dtype_name(bsq_dtype t) {
+    switch (t) {
+    case BSQ_I8: return "int8";
+    case BSQ_I16: return "int16";
+    case BSQ_I32: return "int32";
+    case BSQ_U64: return "uint64";
+    case BSQ_F32: return "float32";
+    default: return "float64";
+    }
+}
+
+bsq_dtype parse_dtype(const std::string &dt) {
+    bsq_dtype t;
+    if (dt.empty() || bsq_dtype_from_destchar(dt[0], &t) != BSQ_OK)
+        throw std::invalid_argument(std::string("Unsupported dtype: ") + dt);
+    return t;
+}
+
+// Result buffer: a numpy array (host) or a torch tensor on `device`.
+struct OutBuf {
+    py::object obj;
+    void *ptr = nullptr;
+    bsq_space space = BSQ_SPACE_HOST;
+    void *stream = nullptr;
+    py::object guard;  // torch.cuda.device(...) context, entered
+    ~OutBuf() {
+        if (guard) {
+            try {
+                guard.attr("__exit__")(py::none(), py::none(), py::none());
+            } catch (...) {
+            }
+        }
+    }
+};
+
+void make_out(OutBuf &o, const std::vector<py::ssize_t> &shape, bsq_dtype t, const py::object &device) {
+    if (device.is_none()) {
+        py::array a(py::dtype(numpy_dtype_name(t)), shape);
+        o.ptr = a.mutable_data();
+        o.obj = a;
+        o.space = BSQ_SPACE_HOST;
+        return;
+    }
+    py::module_ torch = py::module_::import("torch");
+    py::object dev = torch.attr("device")(device);
+    if (dev.attr("type").cast<std::string>() != "cuda")
+        throw std::invalid_argument("device= must be a HIP ('cuda') device; omit it for a numpy result");
+    o.guard = torch.attr("cuda").attr("device")(dev);
+    o.guard.attr("__enter__")();
+    py::object ten = torch.attr("empty")(py::cast(shape), py::arg("dtype") = torch.attr(numpy_dtype_name(t)),
+                                         py::arg("device") = dev);
+    o.ptr = reinterpret_cast<void *>(ten.attr("data_ptr")().cast<uintptr_t>());
+    o.stream = reinterpret_cast<void *>(torch.attr("cuda").attr("current_stream")().attr("cuda_stream").cast<uintptr_t>());
+    o.obj = ten;
+    o.space = BSQ_SPACE_DEVICE;
+}
+
+// A packed-batch argument: numpy array (host) or torch tensor on a HIP device.
+struct ArrayArg {
+    const void *ptr = nullptr;
+    int64_t n = 0;
+    bool on_device = false;
+    py::object keep;
+};
+
+ArrayArg as_array(const py::object &o, const char *np_dtype, size_t itemsize, const char *what) {
+    ArrayArg a;
+    if (py::hasattr(o, "data_ptr") && py::hasattr(o, "is_cuda")) {  // torch tensor
+        py::object t = o;
+        if (!t.attr("is_contiguous")().cast<bool>()) t = t.attr("contiguous")();
+        if (size_t(t.attr("element_size")().cast<int64_t>()) != itemsize)
+            throw std::invalid_argument(std::string(what) + ": wrong element size");
+        a.on_device = t.attr("is_cuda").cast<bool>();
+        a.ptr = reinterpret_cast<const void *>(t.attr("data_ptr")().cast<uintptr_t>());
+        a.n = t.attr("numel")().cast<int64_t>();
+        a.keep = t;
+        return a;
+    }
+    py::array arr = py::array::ensure(o, py::array::c_style);
+    if (!arr) throw std::invalid_argument(std::string(what) + ": expected a numpy array or torch tensor");
+    if (size_t(arr.itemsize()) != itemsize) {
+        arr = py::array::ensure(arr.attr("astype")(np_dtype), py::array::c_style);
+    }
+    a.ptr = arr.data();
+    a.n = int64_t(arr.size());
+    a.keep = arr;
+    return a;
+}
+
+class Tokenizer {
+  public:
+    bsq_desc desc{};
+    std::string key;
+    std::unordered_map<int32_t, std::string> lookup;     // token -> first byte / "<BOS>"...  (tokenize.h:83-99)
+    std::unordered_map<int32_t, std::string> tokensets;  // token -> every byte of the group
+    std::string token_map_str;
+
+    Tokenizer(std::string key_, bool eos, bool bos, bool padchar) : key(std::move(key_)) {
+        std::transform(key.begin(), key.end(), key.begin(), [](unsigned char c) { return char(std::toupper(c)); });
+        const bsq_status st = bsq_desc_init(&desc, key.c_str(), eos, bos, padchar);
+        if (st == BSQ_ERR_INVALID_KEY) {
+            std::string options;
+            for (int i = 0; i < bsq_num_keys(); ++i) options += std::string(bsq_key_name(i)) + ';';
+            throw std::runtime_error(std::string("Invalid tokenizer type; select one from") + options);
+        }
+        if (st != BSQ_OK) throw_status(st);
+        for (int32_t i = 0; i < 256; ++i) {
+            const int32_t value = desc.lut[i];
+            if (lookup.find(value) == lookup.end()) lookup[value] = std::string(1, char(i));
+            tokensets[value] += char(i);
+        }
+        if (desc.bos) lookup[bsq_bos_id(&desc)] = "<BOS>";
+        if (desc.eos) lookup[bsq_eos_id(&desc)] = "<EOS>";
+        if (desc.padchar) lookup[bsq_pad_id(&desc)] = "<PAD>";
+        for (const auto &kv : lookup) token_map_str += std::to_string(kv.first) + ':' + kv.second + ';';
+        if (!token_map_str.empty()) token_map_str.pop_back();
+    }
+
+    void check_padlen(py::ssize_t padlen) const {
+        if (padlen <= 0) throw std::invalid_argument("batch tokenize requires padlen is provded.");
+    }
+
+    [[noreturn]] void throw_too_long(const int64_t *offsets, int64_t bad, py::ssize_t padlen) const {
+        const int64_t tl = offsets[bad + 1] - offsets[bad] + desc.bos + desc.eos;
+        throw std::invalid_argument("seq len + bos + eos > padlen: " + std::to_string(tl) + ", vs padlen " +
+                                    std::to_string(padlen));
+    }
+
+    // batch_tokenize (tokenize.cpp:82-98 -> tokenize.h:381-485)
+    py::object batch_tokenize(py::sequence batch, py::ssize_t padlen, const std::string &dt, bool batch_first,
+                              int nthreads, const py::object &device) const {
+        const bsq_dtype t = parse_dtype(dt);
+        check_padlen(padlen);
+        if (nthreads <= 0) nthreads = 1;
+        Gathered g;
+        gather(batch, py::none(), g);
+        PackLock lock;
+        const Packed p = pack(g, nthreads);
+        OutBuf out;
+        make_out(out, batch_first ? std::vector<py::ssize_t>{p.B, padlen} : std::vector<py::ssize_t>{padlen, p.B}, t,
+                 device);
+        int64_t bad = -1;
+        bsq_status st;
+        {
+            py::gil_scoped_release nogil;
+            st = bsq_tokenize_host(&desc, p.chars, p.offsets, p.B, padlen, batch_first, t, out.ptr, out.space,
+                                   out.stream, &bad);
+        }
+        if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(p.offsets, bad, padlen);
+        if (st != BSQ_OK) throw_status(st);
+        return out.obj;
+    }
+
+    // batch_onehot_encode (tokenize.cpp:65-81 -> tokenize.h:283-371); always (P, B, C)
+    py::object batch_onehot_encode(py::sequence batch, py::ssize_t padlen, const std::string &dt, int nthreads,
+                                   const py::object &mask, const py::object &device) const {
+        const bsq_dtype t = parse_dtype(dt);
+        check_padlen(padlen);
+        if (nthreads <= 0) nthreads = 1;
+        Gathered g;
+        gather(batch, mask, g);
+        PackLock lock;
+        const Packed p = pack(g, nthreads);
+        OutBuf out;
+        make_out(out, {padlen, p.B, py::ssize_t(bsq_alphabet_size(&desc))}, t, device);
+        int64_t bad = -1;
+        bsq_status st;
+        {
+            py::gil_scoped_release nogil;
+            st = bsq_onehot_host(&desc, p.chars, p.offsets, p.mask, p.B, padlen, t, out.ptr, out.space, out.stream,
+                                 &bad);
+        }
+        if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(p.offsets, bad, padlen);
+        if (st != BSQ_OK) throw_status(st);
+        return out.obj;
+    }
+
+    // Packed-batch entry points (additive): chars uint8[total] + offsets int64[B+1] (+ mask uint8[total]),
+    // as numpy arrays (staged through the library) or torch tensors already on the device (zero copy --
+    // the layout of the reference's FlatFile, fxstats.cpp:33-64).
+    py::object encode_packed(bool onehot, const py::object &chars_o, const py::object &offsets_o,
+                             py::ssize_t padlen, const std::string &dt, bool batch_first, const py::object &mask_o,
+                             const py::object &device_o, bool validate) const {
+        const bsq_dtype t = parse_dtype(dt);
+        check_padlen(padlen);
+        ArrayArg chars = as_array(chars_o, "uint8", 1, "chars");
+        ArrayArg offsets = as_array(offsets_o, "int64", 8, "offsets");
+        ArrayArg mask;
+        const bool has_mask = onehot && !mask_o.is_none();
+        if (has_mask) mask = as_array(mask_o, "uint8", 1, "mask");
+        if (offsets.n < 1) throw std::invalid_argument("offsets must have B + 1 entries");
+        const int64_t B = offsets.n - 1;
+        if (chars.on_device != offsets.on_device || (has_mask && mask.on_device != chars.on_device))
+            throw std::invalid_argument("chars, offsets and mask must live in the same memory space");
+        if (has_mask && mask.n < chars.n) throw std::invalid_argument("mask must have one byte per character");
+        py::object device = device_o;
+        if (chars.on_device && device.is_none()) device = chars.keep.attr("device");
+        if (chars.on_device && !device.is_none()) {
+            py::module_ torch = py::module_::import("torch");
+            if (!torch.attr("device")(device).equal(chars.keep.attr("device")))
+                throw std::invalid_argument("device= differs from the device of the packed batch");
+        }
+        const py::ssize_t C = bsq_alphabet_size(&desc);
+        std::vector<py::ssize_t> shape = onehot ? std::vector<py::ssize_t>{padlen, B, C}
+                                                : (batch_first ? std::vector<py::ssize_t>{B, padlen}
+                                                               : std::vector<py::ssize_t>{padlen, B});
+        PackLock lock;
+        OutBuf out;
+        make_out(out, shape, t, device);
+        int64_t bad = -1;
+        bsq_status st;
+        std::vector<int64_t> bad_pair(2, 0);
+        if (chars.on_device) {
+            const int64_t *offs = static_cast<const int64_t *>(offsets.ptr);
+            {
+                py::gil_scoped_release nogil;
+                st = BSQ_OK;
+                if (validate) st = bsq_validate_lengths_device(offs, B, padlen, desc.bos, desc.eos, &bad, out.stream);
+                if (st == BSQ_OK)
+                    st = onehot ? bsq_onehot_device(&desc, static_cast<const uint8_t *>(chars.ptr), offs,
+                                                    has_mask ? static_cast<const uint8_t *>(mask.ptr) : nullptr, B,
+                                                    padlen, t, out.ptr, out.stream)
+                                : bsq_tokenize_device(&desc, static_cast<const uint8_t *>(chars.ptr), offs, B, padlen,
+                                                      batch_first, t, out.ptr, out.stream);
+            }
+            if (st == BSQ_ERR_SEQ_TOO_LONG) {
+                py::object pair = offsets.keep.attr("__getitem__")(py::slice(bad, bad + 2, 1)).attr("tolist")();
+                bad_pair = pair.cast<std::vector<int64_t>>();
+                throw_too_long(bad_pair.data(), 0, padlen);
+            }
+        } else {
+            const int64_t *offs = static_cast<const int64_t *>(offsets.ptr);
+            if (B > 0 && (offs[0] < 0 || offs[B] > chars.n)) throw std::invalid_argument("offsets exceed chars");
+            for (int64_t i = 0; i < B; ++i)
+                if (offs[i + 1] < offs[i]) throw std::invalid_argument("offsets must be non-decreasing");
+            {
+                py::gil_scoped_release nogil;
+                st = onehot ? bsq_onehot_host(&desc, static_cast<const uint8_t *>(chars.ptr), offs,
+                                              has_mask ? static_cast<const uint8_t *>(mask.ptr) : nullptr, B, padlen, t,
+                                              out.ptr, out.space, out.stream, &bad)
+                            : bsq_tokenize_host(&desc, static_cast<const uint8_t *>(chars.ptr), offs, B, padlen,
+                                                batch_first, t, out.ptr, out.space, out.stream, &bad);
+            }
+            if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(offs, bad, padlen);
+        }
+        if (st != BSQ_OK) throw_status(st);
+        return out.obj;
+    }
+
+    // Single-sequence one-hot (tokenize.cpp:8-48 -> tokenize.h:188-216).  NOT part of the batch hot
+    // path: a few hundred bytes of host work, done here like decode_tokens.
+    // Shape (max(L, padlen) + bos + eos, C); PAD rows only up to padlen; the dtype character is
+    // case-masked (B -> uint8, H -> uint16, I -> uint32, F -> float32, D -> float64).  An unmapped
+    // byte leaves its row all-zero (the reference writes one element before the row: tokenize.h:203-206).
+    template <typename T>
+    py::array onehot_single_t(const char *s, py::ssize_t L, py::ssize_t padlen) const {
+        if (padlen > 0 && L > padlen) throw std::runtime_error("padlen is too short to accommodate sequence\n");
+        const py::ssize_t C = bsq_alphabet_size(&desc);
+        const py::ssize_t rows = std::max(L, padlen) + desc.bos + desc.eos;
+        py::array_t<T> ret(std::vector<py::ssize_t>{rows, C});
+        T *ptr = ret.mutable_data();
+        std::fill(ptr, ptr + rows * C, T(0));
+        py::ssize_t r = 0;
+        if (desc.bos) ptr[bsq_bos_id(&desc)] = T(1), ++r;
+        for (py::ssize_t i = 0; i < L; ++i, ++r) {
+            const unsigned char c = static_cast<unsigned char>(s[i]);
+            const int tr = c < 128 ? desc.lut[c] : -1;
+            if (tr >= 0) ptr[r * C + tr] = T(1);
+        }
+        if (desc.eos) ptr[r * C + bsq_eos_id(&desc)] = T(1), ++r;
+        if (desc.padchar)
+            for (; r < padlen; ++r) ptr[r * C + bsq_pad_id(&desc)] = T(1);
+        return ret;
+    }
+    py::object onehot_single(const char *s, py::ssize_t L, py::ssize_t padlen, const std::string &dt) const {
+        switch (dt.empty() ? 0 : (dt[0] & 223)) {
+        case 'B': return onehot_single_t<uint8_t>(s, L, padlen);
+        case 'H': return onehot_single_t<uint16_t>(s, L, padlen);
+        case 'I': return onehot_single_t<uint32_t>(s, L, padlen);
+        case 'F': return onehot_single_t<float>(s, L, padlen);
+        case 'D': return onehot_single_t<double>(s, L, padlen);
+        default: throw std::invalid_argument(std::string("Unsupported dtype: ") + dt);
+        }
+    }
+
+    // decode_tokens (tokenize.h:131-183): 1-D -> str, 2-D -> list of str.
+    py::object decode_tokens(py::array array) const {
+        py::buffer_info info = array.request();
+        if (info.ptr == nullptr) throw std::invalid_argument("Empty array cannot yield a decoded string");
+        if (info.ndim > 2 || info.ndim == 0)
+            throw std::invalid_argument("Currently supported: 1 or 2 dimensions for decoding tokens.");
+        auto load = [&](const uint8_t *p) -> uint32_t {
+            switch (info.itemsize) {
+            case 1: return *p;
+            case 2: { uint16_t v; std::memcpy(&v, p, 2); return v; }
+            case 4: { uint32_t v; std::memcpy(&v, p, 4); return v; }
+            case 8: { uint64_t v; std::memcpy(&v, p, 8); return uint32_t(v); }
+            default:
+                throw std::runtime_error("Unexpected itemsize: expected 1, 2, 4, or 8. Found " +
+                                         std::to_string(info.itemsize));
+            }
+        };
+        auto piece = [&](uint32_t value) -> const std::string & {
+            const auto it = lookup.find(int32_t(value));
+            if (it == lookup.end()) throw std::runtime_error("Unexpected/invalid token " + std::to_string(value));
+            return it->second;
+        };
+        const uint8_t *base = static_cast<const uint8_t *>(info.ptr);
+        if (info.ndim == 1) {
+            std::string s;
+            for (py::ssize_t i = 0; i < info.shape[0]; ++i) s += piece(load(base + i * info.strides[0]));
+            return py::str(s);
+        }
+        py::list ret;
+        for (py::ssize_t r = 0; r < info.shape[0]; ++r) {
+            std::string s;
+            for (py::ssize_t c = 0; c < info.shape[1]; ++c)
+                s += piece(load(base + r * info.strides[0] + c * info.strides[1]));
+            ret.append(py::str(s));
+        }
+        return ret;
+    }
+
+    std::unordered_map<int32_t, py::bytes> token_decoder() const {
+        std::unordered_map<int32_t, py::bytes> ret;
+        for (const auto &kv : tokensets) ret[kv.first] = py::bytes(kv.second);
+        return ret;
+    }
+};
+
+struct Threading {
+    explicit Threading(py::ssize_t n = -1) { set(n); }
+    void set(py::ssize_t n) const {
+        if (n > 0) g_threads.store(int(n));
+    }
+    py::ssize_t get() const { return default_threads(); }
+};
+
+}  // namespace
+
+PYBIND11_MODULE(cbioseq, m) {
+    m.doc() = "bioseq_amd.cbioseq: MI355X-native drop-in for the reference's cbioseq tokenizer module";
+    m.attr("abi_version") = bsq_abi_version();
+    m.def("device_count", [] { return bsq_device_count(); }, "Number of visible HIP devices");
+    m.def("release_staging", [] { bsq_release_staging(); });
+    m.def("alphabet_keys", [] {
+        std::vector<std::string> k;
+        for (int i = 0; i < bsq_num_keys(); ++i) k.emplace_back(bsq_key_name(i));
+        return k;
+    });
+    // omp.cpp:27-32 -- here the knob sizes the host packing threads
+    m.def("set_num_threads", [](py::ssize_t n) {
+        if (n > 0) g_threads.store(int(n));
+    });
+    m.def("get_num_threads", [] { return py::ssize_t(default_threads()); });
+    py::class_<Threading>(m, "Threading")
+        .def(py::init<>())
+        .def(py::init<py::ssize_t>())
+        .def_property("nthreads", &Threading::get, &Threading::set)
+        .def_property("p", &Threading::get, &Threading::set);
+
+    py::class_<Tokenizer>(m, "Tokenizer")
+        .def(py::init<std::string, bool, bool, bool>(), py::arg("key"), py::arg("eos") = false,
+             py::arg("bos") = false, py::arg("padchar") = false)
+        .def("batch_tokenize", &Tokenizer::batch_tokenize, py::arg("batch"), py::arg("padlen") = -1,
+             py::arg("destchar") = "B", py::arg("batch_first") = false, py::arg("nthreads") = 1, py::kw_only(),
+             py::arg("device") = py::none())
+        .def("batch_onehot_encode", &Tokenizer::batch_onehot_encode, py::arg("batch"), py::arg("padlen") = -1,
+             py::arg("destchar") = "B", py::arg("nthreads") = 1, py::arg("mask") = py::none(), py::kw_only(),
+             py::arg("device") = py::none())
+        .def("tokenize_packed",
+             [](const Tokenizer &t, const py::object &chars, const py::object &offsets, py::ssize_t padlen,
+                const std::string &dt, bool batch_first, const py::object &device, bool validate) {
+                 return t.encode_packed(false, chars, offsets, padlen, dt, batch_first, py::none(), device, validate);
+             },
+             py::arg("chars"), py::arg("offsets"), py::arg("padlen"), py::arg("destchar") = "B",
+             py::arg("batch_first") = false, py::arg("device") = py::none(), py::arg("validate") = true)
+        .def("onehot_packed",
+             [](const Tokenizer &t, const py::object &chars, const py::object &offsets, py::ssize_t padlen,
+                const std::string &dt, const py::object &mask, const py::object &device, bool validate) {
+                 return t.encode_packed(true, chars, offsets, padlen, dt, false, mask, device, validate);
+             },
+             py::arg("chars"), py::arg("offsets"), py::arg("padlen"), py::arg("destchar") = "B",
+             py::arg("mask") = py::none(), py::arg("device") = py::none(), py::arg("validate") = true)
+        .def("onehot_encode",
+             [](const Tokenizer &t, py::str s, py::ssize_t padlen, const std::string &dt) {
+                 Py_ssize_t n = 0;
+                 const char *p = PyUnicode_AsUTF8AndSize(s.ptr(), &n);
+                 if (!p) throw py::error_already_set();
+                 return t.onehot_single(p, n, padlen, dt);
+             },
+             py::arg("str"), py::arg("padlen") = 0, py::arg("destchar") = "f")
+        .def("onehot_encode",
+             [](const Tokenizer &t, py::bytearray s, py::ssize_t padlen, const std::string &dt) {
+                 return t.onehot_single(PyByteArray_AS_STRING(s.ptr()), PyByteArray_GET_SIZE(s.ptr()), padlen, dt);
+             },
+             py::arg("bytearray"), py::arg("padlen") = 0, py::arg("destchar") = "f")
+        .def("onehot_encode",
+             [](const Tokenizer &t, py::bytes s, py::ssize_t padlen, const std::string &dt) {
+                 char *p = nullptr;
+                 Py_ssize_t n = 0;
+                 if (PyBytes_AsStringAndSize(s.ptr(), &p, &n)) throw py::error_already_set();
+                 return t.onehot_single(p, n, padlen, dt);
+             },
+             py::arg("str"), py::arg("padlen") = 0, py::arg("destchar") = "B")
+        .def("decode_tokens", &Tokenizer::decode_tokens, py::arg("tokenizer"))
+        .def("lut", [](const Tokenizer &t) { return t.lookup; })
+        .def("token_map", [](const Tokenizer &t) { return t.token_map_str; })
+        .def("token_decoder", &Tokenizer::token_decoder)
+        .def("nchars", [](const Tokenizer &t) { return int(t.desc.nchars); })
+        .def("alphabet_size", [](const Tokenizer &t) { return size_t(bsq_alphabet_size(&t.desc)); })
+        .def("bos", [](const Tokenizer &t) { return int(bsq_bos_id(&t.desc)); })
+        .def("eos", [](const Tokenizer &t) { return int(bsq_eos_id(&t.desc)); })
+        .def("pad", [](const Tokenizer &t) { return int(bsq_pad_id(&t.desc)); })
+        .def_property_readonly("key", [](const Tokenizer &t) { return t.key; })
+        .def("is_padded", [](const Tokenizer &t) { return t.desc.padchar != 0; })
+        .def("includes_bos", [](const Tokenizer &t) { return t.desc.bos != 0; })
+        .def("includes_eos", [](const Tokenizer &t) { return t.desc.eos != 0; })
+        .def("byte_table",
+             [](const Tokenizer &t) {
+                 py::array_t<int8_t> a(256);
+                 std::memcpy(a.mutable_data(), t.desc.lut, 256);
+                 return a;
+             },
+             "256-entry byte -> id table (-1 = unmapped)")
+        .def(py::pickle(
+            [](const Tokenizer &t) {
+                return py::make_tuple(t.key, t.desc.eos != 0, t.desc.bos != 0, t.desc.padchar != 0);
+            },
+            [](py::tuple s) {
+                return Tokenizer(s[0].cast<std::string>(), s[1].cast<bool>(), s[2].cast<bool>(), s[3].cast<bool>());
+            }));
+}

@@ -1,0 +1,140 @@
+/*
+ * bsq.h -- C ABI of libbsq_hip.so: the MI355X (gfx950) batch tokenizer / one-hot encoder.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference (dnbaker/bioseq)
+ * has no C ABI of its own -- its pybind11 lambdas call C++ templates directly
+ * (/root/reference/src/tokenize.cpp:65-98) -- so each entry point below names the reference
+ * function it replaces.  Plain pointers and sizes only; no torch / pybind / STL types.
+ * Status-code returns, no exceptions cross the boundary, the caller owns every buffer.
+ *
+ * Batch representation ("packed batch", same CSR layout as the reference's FlatFile,
+ * /root/reference/src/fxstats.cpp:33-64):
+ *     chars   : uint8[total]   all sequences' bytes, concatenated
+ *     offsets : int64[B + 1]   sequence i is chars[offsets[i] .. offsets[i+1])
+ *     mask    : uint8[total] or NULL, one byte per input character, same offsets
+ *
+ * Output layouts (C-contiguous, bit-exact with the reference's numpy results):
+ *     bsq_tokenize_* : (B, P) when batch_first else (P, B)       -- tokenize.h:420-425
+ *     bsq_onehot_*   : (P, B, C), C = bsq_alphabet_size(desc)    -- tokenize.h:326-330
+ */
+#ifndef BSQ_H
+#define BSQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSQ_ABI_VERSION 1
+
+typedef int32_t bsq_status;
+enum {
+    BSQ_OK = 0,
+    BSQ_ERR_INVALID_KEY = 1,  /* unknown alphabet key            (RuntimeError in Python, tokenize.h:74-79) */
+    BSQ_ERR_INVALID_ARG = 2,  /* NULL pointer, negative size, padlen <= 0 (ValueError, tokenize.h:383)       */
+    BSQ_ERR_DTYPE = 3,        /* unsupported dtype character     (ValueError, tokenize.cpp:80,97)            */
+    BSQ_ERR_SEQ_TOO_LONG = 4, /* len + bos + eos > padlen        (reference aborts, tokenize.h:359-362,456)  */
+    BSQ_ERR_NO_DEVICE = 5,    /* no HIP device visible: the product has NO CPU fallback                      */
+    BSQ_ERR_HIP = 6,          /* a HIP runtime call failed; see bsq_last_error()                             */
+    BSQ_ERR_ALLOC = 7
+};
+
+/* Effective element types of the batch entry points.  The reference lower-cases the dtype
+ * character before dispatch (tokenize.cpp:66,83), so 'B' is int8 and 'L'/'Q' are uint64. */
+typedef enum { BSQ_I8 = 0, BSQ_I16 = 1, BSQ_I32 = 2, BSQ_U64 = 3, BSQ_F32 = 4, BSQ_F64 = 5 } bsq_dtype;
+
+/* Where a buffer handed to a *_host entry point lives. */
+typedef enum { BSQ_SPACE_HOST = 0, BSQ_SPACE_DEVICE = 1 } bsq_space;
+
+/* Immutable tokenizer description == the state of the reference's `struct Tokenizer`
+ * (tokenize.h:9-13): alphabet table + the three flags.  POD; copy freely. */
+typedef struct bsq_desc {
+    int8_t lut[256]; /* byte -> group id, -1 = unmapped (alphabet.h:32-61); bytes >= 0x80 are unmapped */
+    int32_t nchars;  /* number of groups (alphabet.h:27)                                               */
+    int32_t eos;     /* flags, in the reference's positional ctor order (key, eos, bos, padchar)       */
+    int32_t bos;
+    int32_t padchar;
+} bsq_desc;
+
+/* ---- library / errors ------------------------------------------------------------------- */
+int32_t bsq_abi_version(void);
+const char *bsq_strerror(bsq_status s);
+/* Thread-local detail of the last failing call on this thread ("" if none). */
+const char *bsq_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int32_t bsq_device_count(void);
+
+/* ---- alphabets: replaces alph::CAMAP + TAlphabet::make_lut (alphabet.h:32-61,198-222) ---- */
+int32_t bsq_num_keys(void);
+const char *bsq_key_name(int32_t i);
+/* key is matched case-insensitively (tokenize.h:73). */
+bsq_status bsq_lut_get(const char *key, int8_t lut[256], int32_t *nchars);
+/* Tokenizer(key, eos, bos, padchar) (tokenize.h:72-106, tokenize.cpp:23). */
+bsq_status bsq_desc_init(bsq_desc *d, const char *key, int32_t eos, int32_t bos, int32_t padchar);
+/* tokenize.h:21-33 */
+int32_t bsq_bos_id(const bsq_desc *d);        /* -1 when bos is off  */
+int32_t bsq_eos_id(const bsq_desc *d);        /* -1 when eos is off  */
+int32_t bsq_pad_id(const bsq_desc *d);        /* returned even when padchar is off */
+int32_t bsq_alphabet_size(const bsq_desc *d); /* C = nchars + eos + bos + padchar  */
+/* dtype character dispatch of tokenize.cpp:65-98 (first character only, case-folded). */
+bsq_status bsq_dtype_from_destchar(char c, bsq_dtype *out);
+size_t bsq_dtype_size(bsq_dtype t);
+
+/* ---- validation: the length check of tokenize.h:456-459 / :359-362, done BEFORE launch ---- */
+/* offsets in host memory.  *first_bad = index of the first offending sequence or -1. */
+bsq_status bsq_validate_lengths(const int64_t *offsets, int64_t B, int64_t P, int32_t bos, int32_t eos,
+                                int64_t *first_bad);
+/* offsets in device memory; runs a reduction kernel on `hip_stream` and synchronises it. */
+bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos,
+                                       int32_t eos, int64_t *first_bad, void *hip_stream);
+
+/* ---- device entry points: every pointer is device memory; stream-ordered; never synchronise.
+ * Over-long sequences are clamped inside the kernels (memory-safe); call a validate function
+ * first if the reference's error behaviour is wanted.  hip_stream: a hipStream_t (NULL = default).
+ *
+ * bsq_tokenize_device replaces Tokenizer::transencode<T> (tokenize.h:381-485, `batch_tokenize`).
+ * bsq_onehot_device   replaces Tokenizer::tokenize<T>(py::sequence,...) (tokenize.h:283-371,
+ *                     `batch_onehot_encode`); every output element is written exactly once
+ *                     (no memset pass). */
+bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B,
+                               int64_t P, int32_t batch_first, bsq_dtype t, void *out, void *hip_stream);
+bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                             const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                             void *hip_stream);
+/* Same results through the simple one-thread-per-element kernels (any shape/alignment/alphabet).
+ * Used as the in-library cross-check of the tiled kernels and as their fallback. */
+bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                       int64_t B, int64_t P, int32_t batch_first, bsq_dtype t, void *out,
+                                       void *hip_stream);
+bsq_status bsq_onehot_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                     const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                                     void *hip_stream);
+/* Streaming fill of nbytes (multiple of 16, 16-byte aligned) with a 32-bit pattern: the
+ * write-bandwidth yardstick bench.py reports next to the encode kernels. */
+bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip_stream);
+
+/* ---- host entry points: packed batch in HOST memory (pageable or pinned).  The library stages
+ * it through its own pinned + device buffers on the current HIP device, runs the device entry
+ * point on `hip_stream`, and leaves the result in `out`:
+ *   out_space == BSQ_SPACE_DEVICE : out is device memory, the call returns after enqueueing;
+ *   out_space == BSQ_SPACE_HOST   : out is host memory, the call returns after the D2H copy.
+ * Lengths are validated first (BSQ_ERR_SEQ_TOO_LONG, *first_bad set, nothing launched). */
+bsq_status bsq_tokenize_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B,
+                             int64_t P, int32_t batch_first, bsq_dtype t, void *out, bsq_space out_space,
+                             void *hip_stream, int64_t *first_bad);
+bsq_status bsq_onehot_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                           const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                           bsq_space out_space, void *hip_stream, int64_t *first_bad);
+
+/* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer):
+ * returns a buffer of at least nbytes that stays valid until the next call on this thread. */
+void *bsq_pinned_scratch(size_t nbytes);
+/* Free every cached staging buffer of the calling process (tests, shutdown). */
+void bsq_release_staging(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSQ_H */
