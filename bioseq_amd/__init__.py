@@ -19,6 +19,10 @@ from __future__ import annotations
 
 import os as _os
 
+from . import _hipruntime as _hipruntime
+
+_hipruntime.preload()  # share torch's bundled HIP runtime when torch is installed (see _hipruntime.py)
+
 try:
     from . import cbioseq
 except ImportError as _e:  # fail loudly: the HIP extension IS the product

@@ -40,6 +40,8 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m bioseq_amd.build`")
+    from . import _hipruntime
+    _hipruntime.preload()
     L = ctypes.CDLL(LIB_PATH)
     c_int, i32, i64, vp, sz = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
     dp = ctypes.POINTER(Desc)
