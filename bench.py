@@ -182,7 +182,9 @@ def main():
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     kern_avg_ms = float(np.mean(kern_ms))
 
-    # write-bandwidth yardstick: plain 16-byte streaming fill of the same output buffer
+    # write-bandwidth yardstick: the fastest plain fill we know (one 1-KiB store per wave, one aligned
+    # 4-KiB chunk per workgroup, blocks in address order) over the same output buffer
+    capi.check(lib.bsq_tuning_set(b"fill_mode", 1))
     fill_bytes = (out_bytes // 16) * 16
     for _ in range(2):
         capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh))
@@ -211,7 +213,8 @@ def main():
                 traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        kernel_name = {"onehot": "k_onehot_tile", "tokenize": "k_tokenize_rows" if batch_first else "k_tokenize_tile"}[op]
+        kernel_name = (lib.bsq_onehot_kernel_name(ctypes.byref(desc), n, P, dt_code).decode() if op == "onehot"
+                       else ("k_tokenize_rows" if batch_first else "k_tokenize_tile"))
         res = {
             "metric": "Gseq-chars/s + GB/s one-hot written, 64k x 1024 AMINO20" if args.workload == "cfg3"
                       else "Gseq-chars/s + GB/s written (%s)" % args.workload,

@@ -51,6 +51,8 @@ def load():
         "bsq_strerror": (ctypes.c_char_p, [i32]),
         "bsq_last_error": (ctypes.c_char_p, []),
         "bsq_device_count": (i32, []),
+        "bsq_tuning_set": (i32, [ctypes.c_char_p, i32]),
+        "bsq_tuning_get": (i32, [ctypes.c_char_p]),
         "bsq_num_keys": (i32, []),
         "bsq_key_name": (ctypes.c_char_p, [i32]),
         "bsq_lut_get": (i32, [ctypes.c_char_p, vp, ctypes.POINTER(i32)]),
@@ -65,9 +67,11 @@ def load():
         "bsq_validate_lengths_device": (i32, [vp, i64, i64, i32, i32, i64p, vp]),
         "bsq_tokenize_device": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, vp]),
         "bsq_onehot_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
+        "bsq_onehot_kernel_name": (ctypes.c_char_p, [dp, i64, i64, c_int]),
         "bsq_tokenize_device_generic": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, vp]),
         "bsq_onehot_device_generic": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
         "bsq_fill_device": (i32, [vp, sz, ctypes.c_uint32, vp]),
+        "bsq_fill_pattern_device": (i32, [vp, i64, i64, i32, i32, i32, i32, i32, vp]),
         "bsq_tokenize_host": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, c_int, vp, i64p]),
         "bsq_onehot_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),
         "bsq_pinned_scratch": (vp, [sz]),

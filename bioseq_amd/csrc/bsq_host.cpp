@@ -185,12 +185,71 @@ bsq_status set_hip_error(const char *what, hipError_t e) {
     return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? BSQ_ERR_NO_DEVICE : BSQ_ERR_HIP;
 }
 
-bool nontemporal_stores() {
-    static const bool v = [] {
-        const char *e = std::getenv("BSQ_NT_STORES");
-        return e && *e && *e != '0';
-    }();
-    return v;
+namespace {
+struct Knob {
+    const char *name;
+    const char *env;
+    int value;
+    bool init;
+};
+Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
+                  {"onehot_tb", "BSQ_ONEHOT_TB", 0, false},
+                  {"tile_order", "BSQ_TILE_ORDER", 0, false},
+                  {"fill_mode", "BSQ_FILL_MODE", 0, false},
+                  {"variant", "BSQ_VARIANT", 0, false},
+                  {"onehot_path", "BSQ_ONEHOT_PATH", 0, false},
+                  {"expand_cpw", "BSQ_EXPAND_CPW", 0, false}};
+std::mutex g_knob_mu;
+Knob *find_knob(const char *name) {
+    for (Knob &k : g_knobs)
+        if (name && std::strcmp(k.name, name) == 0) return &k;
+    return nullptr;
+}
+}  // namespace
+
+bsq_status workspace_acquire(size_t nbytes, hipStream_t stream, void **ptr) {
+    static std::once_flag once[kMaxDevices];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_hip_error("hipGetDevice", e);
+    if (dev >= 0 && dev < kMaxDevices) {
+        std::call_once(once[dev], [dev] {  // keep freed blocks in the pool instead of returning them to the OS
+            hipMemPool_t pool = nullptr;
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                uint64_t keep = ~uint64_t(0);
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+            (void)hipGetLastError();
+        });
+    }
+    e = hipMallocAsync(ptr, nbytes ? nbytes : 16, stream);
+    if (e != hipSuccess) return set_hip_error("hipMallocAsync(workspace)", e);
+    return BSQ_OK;
+}
+
+void workspace_release(void *ptr, hipStream_t stream) {
+    if (ptr) (void)hipFreeAsync(ptr, stream);
+}
+
+int tuning(const char *name) {
+    std::lock_guard<std::mutex> lock(g_knob_mu);
+    Knob *k = find_knob(name);
+    if (!k) return 0;
+    if (!k->init) {
+        const char *e = std::getenv(k->env);
+        if (e && *e) k->value = std::atoi(e);
+        k->init = true;
+    }
+    return k->value;
+}
+
+bool set_tuning(const char *name, int value) {
+    std::lock_guard<std::mutex> lock(g_knob_mu);
+    Knob *k = find_knob(name);
+    if (!k) return false;
+    k->value = value;
+    k->init = true;
+    return true;
 }
 
 }  // namespace bsq_internal
@@ -198,6 +257,12 @@ bool nontemporal_stores() {
 extern "C" {
 
 const char *bsq_last_error(void) { return t_last_error.c_str(); }
+
+bsq_status bsq_tuning_set(const char *name, int32_t value) {
+    return bsq_internal::set_tuning(name, value) ? BSQ_OK
+                                                 : bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "unknown tuning knob");
+}
+int32_t bsq_tuning_get(const char *name) { return bsq_internal::tuning(name); }
 
 int32_t bsq_device_count(void) {
     int n = 0;

@@ -53,8 +53,21 @@ struct KParams {
     int32_t fill_id;  // token of positions >= L+bos+eos: pad id, or kNone without padchar
     int32_t ntb;      // number of sequence tiles
     int32_t aligned;  // 1: every output row segment is 16-byte aligned -> vector stores
+    int32_t ntt;      // number of position tiles
+    int32_t order;    // 0: sequence-tile index fastest over blockIdx, 1: position-tile index fastest
+    int32_t variant;  // A/B knob: 1 = interleave a wave's rows (w, w+4, ...) instead of 16 contiguous rows
     uint64_t one_bits;
 };
+
+__device__ __forceinline__ void tile_of_block(const KParams &p, int32_t &tb, int32_t &tt) {
+    if (p.order == 0) {
+        tb = static_cast<int32_t>(blockIdx.x % static_cast<uint32_t>(p.ntb));
+        tt = static_cast<int32_t>(blockIdx.x / static_cast<uint32_t>(p.ntb));
+    } else {
+        tt = static_cast<int32_t>(blockIdx.x % static_cast<uint32_t>(p.ntt));
+        tb = static_cast<int32_t>(blockIdx.x / static_cast<uint32_t>(p.ntt));
+    }
+}
 
 // Aligned dword load through the GLOBAL address space (a pointer rebuilt from an integer would
 // otherwise be a flat pointer and cost a flat_load + lgkmcnt wait).
@@ -200,8 +213,8 @@ __global__ __launch_bounds__(kThreads) void k_onehot_tile(const KParams p) {
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int32_t tb = static_cast<int32_t>(blockIdx.x % static_cast<uint32_t>(p.ntb));
-    const int32_t tt = static_cast<int32_t>(blockIdx.x / static_cast<uint32_t>(p.ntb));
+    int32_t tb, tt;
+    tile_of_block(p, tb, tt);
     const int64_t b0 = static_cast<int64_t>(tb) * TB;
     const int32_t t0 = tt * kTT;
 
@@ -223,9 +236,12 @@ __global__ __launch_bounds__(kThreads) void k_onehot_tile(const KParams p) {
     constexpr int kRowsPerWave = kTT / 4;
     constexpr int kSeqPerLane = TB / 64;
     for (int r = 0; r < kRowsPerWave; ++r) {
-        const int32_t tl = wave * kRowsPerWave + r;
+        const int32_t tl = p.variant == 1 ? r * 4 + wave : wave * kRowsPerWave + r;
         const int64_t t = static_cast<int64_t>(t0) + tl;
-        if (t >= p.P) break;  // wave-uniform
+        if (t >= p.P) {  // wave-uniform
+            if (p.variant == 1) break;
+            break;
+        }
         // 1. scatter the ones of this row into the wave's LDS image
         int32_t hot[kSeqPerLane];
 #pragma unroll
@@ -273,7 +289,7 @@ __device__ __forceinline__ T token_value(uint32_t tk) {
     return tk == kNone ? T(0) : static_cast<T>(tk);  // unmapped / unpadded positions keep the memset 0
 }
 
-template <typename T, int TB>
+template <typename T, int TB, bool RAW = false>  // RAW: keep kNone (0xFF) markers -- feeds k_expand_chunks
 __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     int64_t *s_off = reinterpret_cast<int64_t *>(smem);
@@ -281,8 +297,8 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
     uint8_t *s_tok = s_lut + 256;
 
     const int tid = threadIdx.x;
-    const int32_t tb = static_cast<int32_t>(blockIdx.x % static_cast<uint32_t>(p.ntb));
-    const int32_t tt = static_cast<int32_t>(blockIdx.x / static_cast<uint32_t>(p.ntb));
+    int32_t tb, tt;
+    tile_of_block(p, tb, tt);
     const int64_t b0 = static_cast<int64_t>(tb) * TB;
     const int32_t t0 = tt * kTT;
     build_token_tile<TB>(p, b0, t0, s_lut, s_off, s_tok);
@@ -297,7 +313,10 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
         const int32_t sb0 = q * EPC;
         alignas(16) T vals[EPC];
 #pragma unroll
-        for (int i = 0; i < EPC; ++i) vals[i] = token_value<T>(s_tok[(sb0 + i) * kTokStride + tl]);
+        for (int i = 0; i < EPC; ++i) {
+            const uint32_t tk = s_tok[(sb0 + i) * kTokStride + tl];
+            vals[i] = RAW ? static_cast<T>(tk) : token_value<T>(tk);
+        }
         T *dst = out + t * p.B + b0 + sb0;
         if (p.aligned && b0 + sb0 + EPC <= p.B) {
             *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(vals);
@@ -305,6 +324,97 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
 #pragma unroll
             for (int i = 0; i < EPC; ++i)
                 if (b0 + sb0 + i < p.B) dst[i] = vals[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One-hot, two-pass form.  The (P,B,C) one-hot tensor is the flat expansion of the flat (P,B) token
+// matrix: out[r*C + c] = (tok[r] == c), r = t*B + b.  k_expand_chunks streams that expansion in units
+// of naturally aligned 4-KiB CHUNKS of the output, and every workgroup only writes chunks of ONE
+// residue class mod 8: blocks are dealt round-robin over the 8 XCDs, so block b (class b % 8) keeps
+// "XCD x writes the chunks with (chunk id % 8) == x" -- measured on MI355X: 7.1 TB/s for that
+// assignment vs 5.8 TB/s when the classes are mixed across XCDs (profiles/r01/write_patterns.txt).
+// The mapping only affects speed, never results.
+//
+// One wave = one chunk at a time: load the ~4096/(C*sizeof(T)) tokens whose rows intersect the chunk
+// (coalesced bytes), scatter their ones into the wave's private 4-KiB LDS image, stream the image
+// out with 4 x (ds_read_b128 -> global_store_dwordx4), clear the ones.  No barriers.
+// ------------------------------------------------------------------------------------------
+constexpr int kChunk = 4096;
+
+struct EParams {
+    const uint8_t *tok;  // nrows raw tokens (kNone = no one)
+    uint8_t *out;        // output base (any alignment that is a multiple of sizeof(ST))
+    int64_t total;       // output bytes
+    int64_t nrows;       // P * B
+    int64_t nchunks;     // chunks intersecting [out, out + total)
+    int32_t head;        // out & 4095
+    int32_t C;
+    int32_t cpw;         // chunks per wave
+    uint64_t one_bits;
+};
+
+template <typename ST, bool NT>
+__global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
+    __shared__ __align__(16) uint8_t s_img[4][kChunk];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *img = s_img[wave];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
+
+    const int32_t cls = static_cast<int32_t>(blockIdx.x & 7u);
+    const int64_t group = static_cast<int64_t>(blockIdx.x >> 3);
+    const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
+    const ST one = static_cast<ST>(p.one_bits);
+    // first chunk of this wave: k = cls + 8 * j0, then k += 8 per step (same class)
+    int64_t j = (group * 4 + wave) * p.cpw;
+    for (int32_t it = 0; it < p.cpw; ++it, ++j) {
+        const int64_t k = cls + 8 * j;
+        if (k >= p.nchunks) break;  // wave-uniform
+        int64_t lo = k * kChunk - p.head, hi = lo + kChunk;  // byte range of the chunk relative to `out`
+        if (lo < 0) lo = 0;
+        if (hi > p.total) hi = p.total;
+        const int32_t len = static_cast<int32_t>(hi - lo);
+        const int64_t r_lo = lo / rowbytes;                    // first row intersecting the chunk
+        const int32_t skip = static_cast<int32_t>(lo - r_lo * rowbytes);  // bytes of row r_lo before the chunk
+        const int32_t nr = (skip + len + rowbytes - 1) / rowbytes;        // rows intersecting it
+        // 1. scatter: row r_lo + i has its one at byte (i*rowbytes - skip) + tok*sizeof(ST) of the image
+        for (int32_t i0 = 0; i0 < nr; i0 += 64) {
+            const int32_t i = i0 + lane;
+            if (i < nr) {
+                const uint32_t tk = p.tok[r_lo + i];
+                const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
+                if (tk != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 2. stream the image out
+        uint8_t *g = p.out + lo;
+        if (len == kChunk) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(img + lane * 16);
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(img + 1024 + lane * 16);
+            const uint4 v2 = *reinterpret_cast<const uint4 *>(img + 2048 + lane * 16);
+            const uint4 v3 = *reinterpret_cast<const uint4 *>(img + 3072 + lane * 16);
+            store16<NT>(g + lane * 16, v0);
+            store16<NT>(g + 1024 + lane * 16, v1);
+            store16<NT>(g + 2048 + lane * 16, v2);
+            store16<NT>(g + 3072 + lane * 16, v3);
+        } else {  // clipped first / last chunk of the tensor
+            for (int32_t o = lane * static_cast<int32_t>(sizeof(ST)); o < len; o += 64 * static_cast<int32_t>(sizeof(ST)))
+                *reinterpret_cast<ST *>(g + o) = *reinterpret_cast<const ST *>(img + o);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 3. clear
+        for (int32_t i0 = 0; i0 < nr; i0 += 64) {
+            const int32_t i = i0 + lane;
+            if (i < nr) {
+                const uint32_t tk = p.tok[r_lo + i];
+                const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
+                if (tk != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = ST(0);
+            }
         }
     }
 }
@@ -418,6 +528,64 @@ __global__ __launch_bounds__(kThreads) void k_fill(uint4 *dst, size_t n16, uint3
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n16; i += stride) dst[i] = v;
 }
 
+// Write-pattern experiments (fill_mode 1..4); mode 0 is k_fill above.
+//  1/3: one 16-byte store per thread, one block per 4 KiB (plain / nt)
+//  2/4: one block per 16 KiB, 4 stores per thread 4 KiB apart (plain / nt)
+template <int PER_THREAD, bool NT>
+__global__ __launch_bounds__(kThreads) void k_fill_blocks(uint4 *dst, size_t n16, uint32_t pattern) {
+    const uint4 v{pattern, pattern, pattern, pattern};
+    const size_t base = static_cast<size_t>(blockIdx.x) * (kThreads * PER_THREAD) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * kThreads;
+        if (i < n16) store16<NT>(dst + i, v);
+    }
+}
+
+// Diagnostic: the WRITE PATTERN of the tiled one-hot kernel without any of its work.  The output is a
+// (rows, pitch) byte matrix; block (cb, rb) owns columns [cb*seg, (cb+1)*seg) of 4*rpw rows; each of its
+// 4 waves writes rpw rows (contiguous rows if !interleave), `seg` contiguous bytes per row.
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void k_fill_pattern(uint8_t *dst, int64_t rows, int64_t pitch, int32_t seg,
+                                                           int32_t rpw, int32_t ncb, int32_t nrb, int32_t order,
+                                                           int32_t interleave) {
+    int32_t cb, rb;
+    if (order >= 2) {  // permutations of the block -> column-chunk map (ncb must be a multiple of 64)
+        const uint32_t b = blockIdx.x % ncb;
+        rb = blockIdx.x / ncb;
+        uint32_t c = b;
+        if (order == 2) c = (b & ~7u) | ((b + (b >> 3)) & 7u);            // rotate the mod-8 class per group of 8
+        if (order == 3) c = b ^ 1u;                                        // swap neighbours
+        if (order == 4) c = (b & ~63u) | (__brev(b & 63u) >> 26);          // bit-reverse inside 64-chunk windows
+        if (order == 5) c = (b & ~7u) | ((b + 1u) & 7u);                   // constant rotation of the class
+        if (order == 6) c = (b & ~63u) | (((b & 7u) << 3) | ((b >> 3) & 7u));  // transpose 8x8 inside windows
+        cb = static_cast<int32_t>(c);
+    } else if (order == 0) {
+        cb = blockIdx.x % ncb;
+        rb = blockIdx.x / ncb;
+    } else {
+        rb = blockIdx.x % nrb;
+        cb = blockIdx.x / nrb;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint4 v{1, 2, 3, 4};
+    if (interleave == 2) {  // row-wise: the 4 waves write 4 adjacent segments of the SAME row
+        for (int r = 0; r < rpw; ++r) {
+            const int64_t row = static_cast<int64_t>(rb) * rpw + r;
+            if (row >= rows) break;
+            uint8_t *g = dst + row * pitch + (static_cast<int64_t>(cb) * 4 + wave) * seg;
+            for (int32_t o = lane * 16; o < seg; o += 1024) store16<NT>(g + o, v);
+        }
+        return;
+    }
+    for (int r = 0; r < rpw; ++r) {
+        const int64_t row = static_cast<int64_t>(rb) * 4 * rpw + (interleave ? r * 4 + wave : wave * rpw + r);
+        if (row >= rows) break;
+        uint8_t *g = dst + row * pitch + static_cast<int64_t>(cb) * seg;
+        for (int32_t o = lane * 16; o < seg; o += 1024) store16<NT>(g + o, v);
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offsets, int64_t B, int64_t room,
                                                              unsigned long long *first_bad) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
@@ -460,6 +628,9 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     k.eos_id = bsq_eos_id(d);
     k.fill_id = d->padchar ? bsq_pad_id(d) : static_cast<int32_t>(kNone);
     k.ntb = 1;
+    k.ntt = int32_t((P + kTT - 1) / kTT);
+    k.order = bsq_internal::tuning("tile_order");
+    k.variant = bsq_internal::tuning("variant");
     k.aligned = 0;
     k.one_bits = 1;
     return BSQ_OK;
@@ -507,12 +678,215 @@ template <typename ST>
 bsq_status dispatch_onehot_tile(KParams &k, hipStream_t s) {
     // Row segment = TB*C*sizeof(ST) bytes of contiguous output per (tile,row): keep it >= 2 KiB.
     const int seg64 = 64 * k.C * int(sizeof(ST));
-    if (seg64 >= 2048) {
-        k.ntb = int32_t((k.B + 63) / 64);
-        return launch_onehot_tile<ST, 64>(k, s);
-    }
-    k.ntb = int32_t((k.B + 255) / 256);
+    int tb = seg64 >= 2048 ? 64 : 256;
+    const int forced = bsq_internal::tuning("onehot_tb");
+    if ((forced == 64 || forced == 128 || forced == 256) &&
+        4 * (forced * k.C * int(sizeof(ST)) + 16) + tile_fixed_bytes<256>() <= 64 * 1024)
+        tb = forced;
+    k.ntb = int32_t((k.B + tb - 1) / tb);
+    if (tb == 64) return launch_onehot_tile<ST, 64>(k, s);
+    if (tb == 128) return launch_onehot_tile<ST, 128>(k, s);
     return launch_onehot_tile<ST, 256>(k, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// One-hot, single pass, CHUNK-OWNER form: one wave = one naturally aligned 4-KiB chunk of the output,
+// chunk classes (id % 8) pinned to XCDs exactly as in k_expand_chunks, but the tokens of the chunk's
+// rows are resolved on the fly: rows r_lo.. are consecutive sequences b at (mostly) one position t,
+// so each lane loads offsets[b], offsets[b+1] (coalesced) and gathers ONE character per sequence.
+// The gathered lines are re-used by the next positions from L2 (each XCD keeps to its own chunk
+// columns when the row pitch is a multiple of 32 KiB), so HBM sees the characters about once.
+// Any shape / pitch / alignment; best when a row (C*sizeof(T) bytes) is >= ~32 bytes.
+// ------------------------------------------------------------------------------------------
+struct CParams {
+    int8_t lut[256];
+    const uint8_t *chars;
+    const int64_t *offsets;
+    const uint8_t *mask;
+    uint8_t *out;
+    int64_t total;    // output bytes
+    int64_t nchunks;
+    int64_t B, P;
+    int32_t head;     // out & 4095
+    int32_t C;
+    int32_t bos;
+    uint32_t bos_id, at_len_id, fill_id;
+    int32_t room;     // P - bos - eos (length clamp)
+    int32_t cpw;
+    uint64_t one_bits;
+};
+
+template <typename ST, bool NT>
+__global__ __launch_bounds__(kThreads) void k_onehot_chunks(const CParams p) {
+    __shared__ __align__(16) uint8_t s_img[4][kChunk];
+    __shared__ __align__(16) uint8_t s_lut4[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *img = s_img[wave];
+    uint8_t *lut = s_lut4[wave];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
+    {   // wave-private copy of the alphabet table (unmapped / >= 0x80 -> kNone): no workgroup barrier needed
+        uint32_t w = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane * 4 + q;
+            const int8_t v = p.lut[idx];
+            const uint32_t e = (idx < 128 && v >= 0) ? static_cast<uint32_t>(v) : kNone;
+            w |= e << (8 * q);
+        }
+        reinterpret_cast<uint32_t *>(lut)[lane] = w;
+    }
+    const int32_t cls = static_cast<int32_t>(blockIdx.x & 7u);
+    const int64_t group = static_cast<int64_t>(blockIdx.x >> 3);
+    const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
+    const ST one = static_cast<ST>(p.one_bits);
+    int64_t j = (group * 4 + wave) * p.cpw;
+    for (int32_t it = 0; it < p.cpw; ++it, ++j) {
+        const int64_t k = cls + 8 * j;
+        if (k >= p.nchunks) break;  // wave-uniform
+        int64_t lo = k * kChunk - p.head, hi = lo + kChunk;
+        if (lo < 0) lo = 0;
+        if (hi > p.total) hi = p.total;
+        const int32_t len = static_cast<int32_t>(hi - lo);
+        const int64_t r_lo = lo / rowbytes;
+        const int32_t skip = static_cast<int32_t>(lo - r_lo * rowbytes);
+        const int32_t nr = (skip + len + rowbytes - 1) / rowbytes;
+        const int64_t t_lo = r_lo / p.B;
+        const int64_t b_lo = r_lo - t_lo * p.B;
+        for (int32_t i0 = 0; i0 < nr; i0 += 64) {
+            const int32_t i = i0 + lane;
+            if (i < nr) {
+                int64_t b = b_lo + i, t = t_lo;
+                if (b >= p.B) {  // the chunk runs over the end of position t's rows
+                    const int64_t q = b / p.B;
+                    t += q;
+                    b -= q * p.B;
+                }
+                const int64_t start = p.offsets[b];
+                int64_t L = p.offsets[b + 1] - start;
+                L = L > p.room ? p.room : L;
+                uint32_t tk;
+                const int64_t jj = t - p.bos;
+                if (jj < 0) {
+                    tk = p.bos_id;
+                } else if (jj < L) {
+                    tk = lut[p.chars[start + jj]];
+                    if (p.mask && p.mask[start + jj] == 0) tk = kNone;
+                } else {
+                    tk = (jj == L) ? p.at_len_id : p.fill_id;
+                }
+                const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
+                if (tk != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint8_t *g = p.out + lo;
+        if (len == kChunk) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(img + lane * 16);
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(img + 1024 + lane * 16);
+            const uint4 v2 = *reinterpret_cast<const uint4 *>(img + 2048 + lane * 16);
+            const uint4 v3 = *reinterpret_cast<const uint4 *>(img + 3072 + lane * 16);
+            store16<NT>(g + lane * 16, v0);
+            store16<NT>(g + 1024 + lane * 16, v1);
+            store16<NT>(g + 2048 + lane * 16, v2);
+            store16<NT>(g + 3072 + lane * 16, v3);
+        } else {
+            for (int32_t o = lane * static_cast<int32_t>(sizeof(ST)); o < len; o += 64 * static_cast<int32_t>(sizeof(ST)))
+                *reinterpret_cast<ST *>(g + o) = *reinterpret_cast<const ST *>(img + o);
+        }
+        if (it + 1 < p.cpw) {  // image is reused: wipe it (wave-private, in-order LDS)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
+        }
+    }
+}
+
+template <typename ST>
+bsq_status launch_chunks(const CParams &c, hipStream_t s) {
+    const int64_t per_class = (c.nchunks + 7) / 8;
+    const int64_t groups = (per_class + int64_t(4) * c.cpw - 1) / (int64_t(4) * c.cpw);
+    const dim3 grid(unsigned(groups * 8));
+    if (bsq_internal::nontemporal_stores())
+        hipLaunchKernelGGL((k_onehot_chunks<ST, true>), grid, dim3(kThreads), 0, s, c);
+    else
+        hipLaunchKernelGGL((k_onehot_chunks<ST, false>), grid, dim3(kThreads), 0, s, c);
+    return check_launch("k_onehot_chunks");
+}
+
+bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
+    CParams c;
+    for (int i = 0; i < 256; ++i) c.lut[i] = k.lut[i];
+    c.chars = k.chars;
+    c.offsets = k.offsets;
+    c.mask = k.mask;
+    c.out = static_cast<uint8_t *>(k.out);
+    c.B = k.B;
+    c.P = k.P;
+    c.total = k.P * k.B * k.C * int64_t(sz);
+    c.head = int32_t(reinterpret_cast<uintptr_t>(k.out) & (kChunk - 1));
+    c.nchunks = (c.head + c.total + kChunk - 1) / kChunk;
+    c.C = k.C;
+    c.bos = k.bos;
+    c.bos_id = uint32_t(k.bos_id);
+    c.fill_id = uint32_t(k.fill_id);
+    c.at_len_id = k.eos ? uint32_t(k.eos_id) : c.fill_id;
+    const int64_t room = k.P - k.bos - k.eos;
+    c.room = int32_t(room < 0 ? 0 : room);
+    const int cpw = bsq_internal::tuning("expand_cpw");
+    c.cpw = cpw > 0 ? cpw : 1;
+    c.one_bits = k.one_bits;
+    if ((c.nchunks + 7) / 8 / (4 * c.cpw) + 1 >= (int64_t(1) << 28)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
+    switch (sz) {
+    case 1: return launch_chunks<uint8_t>(c, s);
+    case 2: return launch_chunks<uint16_t>(c, s);
+    case 4: return launch_chunks<uint32_t>(c, s);
+    default: return launch_chunks<uint64_t>(c, s);
+    }
+}
+
+template <typename ST>
+bsq_status launch_expand(const EParams &e, hipStream_t s) {
+    const int64_t per_class = (e.nchunks + 7) / 8;
+    const int64_t groups = (per_class + int64_t(4) * e.cpw - 1) / (int64_t(4) * e.cpw);
+    const dim3 grid(unsigned(groups * 8));
+    if (bsq_internal::nontemporal_stores())
+        hipLaunchKernelGGL((k_expand_chunks<ST, true>), grid, dim3(kThreads), 0, s, e);
+    else
+        hipLaunchKernelGGL((k_expand_chunks<ST, false>), grid, dim3(kThreads), 0, s, e);
+    return check_launch("k_expand_chunks");
+}
+
+// Two-pass one-hot: raw (P,B) tokens into `workspace` (P*B bytes), then the chunk expansion.
+bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s) {
+    void *out = k.out;
+    k.out = workspace;
+    k.aligned = (reinterpret_cast<uintptr_t>(workspace) % 16 == 0) && (k.B % 16 == 0);
+    k.ntb = int32_t((k.B + 255) / 256);
+    const size_t smem = tile_fixed_bytes<256>();
+    hipLaunchKernelGGL((k_tokenize_tile<uint8_t, 256, true>), dim3(unsigned(int64_t(k.ntb) * k.ntt)), dim3(kThreads),
+                       smem, s, k);
+    bsq_status st = check_launch("k_tokenize_tile<raw>");
+    if (st != BSQ_OK) return st;
+    EParams e;
+    e.tok = static_cast<const uint8_t *>(workspace);
+    e.out = static_cast<uint8_t *>(out);
+    e.nrows = k.P * k.B;
+    e.total = e.nrows * k.C * int64_t(sz);
+    e.head = int32_t(reinterpret_cast<uintptr_t>(out) & (kChunk - 1));
+    e.nchunks = (e.head + e.total + kChunk - 1) / kChunk;
+    e.C = k.C;
+    e.one_bits = k.one_bits;
+    int cpw = bsq_internal::tuning("expand_cpw");
+    e.cpw = cpw > 0 ? cpw : 4;
+    switch (sz) {
+    case 1: return launch_expand<uint8_t>(e, s);
+    case 2: return launch_expand<uint16_t>(e, s);
+    case 4: return launch_expand<uint32_t>(e, s);
+    default: return launch_expand<uint64_t>(e, s);
+    }
 }
 
 template <typename T, int TB>
@@ -528,6 +902,31 @@ bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
 
 extern "C" {
 
+// 0 generic, 1 tiled, 2 two-pass, 3 chunk-owner
+static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P) {
+    const int64_t ntiles = ((B + 63) / 64) * ((P + kTT - 1) / kTT);
+    const bool tiled_ok = C <= 250 && 4 * (64 * C * int64_t(sz) + 16) + tile_fixed_bytes<64>() <= 60 * 1024 &&
+                          ntiles < (int64_t(1) << 31) && B < (int64_t(1) << 31) - 256;
+    if (!tiled_ok) return 0;
+    int path = bsq_internal::tuning("onehot_path");
+    if (path == 0) {
+        const int64_t rowbytes = C * int64_t(sz), pitch = B * rowbytes;
+        const bool pinned_columns = pitch % (8 * kChunk) == 0;
+        path = (rowbytes >= 48 && ((pinned_columns && B <= 262144) || B <= 16384)) ? 3 : 1;
+    }
+    return path;
+}
+
+const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_dtype t) {
+    if (!d) return "";
+    switch (choose_onehot_path(bsq_alphabet_size(d), bsq_dtype_size(t), B, P)) {
+    case 1: return "k_onehot_tile";
+    case 2: return "k_tokenize_tile+k_expand_chunks";
+    case 3: return "k_onehot_chunks";
+    default: return "k_onehot_generic";
+    }
+}
+
 bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                              const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                              void *hip_stream) {
@@ -537,15 +936,26 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     if (B == 0) return BSQ_OK;
     const size_t sz = bsq_dtype_size(t);
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
-    // Tiled kernel limits: 8-bit token ids, 32-bit tile arithmetic, row images must fit in LDS.
-    const int64_t ntiles = ((B + 63) / 64) * ((P + kTT - 1) / kTT);
-    const bool tiled_ok = k.C <= 250 && 4 * (64 * k.C * int64_t(sz) + 16) + tile_fixed_bytes<64>() <= 60 * 1024 &&
-                          ntiles < (int64_t(1) << 31) && B < (int64_t(1) << 31) - 256;
-    if (!tiled_ok) return bsq_onehot_device_generic(d, chars, offsets, mask_or_null, B, P, t, out, hip_stream);
+    // Limits of the LDS kernels: 8-bit token ids, 32-bit tile arithmetic, row images must fit in LDS.
+    const int path = choose_onehot_path(k.C, sz, B, P);
+    if (path == 0) return bsq_onehot_device_generic(d, chars, offsets, mask_or_null, B, P, t, out, hip_stream);
     k.one_bits = one_bits_of(t);
     const int64_t pitch = B * k.C * int64_t(sz);
     k.aligned = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (pitch % 16 == 0);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    // Path selection (tuning knob "onehot_path": 0 auto, 1 tiled, 2 two-pass, 3 chunk-owner).
+    // Measured on MI355X (profiles/r01/sweep_shapes.txt): the chunk-owner kernel streams at ~7 TB/s when a
+    // row is >= 48 bytes and its per-position gather set stays L2-resident -- i.e. the row pitch is a
+    // multiple of 32 KiB (each XCD then keeps to its own chunk columns) and B is moderate, or B is small.
+    if (path == 3) return onehot_chunk_owner(k, sz, s);
+    if (path == 2) {
+        void *ws = nullptr;
+        bsq_status wst = bsq_internal::workspace_acquire(size_t(P) * size_t(B), s, &ws);
+        if (wst != BSQ_OK) return wst;
+        wst = onehot_two_pass(k, sz, ws, s);
+        bsq_internal::workspace_release(ws, s);
+        return wst;
+    }
     switch (sz) {
     case 1: return dispatch_onehot_tile<uint8_t>(k, s);
     case 2: return dispatch_onehot_tile<uint16_t>(k, s);
@@ -646,10 +1056,43 @@ bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip
     if (nbytes == 0) return BSQ_OK;
     const size_t n16 = nbytes / 16;
     const size_t blocks = (n16 + kThreads - 1) / kThreads;
-    const unsigned grid = unsigned(blocks > 256 * 16 ? 256 * 16 : blocks);
-    hipLaunchKernelGGL(k_fill, dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(hip_stream),
-                       static_cast<uint4 *>(dst), n16, pattern);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    uint4 *d4 = static_cast<uint4 *>(dst);
+    const int mode = bsq_internal::tuning("fill_mode");
+    if (blocks >= (size_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "fill too large");
+    switch (mode) {
+    case 1: hipLaunchKernelGGL((k_fill_blocks<1, false>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, d4, n16, pattern); break;
+    case 2: hipLaunchKernelGGL((k_fill_blocks<4, false>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;
+    case 3: hipLaunchKernelGGL((k_fill_blocks<1, true>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, d4, n16, pattern); break;
+    case 4: hipLaunchKernelGGL((k_fill_blocks<4, true>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;
+    default: {
+        const unsigned grid = unsigned(blocks > 256 * 16 ? 256 * 16 : blocks);
+        hipLaunchKernelGGL(k_fill, dim3(grid), dim3(kThreads), 0, s, d4, n16, pattern);
+    }
+    }
     return check_launch("k_fill");
+}
+
+bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32_t seg, int32_t rows_per_wave,
+                                   int32_t order, int32_t interleave, int32_t nt, void *hip_stream) {
+    if (!dst || rows <= 0 || pitch <= 0 || seg <= 0 || seg % 16 || pitch % seg || rows_per_wave <= 0)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bad fill pattern");
+    int32_t ncb = int32_t(pitch / seg);
+    int32_t nrb = int32_t((rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave));
+    if (interleave == 2) {
+        if (ncb % 4) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "row-wise pattern needs pitch % (4*seg) == 0");
+        ncb /= 4;
+        nrb = int32_t((rows + rows_per_wave - 1) / rows_per_wave);
+    }
+    const dim3 grid(unsigned(int64_t(ncb) * nrb));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (nt)
+        hipLaunchKernelGGL((k_fill_pattern<true>), grid, dim3(kThreads), 0, s, static_cast<uint8_t *>(dst), rows, pitch,
+                           seg, rows_per_wave, ncb, nrb, order, interleave);
+    else
+        hipLaunchKernelGGL((k_fill_pattern<false>), grid, dim3(kThreads), 0, s, static_cast<uint8_t *>(dst), rows, pitch,
+                           seg, rows_per_wave, ncb, nrb, order, interleave);
+    return check_launch("k_fill_pattern");
 }
 
 bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos,

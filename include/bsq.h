@@ -66,6 +66,12 @@ const char *bsq_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int32_t bsq_device_count(void);
 
+/* Tuning / diagnostic knobs (kernel variants for A/B measurements; results never change).
+ * Names: "nt_stores", "onehot_tb", "tile_order", "fill_mode", "variant", "onehot_path", "expand_cpw".  Environment variables
+ * BSQ_NT_STORES etc. give the initial values. */
+bsq_status bsq_tuning_set(const char *name, int32_t value);
+int32_t bsq_tuning_get(const char *name);
+
 /* ---- alphabets: replaces alph::CAMAP + TAlphabet::make_lut (alphabet.h:32-61,198-222) ---- */
 int32_t bsq_num_keys(void);
 const char *bsq_key_name(int32_t i);
@@ -103,6 +109,8 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
 bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                              const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                              void *hip_stream);
+/* Name of the kernel(s) bsq_onehot_device would launch for this shape (profiling / bench labels). */
+const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_dtype t);
 /* Same results through the simple one-thread-per-element kernels (any shape/alignment/alphabet).
  * Used as the in-library cross-check of the tiled kernels and as their fallback. */
 bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
@@ -114,6 +122,11 @@ bsq_status bsq_onehot_device_generic(const bsq_desc *d, const uint8_t *chars, co
 /* Streaming fill of nbytes (multiple of 16, 16-byte aligned) with a 32-bit pattern: the
  * write-bandwidth yardstick bench.py reports next to the encode kernels. */
 bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip_stream);
+/* Diagnostic: writes a (rows x pitch bytes) matrix with the tiled one-hot kernel's store pattern and none
+ * of its work -- block (cb, rb) owns `seg` contiguous bytes of 4*rows_per_wave rows, one wave per
+ * rows_per_wave rows.  Used by scripts/sweep_pattern.py to separate pattern cost from kernel cost. */
+bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32_t seg, int32_t rows_per_wave,
+                                   int32_t order, int32_t interleave, int32_t nt, void *hip_stream);
 
 /* ---- host entry points: packed batch in HOST memory (pageable or pinned).  The library stages
  * it through its own pinned + device buffers on the current HIP device, runs the device entry
