@@ -1,0 +1,103 @@
+"""Multi-GPU use of the hot path: shard a ragged batch BY SEQUENCE, one process per GPU.
+
+Sequences are independent (the reference's OpenMP loop partitions exactly like this on threads,
+/root/reference/src/tokenize.h:340-342), and every sequence costs the same output bytes
+(P*C'*sizeof(T)), so equal-count contiguous ranges balance the dominant (write) cost.  A
+data-parallel consumer needs NO collective: each rank keeps its shard.  Only when one rank needs the
+whole batch do the shards travel -- `gather_tokens` / `gather_onehot` (torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" for CPU tests).
+
+Whole-batch assembly:
+  * batch-first tokens (B_g, P): shards are contiguous slabs of the result -> one all_gather.
+  * seq-first tokens (P, B_g) and one-hot (P, B_g, C): a shard is a COLUMN block of every position row;
+    shards are all-gathered into per-rank staging slabs and concatenated along the batch axis
+    (one extra read+write of the tensor on the receiver; SURVEY.md section 8e option 2).
+Ragged shard counts (B % world != 0) are padded to the largest shard for the collective and trimmed.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(B: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous range [b0, b1) of rank `rank`; sizes differ by at most one, larger shards first."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, extra = divmod(B, world)
+    b0 = rank * base + min(rank, extra)
+    return b0, b0 + base + (1 if rank < extra else 0)
+
+
+def shard_packed(chars, offsets, world: int, rank: int):
+    """Slice a packed batch (numpy or torch) to this rank's sequences; offsets are rebased to 0."""
+    B = int(offsets.shape[0]) - 1
+    b0, b1 = shard_bounds(B, world, rank)
+    c0, c1 = int(offsets[b0]), int(offsets[b1])
+    return chars[c0:c1], offsets[b0:b1 + 1] - offsets[b0]
+
+
+def _dist():
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised")
+    return dist
+
+
+def _all_gather_padded(local, batch_axis: int, B: int, group=None):
+    """all_gather of shards that differ by at most one along `batch_axis`; returns the list of trimmed shards."""
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
+    if local.shape[batch_axis] != sizes[rank]:
+        raise ValueError("local shard has %d sequences, expected %d" % (local.shape[batch_axis], sizes[rank]))
+    mx = max(sizes)
+    send = local
+    if sizes[rank] != mx:
+        pad_shape = list(local.shape)
+        pad_shape[batch_axis] = mx - sizes[rank]
+        send = torch.cat([local, local.new_zeros(pad_shape)], dim=batch_axis)
+    send = send.contiguous()
+    bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(bufs, send, group=group)
+    return [b.narrow(batch_axis, 0, sizes[r]) for r, b in enumerate(bufs)]
+
+
+def gather_tokens(local, B: int, batch_first: bool, group=None):
+    """Whole-batch token matrix on every rank from per-rank shards ((B_g,P) or (P,B_g))."""
+    import torch
+    axis = 0 if batch_first else 1
+    return torch.cat(_all_gather_padded(local, axis, B, group), dim=axis)
+
+
+def gather_onehot(local, B: int, group=None):
+    """Whole-batch (P, B, C) one-hot on every rank from per-rank (P, B_g, C) shards."""
+    import torch
+    return torch.cat(_all_gather_padded(local, 1, B, group), dim=1)
+
+
+def encode_sharded(encode: Callable, chars, offsets, gather: Optional[str] = None, group=None):
+    """Run `encode(chars_shard, offsets_shard)` on this rank's sequences.
+
+    encode: e.g. ``lambda c, o: tok.onehot_packed(c, o, padlen, 'f', device=dev)``.
+    gather: None (data-parallel consumer: keep the shard), 'onehot', 'tokens_bf' or 'tokens_sf'.
+    """
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = int(offsets.shape[0]) - 1
+    c, o = shard_packed(chars, offsets, world, rank)
+    local = encode(c, o)
+    if gather is None:
+        return local
+    import torch
+    if isinstance(local, np.ndarray):
+        local = torch.from_numpy(local)
+    if gather == "onehot":
+        return gather_onehot(local, B, group)
+    if gather == "tokens_bf":
+        return gather_tokens(local, B, True, group)
+    if gather == "tokens_sf":
+        return gather_tokens(local, B, False, group)
+    raise ValueError("gather must be None, 'onehot', 'tokens_bf' or 'tokens_sf'")

@@ -1,0 +1,118 @@
+"""CPU: the C-ABI library loads and exports every symbol include/bsq.h declares; host-only ABI calls
+behave; repository layout rules (the product never touches the oracle; no reference sources)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bioseq_amd import capi
+    lib = capi.load()
+    names = capi.declared_symbols()
+    assert len(names) >= 25 and "bsq_onehot_device" in names and "bsq_tokenize_host" in names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.bsq_abi_version() == 1
+
+
+def test_host_only_abi_calls(alphabets_golden):
+    from bioseq_amd import capi
+    lib = capi.load()
+    assert lib.bsq_num_keys() == 20
+    assert [lib.bsq_key_name(i).decode() for i in range(20)] == sorted(alphabets_golden["keys"])
+    lut = (ctypes.c_int8 * 256)()
+    n = ctypes.c_int32(0)
+    assert lib.bsq_lut_get(b"seb14", lut, ctypes.byref(n)) == capi.OK and n.value == 14
+    assert list(lut) == alphabets_golden["luts"]["SEB14"]
+    assert lib.bsq_lut_get(b"zzz", lut, ctypes.byref(n)) == capi.ERR_INVALID_KEY
+    d = capi.make_desc("DNA", eos=True, bos=True, padchar=True)
+    assert (lib.bsq_bos_id(ctypes.byref(d)), lib.bsq_eos_id(ctypes.byref(d)), lib.bsq_pad_id(ctypes.byref(d)),
+            lib.bsq_alphabet_size(ctypes.byref(d))) == (4, 5, 6, 7)
+    dt = ctypes.c_int(-1)
+    for ch, code in ((b"B", capi.I8), (b"h", capi.I16), (b"I", capi.I32), (b"L", capi.U64), (b"q", capi.U64),
+                     (b"f", capi.F32), (b"D", capi.F64)):
+        assert lib.bsq_dtype_from_destchar(ch, ctypes.byref(dt)) == capi.OK and dt.value == code
+    assert lib.bsq_dtype_from_destchar(b"u", ctypes.byref(dt)) == capi.ERR_DTYPE
+    assert [lib.bsq_dtype_size(i) for i in range(6)] == [1, 2, 4, 8, 4, 8]
+    offs = np.array([0, 4, 9, 9], dtype=np.int64)
+    bad = ctypes.c_int64(0)
+    assert lib.bsq_validate_lengths(offs.ctypes.data, 3, 7, 1, 1, ctypes.byref(bad)) == capi.OK and bad.value == -1
+    assert lib.bsq_validate_lengths(offs.ctypes.data, 3, 6, 1, 1, ctypes.byref(bad)) == capi.ERR_SEQ_TOO_LONG and bad.value == 1
+    assert lib.bsq_strerror(capi.ERR_SEQ_TOO_LONG) == b"seq len + bos + eos > padlen"
+    assert lib.bsq_tuning_set(b"no_such_knob", 1) == capi.ERR_INVALID_ARG
+    assert lib.bsq_tuning_set(b"onehot_path", 0) == capi.OK and lib.bsq_tuning_get(b"onehot_path") == 0
+    assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("AMINO20")), 65536, 1024, capi.F32) == b"k_onehot_chunks"
+    assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA4", 1, 1, 1)), 1000000, 160, capi.I8) == b"k_onehot_tile"
+    assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("BYTES", 1, 1, 1)), 1000, 160, capi.I16) == b"k_onehot_generic"
+
+
+def test_compute_entry_points_refuse_without_a_device():
+    from bioseq_amd import capi
+    lib = capi.load()
+    if lib.bsq_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    d = capi.make_desc("DNA")
+    chars = np.frombuffer(b"ACGT", dtype=np.uint8).copy()
+    offs = np.array([0, 4], dtype=np.int64)
+    out = np.zeros(8, dtype=np.int8)
+    bad = ctypes.c_int64(0)
+    st = lib.bsq_tokenize_host(ctypes.byref(d), chars.ctypes.data, offs.ctypes.data, 1, 8, 1, capi.I8,
+                               out.ctypes.data, capi.SPACE_HOST, None, ctypes.byref(bad))
+    assert st == capi.ERR_NO_DEVICE and b"no HIP device" in lib.bsq_last_error()
+    assert (out == 0).all()
+
+
+def _py_files(sub):
+    for dp, _, fs in os.walk(os.path.join(ROOT, sub)):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                yield os.path.join(dp, f)
+
+
+def test_product_never_touches_the_oracle():
+    pat = re.compile(r"\boracle\b|bsq_oracle|bsqo_|_ref\b")
+    for path in list(_py_files("bioseq_amd")) + list(_py_files("include")):
+        text = open(path, errors="replace").read()
+        hits = [l for l in text.splitlines() if pat.search(l)]
+        assert not hits, (path, hits[:3])
+
+
+def _non_doc_strings(path):
+    """String constants of a Python file that are not docstrings."""
+    import ast
+    tree = ast.parse(open(path).read())
+    doc_ids = set()
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.Module, ast.ClassDef, ast.FunctionDef, ast.AsyncFunctionDef)) and node.body:
+            first = node.body[0]
+            if isinstance(first, ast.Expr) and isinstance(first.value, ast.Constant) and isinstance(first.value.value, str):
+                doc_ids.add(id(first.value))
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Constant) and isinstance(node.value, str) and id(node) not in doc_ids:
+            yield node.value
+
+
+def test_nothing_reads_the_reference_tree_at_run_time():
+    """/root/reference does not exist on the GPU box: only doc citations may mention it (make_golden.py
+    and __graft_entry__.build() are build-container tools and are exempt)."""
+    files = [os.path.join(ROOT, "bench.py")] + [p for p in _py_files("bioseq_amd") if p.endswith(".py")] + \
+            [p for p in _py_files("tests") if p.endswith(".py") and not p.endswith("make_golden.py")] + \
+            [p for p in _py_files("oracle") if p.endswith(".py")] + [p for p in _py_files("scripts") if p.endswith(".py")]
+    for path in files:
+        bad = [v for v in _non_doc_strings(path) if "/root/reference" in v and os.path.basename(path) != "test_abi_and_layout.py"]
+        assert not bad, (path, bad)
+
+
+def test_repo_layout():
+    for f in ("bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/bsq.h", "oracle/bsq_oracle.c",
+              "oracle/Makefile", "tests/golden/make_golden.py", "profiles/README.md"):
+        assert os.path.exists(os.path.join(ROOT, f)), f
+    gi = open(os.path.join(ROOT, ".gitignore")).read()
+    assert "oracle/_ref/" in gi
+    gri = open(os.path.join(ROOT, ".gpurunignore")).read()
+    assert "_ref" not in gri and ".so" not in gri  # built artefacts must travel to the GPU box

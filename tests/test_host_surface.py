@@ -1,0 +1,136 @@
+"""CPU: the host-only parts of the product -- Tokenizer ids / decode tables / pickle, the package's
+tokenizer dictionaries and facade argument handling, dtype and error conventions that are decided
+before any launch, the single-sequence helper, and that encode calls FAIL LOUDLY without a GPU."""
+import itertools
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+COMBOS = list(itertools.product([0, 1], repeat=3))
+
+
+def test_ids_and_tables_match_reference(bsq, alphabets_golden):
+    for key in alphabets_golden["keys"]:
+        lut = np.array(alphabets_golden["luts"][key])
+        got = bsq.Tokenizer(key).byte_table().astype(np.int64)
+        assert (got == lut).all(), key  # incl. BYTES: lut[i] = int8(i)
+        for eos, bos, pad in COMBOS:
+            m = alphabets_golden["meta"][key][f"{eos}{bos}{pad}"]
+            t = bsq.Tokenizer(key.lower(), eos, bos, pad)
+            assert t.key == m["key"] == key
+            assert (t.alphabet_size(), t.bos(), t.eos(), t.pad(), t.nchars()) == \
+                   (m["alphabet_size"], m["bos"], m["eos"], m["pad"], m["nchars"])
+            assert (t.is_padded(), t.includes_bos(), t.includes_eos()) == (m["is_padded"], m["includes_bos"], m["includes_eos"])
+            if "token_map" in m:
+                assert t.token_map() == m["token_map"]                       # same unordered_map iteration order
+                assert {str(k): v for k, v in t.lut().items()} == m["lut"]
+            if "decoder" in m:
+                assert {str(k): bytes(v).decode("latin-1") for k, v in t.token_decoder().items()} == m["decoder"]
+
+
+def test_keyword_and_positional_ctor_order(bsq):
+    t = bsq.Tokenizer("dna", True, False, False)           # positional order is (key, eos, bos, padchar)
+    assert t.includes_eos() and not t.includes_bos() and t.eos() == 4 and t.bos() == -1 and t.pad() == 5
+    t = bsq.Tokenizer("DNA", bos=True)
+    assert t.bos() == 4 and t.eos() == -1 and t.pad() == 5 and t.alphabet_size() == 5
+    with pytest.raises(RuntimeError, match="Invalid tokenizer type; select one fromAMINO;AMINO20;BYTES;C;"):
+        bsq.Tokenizer("protein2")
+
+
+def test_pickle_roundtrip(bsq):
+    t = bsq.Tokenizer("seb8", eos=True, padchar=True)
+    u = pickle.loads(pickle.dumps(t))
+    assert (u.key, u.includes_eos(), u.includes_bos(), u.is_padded()) == ("SEB8", True, False, True)
+    assert u.token_map() == t.token_map()
+
+
+def test_decode_tokens(bsq, kats):
+    tok = bsq.pbeos_tokenizers["DNA"]
+    arr = np.array(kats["readme"]["tokens"], dtype=np.int8)
+    assert tok.decode_tokens(arr) == kats["readme"]["decoded"] == ['<BOS>ACGT<EOS><PAD>', '<BOS>GGGG<EOS><PAD>']
+    assert tok.decode_tokens(arr[0]) == '<BOS>ACGT<EOS><PAD>'
+    assert tok.decode_tokens(arr.astype(np.int64)) == kats["readme"]["decoded"]
+    assert tok.decode_tokens(np.asfortranarray(arr.astype(np.int32))) == kats["readme"]["decoded"]  # strided
+    with pytest.raises(RuntimeError, match="Unexpected/invalid token 9"):
+        tok.decode_tokens(np.array([9], dtype=np.int8))
+    with pytest.raises(ValueError):
+        tok.decode_tokens(np.zeros((1, 1, 1), dtype=np.int8))
+
+
+def test_package_dictionaries(bsq, golden_dir):
+    J = json.load(open(os.path.join(golden_dir, "facade.json")))
+    assert list(bsq.bkeys) == J["bkeys"] and len(bsq.bkeys) == 34
+    assert sorted(bsq.default_tokenizers) == J["default_keys"]
+    for name, size in J["dict_sizes"].items():
+        assert len(getattr(bsq, name)) == size, name
+    for name, (key, asize) in J["named"].items():
+        t = getattr(bsq, name)
+        assert (t.key, t.alphabet_size()) == (key, asize), name
+    for flags, exp in J["get_tokenizer_dict"].items():
+        b, e, p = (int(c) for c in flags)
+        t = bsq.get_tokenizer_dict(b, e, p)["DNA"]
+        assert [t.includes_bos(), t.includes_eos(), t.is_padded()] == exp
+    assert bsq.get_tokenizer_dict(0, 0, 0) is bsq.default_tokenizers
+    t = bsq.total_tokenizer_dict[(1, 0, 1, "seb10")]
+    assert (t.key, t.includes_bos(), t.includes_eos(), t.is_padded()) == ("SEB10", True, False, True)
+
+
+def test_single_sequence_helper_matches_reference(bsq, golden_dir):
+    A = np.load(os.path.join(golden_dir, "facade.npz"))
+    r = bsq.f_encode("ACGT", key="DNA")
+    assert r.dtype == A["single_str_default"].dtype == np.uint8 and (r == A["single_str_default"]).all()
+    r = bsq.pbeos_tokenizers["DNA"].onehot_encode("ACGT", 8, "f")
+    assert r.dtype == np.float32 and r.shape == (10, 7) and (r == A["single_pbeos_p8"]).all()
+    r = bsq.DNATokenizer.onehot_encode(b"ACGTA")
+    assert r.dtype == A["single_bytes_default"].dtype and (r == A["single_bytes_default"]).all()
+    assert bsq.DNATokenizer.onehot_encode(bytearray(b"AC")).dtype == np.float32
+    with pytest.raises(RuntimeError, match="padlen is too short"):
+        bsq.DNATokenizer.onehot_encode("ACGTACGT", 4)
+    with pytest.raises(ValueError, match="Unsupported dtype"):
+        bsq.DNATokenizer.onehot_encode("ACGT", 0, "q")
+
+
+def test_errors_decided_before_launch(bsq):
+    tok = bsq.pbeos_tokenizers["DNA"]
+    with pytest.raises(ValueError, match="Unsupported dtype: x"):
+        tok.batch_tokenize(["ACGT"], padlen=8, destchar="x")
+    with pytest.raises(ValueError, match="batch tokenize requires padlen is provded."):
+        tok.batch_tokenize(["ACGT"])
+    with pytest.raises(ValueError, match="batch tokenize requires padlen is provded."):
+        tok.batch_onehot_encode(["ACGT"], padlen=-3)
+    with pytest.raises(ValueError, match="item was none of string, bytes, or numpy array of 8-bit integers"):
+        tok.batch_onehot_encode(["ACGT", 3.5], padlen=8)
+    with pytest.raises(TypeError):
+        tok.batch_tokenize(iter(["ACGT"]), padlen=8)
+    with pytest.raises(TypeError):
+        tok.batch_tokenize(["ACGT"], 8, "B", False, 1, "cuda")  # device= is keyword-only: defaults unchanged
+
+
+def test_threads_knobs(bsq):
+    n0 = bsq.get_num_threads()
+    assert n0 >= 1
+    bsq.set_num_threads(3)
+    assert bsq.get_num_threads() == 3 and bsq.Threading().nthreads == 3
+    th = bsq.Threading(2)
+    assert th.p == 2
+    th.nthreads = 5
+    assert bsq.get_num_threads() == 5
+    bsq.set_num_threads(-1)  # ignored, as in omp.cpp:21-23
+    assert bsq.get_num_threads() == 5
+    bsq.set_num_threads(n0)
+
+
+def test_no_gpu_means_loud_failure(bsq):
+    """The product has no CPU fallback: without a HIP device every encode call raises."""
+    if bsq.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    tok = bsq.pbeos_tokenizers["DNA"]
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        tok.batch_tokenize(["ACGT"], padlen=8)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        tok.batch_onehot_encode(["ACGT"], padlen=8)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        tok.onehot_packed(np.frombuffer(b"ACGT", dtype=np.uint8), np.array([0, 4]), 8, "f")

@@ -1,0 +1,84 @@
+"""CPU, world_size 2 over gloo: the multi-process path -- shard-by-sequence bounds, packed-batch
+slicing, and whole-batch assembly of seq-first / batch-first shards (the per-rank encode is done by the
+oracle here, since the product itself needs a GPU; the GPU box runs the same code with nccl = RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_and_balance():
+    from bioseq_amd.sharding import shard_bounds
+    for B in (0, 1, 7, 8, 9, 65536, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(B, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_shard_packed_rebases_offsets():
+    from bioseq_amd import synth
+    from bioseq_amd.sharding import shard_packed
+    chars, offs = synth.synth_packed(3, 11, 0, 9, "ACGT")
+    seqs = synth.unpack(chars, offs)
+    got = []
+    for r in range(3):
+        c, o = shard_packed(chars, offs, 3, r)
+        assert o[0] == 0 and o[-1] == c.size
+        got += synth.unpack(c, o)
+    assert got == seqs
+
+
+def _worker(rank, world, port, B, P, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from bioseq_amd import sharding, synth
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        chars, offs = synth.synth_packed(99, B, 0, P - 2, synth.DIRTY)
+        tok = O.OracleTokenizer("AMINO20", 1, 1, 1)
+        full_oh = tok.onehot_packed(chars, offs, P, "f")
+        full_bf = tok.tokenize_packed(chars, offs, P, "B", True)
+        full_sf = tok.tokenize_packed(chars, offs, P, "i", False)
+        oh = sharding.encode_sharded(lambda c, o: tok.onehot_packed(c, o, P, "f"), chars, offs, gather="onehot")
+        bf = sharding.encode_sharded(lambda c, o: tok.tokenize_packed(c, o, P, "B", True), chars, offs, gather="tokens_bf")
+        sf = sharding.encode_sharded(lambda c, o: tok.tokenize_packed(c, o, P, "i", False), chars, offs, gather="tokens_sf")
+        keep = sharding.encode_sharded(lambda c, o: tok.onehot_packed(c, o, P, "f"), chars, offs)
+        b0, b1 = sharding.shard_bounds(B, world, rank)
+        ok = (oh.numpy().tobytes() == full_oh.tobytes() and bf.numpy().tobytes() == full_bf.tobytes()
+              and sf.numpy().tobytes() == full_sf.tobytes()
+              and keep.tobytes() == np.ascontiguousarray(full_oh[:, b0:b1]).tobytes())
+        # bench.py-style timing reduction: MAX over ranks
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = ok and t.item() == world
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [10, 11])
+def test_world2_gather_matches_single_process(B):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, 23, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
