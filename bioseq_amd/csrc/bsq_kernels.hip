@@ -459,6 +459,169 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_rows(const KParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Tokens, (B,P) layout, CHUNK form: the (B,P) matrix is a flat stream of B*P elements; one wave
+// produces one naturally aligned 4-KiB chunk of it (chunk classes pinned to XCDs as in the one-hot
+// chunk kernels).  A lane owns 16 output bytes = EPL = 16/sizeof(T) consecutive positions of one
+// sequence per store (needs P % EPL == 0 and a 16-byte aligned base): one unaligned vector load of
+// its EPL characters, EPL LUT lookups from a wave-private LDS table, one 16-byte store.
+// ------------------------------------------------------------------------------------------
+struct TParams {
+    int8_t lut[256];
+    const uint8_t *chars;
+    const int64_t *offsets;
+    uint8_t *out;
+    int64_t total;    // output bytes
+    int64_t nchunks;
+    int64_t B, P;
+    int32_t bos;
+    uint32_t bos_id, at_len_id, fill_id;
+    int32_t room;
+};
+
+// N characters held as whole words (bytes are extracted only where they are consumed, so the loads
+// stay in flight); alignment 1: gfx950 does unaligned vector loads in hardware.
+template <int N>
+struct __attribute__((packed, aligned(1))) UBytes {
+    uint32_t w[N / 4];
+    __device__ __forceinline__ uint32_t byte(int i) const { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; }
+    __device__ __forceinline__ void set_byte(int i, uint32_t v) {
+        w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((v & 0xFFu) << (8 * (i & 3)));
+    }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) w[q] = 0;
+    }
+};
+template <>
+struct __attribute__((packed, aligned(1))) UBytes<2> {
+    uint16_t h;
+    __device__ __forceinline__ uint32_t byte(int i) const { return (h >> (8 * i)) & 0xFFu; }
+    __device__ __forceinline__ void set_byte(int i, uint32_t v) {
+        h = static_cast<uint16_t>((h & ~(0xFFu << (8 * i))) | ((v & 0xFFu) << (8 * i)));
+    }
+    __device__ __forceinline__ void clear() { h = 0; }
+};
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
+    __shared__ __align__(16) uint8_t s_lut4[4][256];
+    constexpr int SZ = static_cast<int>(sizeof(T));
+    constexpr int EPL = 16 / SZ;  // elements (= characters) per lane per store
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *lut = s_lut4[wave];
+    {   // wave-private table of token VALUES: unmapped / >= 0x80 -> 0 (the memset value of tokenize.h:427)
+        uint32_t w = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane * 4 + q;
+            const int8_t v = p.lut[idx];
+            const uint32_t e = (idx < 128 && v >= 0) ? static_cast<uint32_t>(v) : 0u;
+            w |= e << (8 * q);
+        }
+        reinterpret_cast<uint32_t *>(lut)[lane] = w;
+    }
+    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave);
+    if (k >= p.nchunks) return;
+    const int64_t total_chars = p.offsets[p.B];
+    const int64_t lo = k * kChunk;  // chunks are relative to `out` (16-byte aligned on this path)
+    constexpr int32_t EPS = 1024 / SZ;  // elements between two consecutive stores of a lane
+    // The lane's four stores: element e0 + u*EPS.  One wide division, then small 32-bit steps.
+    const int64_t e0 = (lo + lane * 16) / SZ;
+    int64_t b0;
+    int32_t t00;
+    if (p.B * p.P < (int64_t(1) << 32)) {
+        const uint32_t q = static_cast<uint32_t>(e0) / static_cast<uint32_t>(p.P);
+        b0 = q;
+        t00 = static_cast<int32_t>(static_cast<uint32_t>(e0) - q * static_cast<uint32_t>(p.P));
+    } else {
+        b0 = e0 / p.P;
+        t00 = static_cast<int32_t>(e0 - b0 * p.P);
+    }
+    // stage A: row coordinates + offsets of all four stores (unconditional: 8 independent loads in flight)
+    bool live[4];
+    int32_t t0[4];
+    int64_t start[4], stop[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t tt = static_cast<uint32_t>(t00) + static_cast<uint32_t>(u) * EPS;
+        const uint32_t q = tt / static_cast<uint32_t>(p.P);
+        int64_t b = b0 + q;
+        t0[u] = static_cast<int32_t>(tt - q * static_cast<uint32_t>(p.P));
+        live[u] = b < p.B;
+        b = live[u] ? b : p.B - 1;
+        start[u] = p.offsets[b];
+        stop[u] = p.offsets[b + 1];
+    }
+    int32_t L[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t len = stop[u] - start[u];
+        L[u] = static_cast<int32_t>(len > p.room ? p.room : len);
+    }
+    // stage B: the characters.  Loads are UNCONDITIONAL (lanes that must not touch their own address read
+    // the first EPL bytes of the buffer instead) so that all four are in flight together.
+    UBytes<EPL> cw[4];
+    bool slow[4], fast[4];
+    const bool can_vec = total_chars >= EPL;  // wave-uniform
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int32_t j0 = t0[u] - p.bos;
+        const int64_t a = start[u] + j0;
+        const bool need = live[u] && j0 < L[u] && j0 + EPL > 0;
+        fast[u] = can_vec && need && a >= 0 && a + EPL <= total_chars;
+        slow[u] = need && !fast[u];
+    }
+    if (can_vec) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            cw[u] = *reinterpret_cast<const UBytes<EPL> *>(p.chars + (fast[u] ? start[u] + t0[u] - p.bos : 0));
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cw[u].clear();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (slow[u]) {  // first / last bytes of the buffer: never read outside it
+            const int32_t j0 = t0[u] - p.bos;
+            cw[u].clear();
+#pragma unroll
+            for (int i = 0; i < EPL; ++i)
+                if (j0 + i >= 0 && j0 + i < L[u]) cw[u].set_byte(i, p.chars[start[u] + j0 + i]);
+        }
+    }
+    // stage C: LUT lookups packed 4 (or 2) per word; BOS / EOS / PAD folded in with word masks
+    constexpr int WB = EPL >= 4 ? 4 : EPL;  // characters per word
+    const uint32_t ones = WB == 4 ? 0x01010101u : 0x0101u;
+    const uint32_t fill_v = p.fill_id == kNone ? 0u : p.fill_id;
+    const uint32_t at_len_v = p.at_len_id == kNone ? 0u : p.at_len_id;
+    const uint32_t fill_w = fill_v * ones;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (!live[u]) continue;
+        const int32_t j0 = t0[u] - p.bos;
+        alignas(16) T vals[EPL];
+#pragma unroll
+        for (int q = 0; q < EPL / WB; ++q) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int i = 0; i < WB; ++i) w |= static_cast<uint32_t>(lut[cw[u].byte(q * WB + i)]) << (8 * i);
+            const int32_t jf = j0 + q * WB;  // character index of the word's first byte
+            const int32_t nv = L[u] - jf;    // characters of the sequence left from there
+            if (nv < WB) {
+                const uint32_t m = nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u);
+                w = (w & m) | (fill_w & ~m);
+                if (nv >= 0) w = (w & ~(0xFFu << (8 * nv))) | (at_len_v << (8 * nv));  // position bos+L
+            }
+            if (jf < 0) w = (w & ~0xFFu) | p.bos_id;  // position 0 with BOS
+#pragma unroll
+            for (int i = 0; i < WB; ++i) vals[q * WB + i] = static_cast<T>((w >> (8 * i)) & 0xFFu);
+        }
+        store16<NT>(p.out + lo + u * 1024 + lane * 16, *reinterpret_cast<const uint4 *>(vals));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Generic one-thread-per-element kernels (ids up to 258, any alignment).
 // ------------------------------------------------------------------------------------------
@@ -898,6 +1061,33 @@ bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
     return check_launch("k_tokenize_tile");
 }
 
+template <typename T>
+bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
+    TParams c;
+    for (int i = 0; i < 256; ++i) c.lut[i] = k.lut[i];
+    c.chars = k.chars;
+    c.offsets = k.offsets;
+    c.out = static_cast<uint8_t *>(k.out);
+    c.B = k.B;
+    c.P = k.P;
+    c.total = k.B * k.P * int64_t(sizeof(T));
+    c.nchunks = (c.total + kChunk - 1) / kChunk;
+    c.bos = k.bos;
+    c.bos_id = uint32_t(k.bos_id);
+    c.fill_id = uint32_t(k.fill_id);
+    c.at_len_id = k.eos ? uint32_t(k.eos_id) : c.fill_id;
+    const int64_t room = k.P - k.bos - k.eos;
+    c.room = int32_t(room < 0 ? 0 : room);
+    const int64_t groups = ((c.nchunks + 7) / 8 + 3) / 4;
+    if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
+    const dim3 grid(unsigned(groups * 8));
+    if (bsq_internal::nontemporal_stores())
+        hipLaunchKernelGGL((k_tokenize_chunks<T, true>), grid, dim3(kThreads), 0, s, c);
+    else
+        hipLaunchKernelGGL((k_tokenize_chunks<T, false>), grid, dim3(kThreads), 0, s, c);
+    return check_launch("k_tokenize_chunks");
+}
+
 }  // namespace
 
 extern "C" {
@@ -976,6 +1166,17 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         return bsq_tokenize_device_generic(d, chars, offsets, B, P, batch_first, t, out, hip_stream);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const uintptr_t addr = reinterpret_cast<uintptr_t>(out);
+    if (batch_first && bsq_internal::tuning("tokenize_path") != 1 && addr % 16 == 0 &&
+        P % int64_t(16 / sz) == 0) {  // chunk kernel: every lane's 16 output bytes lie inside one row
+        switch (t) {
+        case BSQ_I8: return launch_tokenize_chunks<int8_t>(k, s);
+        case BSQ_I16: return launch_tokenize_chunks<int16_t>(k, s);
+        case BSQ_I32: return launch_tokenize_chunks<int32_t>(k, s);
+        case BSQ_U64: return launch_tokenize_chunks<uint64_t>(k, s);
+        case BSQ_F32: return launch_tokenize_chunks<float>(k, s);
+        case BSQ_F64: return launch_tokenize_chunks<double>(k, s);
+        }
+    }
     if (batch_first) {
         const size_t vec = sz * 4 > 16 ? 16 : sz * 4;  // widest store used by k_tokenize_rows
         k.aligned = (addr % vec == 0) && ((P * int64_t(sz)) % int64_t(vec) == 0);
