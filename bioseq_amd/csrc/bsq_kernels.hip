@@ -363,58 +363,133 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
 
-    const int32_t cls = static_cast<int32_t>(blockIdx.x & 7u);
-    const int64_t group = static_cast<int64_t>(blockIdx.x >> 3);
+    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave);
+    if (k >= p.nchunks) return;  // one chunk per wave, then the wave retires
     const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
     const ST one = static_cast<ST>(p.one_bits);
-    // first chunk of this wave: k = cls + 8 * j0, then k += 8 per step (same class)
-    int64_t j = (group * 4 + wave) * p.cpw;
-    for (int32_t it = 0; it < p.cpw; ++it, ++j) {
-        const int64_t k = cls + 8 * j;
-        if (k >= p.nchunks) break;  // wave-uniform
-        int64_t lo = k * kChunk - p.head, hi = lo + kChunk;  // byte range of the chunk relative to `out`
-        if (lo < 0) lo = 0;
-        if (hi > p.total) hi = p.total;
-        const int32_t len = static_cast<int32_t>(hi - lo);
-        const int64_t r_lo = lo / rowbytes;                    // first row intersecting the chunk
-        const int32_t skip = static_cast<int32_t>(lo - r_lo * rowbytes);  // bytes of row r_lo before the chunk
-        const int32_t nr = (skip + len + rowbytes - 1) / rowbytes;        // rows intersecting it
-        // 1. scatter: row r_lo + i has its one at byte (i*rowbytes - skip) + tok*sizeof(ST) of the image
-        for (int32_t i0 = 0; i0 < nr; i0 += 64) {
-            const int32_t i = i0 + lane;
-            if (i < nr) {
-                const uint32_t tk = p.tok[r_lo + i];
-                const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
-                if (tk != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
-            }
+    int64_t lo = k * kChunk - p.head, hi = lo + kChunk;  // byte range of the chunk relative to `out`
+    if (lo < 0) lo = 0;
+    if (hi > p.total) hi = p.total;
+    const int32_t len = static_cast<int32_t>(hi - lo);
+    const int64_t r_lo = lo / rowbytes;                               // first row intersecting the chunk
+    const int32_t skip = static_cast<int32_t>(lo - r_lo * rowbytes);  // bytes of row r_lo before the chunk
+    const int32_t nr = (skip + len + rowbytes - 1) / rowbytes;        // rows intersecting it
+    const uint8_t *tok = p.tok + r_lo;
+    // scatter: row r_lo + i has its one at image byte i*rowbytes - skip + tok*sizeof(ST).
+    // 4 coalesced token loads in flight per step.
+    for (int32_t i0 = 0; i0 < nr; i0 += 256) {
+        uint32_t tk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int32_t i = i0 + 64 * q + lane;
+            tk[q] = i < nr ? static_cast<uint32_t>(tok[i]) : kNone;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // 2. stream the image out
-        uint8_t *g = p.out + lo;
-        if (len == kChunk) {
-            const uint4 v0 = *reinterpret_cast<const uint4 *>(img + lane * 16);
-            const uint4 v1 = *reinterpret_cast<const uint4 *>(img + 1024 + lane * 16);
-            const uint4 v2 = *reinterpret_cast<const uint4 *>(img + 2048 + lane * 16);
-            const uint4 v3 = *reinterpret_cast<const uint4 *>(img + 3072 + lane * 16);
-            store16<NT>(g + lane * 16, v0);
-            store16<NT>(g + 1024 + lane * 16, v1);
-            store16<NT>(g + 2048 + lane * 16, v2);
-            store16<NT>(g + 3072 + lane * 16, v3);
-        } else {  // clipped first / last chunk of the tensor
-            for (int32_t o = lane * static_cast<int32_t>(sizeof(ST)); o < len; o += 64 * static_cast<int32_t>(sizeof(ST)))
-                *reinterpret_cast<ST *>(g + o) = *reinterpret_cast<const ST *>(img + o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int32_t i = i0 + 64 * q + lane;
+            const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk[q]) * static_cast<int32_t>(sizeof(ST));
+            if (tk[q] != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // 3. clear
-        for (int32_t i0 = 0; i0 < nr; i0 += 64) {
-            const int32_t i = i0 + lane;
-            if (i < nr) {
-                const uint32_t tk = p.tok[r_lo + i];
-                const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
-                if (tk != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = ST(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint8_t *g = p.out + lo;
+    if (len == kChunk) {
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(img + lane * 16);
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(img + 1024 + lane * 16);
+        const uint4 v2 = *reinterpret_cast<const uint4 *>(img + 2048 + lane * 16);
+        const uint4 v3 = *reinterpret_cast<const uint4 *>(img + 3072 + lane * 16);
+        store16<NT>(g + lane * 16, v0);
+        store16<NT>(g + 1024 + lane * 16, v1);
+        store16<NT>(g + 2048 + lane * 16, v2);
+        store16<NT>(g + 3072 + lane * 16, v3);
+    } else {  // clipped first / last chunk of the tensor
+        for (int32_t o = lane * static_cast<int32_t>(sizeof(ST)); o < len; o += 64 * static_cast<int32_t>(sizeof(ST)))
+            *reinterpret_cast<ST *>(g + o) = *reinterpret_cast<const ST *>(img + o);
+    }
+}
+
+// Raw (P,B) uint8 tokens (kNone kept) for k_expand_chunks.  Workgroup = 256 sequences x 64 positions.
+// Phase 1: 4 characters per lane (two aligned words + alignbyte), 4 LUT lookups packed into a word, BOS /
+// EOS / PAD / mask folded in with byte masks, written TRANSPOSED into LDS (row = position).  Phase 2:
+// each position row of the tile is 256 contiguous bytes of the output: ds_read_b128 -> 16-byte stores.
+constexpr int kRawTB = 256;
+constexpr int kRawStride = kRawTB + 4;  // 65 dwords: odd stride -> the 4 byte-writes of a lane spread over banks
+
+__global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
+    __shared__ __align__(16) uint8_t s_lut[256];
+    __shared__ __align__(16) int64_t s_off[kRawTB + 1];
+    __shared__ __align__(16) uint8_t s_t[kTT * kRawStride];
+    const int tid = threadIdx.x;
+    int32_t tb, tt;
+    tile_of_block(p, tb, tt);
+    const int64_t b0 = static_cast<int64_t>(tb) * kRawTB;
+    const int32_t t0 = tt * kTT;
+    stage_lut(p, s_lut);
+    for (int i = tid; i <= kRawTB; i += kThreads) {
+        const int64_t b = b0 + i;
+        s_off[i] = p.offsets[b <= p.B ? b : p.B];
+    }
+    __syncthreads();
+    const uintptr_t chars = reinterpret_cast<uintptr_t>(p.chars), mask = reinterpret_cast<uintptr_t>(p.mask);
+    const uint32_t fill_w = static_cast<uint32_t>(p.fill_id) * 0x01010101u;
+    const uint32_t at_len = p.eos ? static_cast<uint32_t>(p.eos_id) : static_cast<uint32_t>(p.fill_id);
+    const int g = tid & 15;
+    const int32_t tpos = t0 + 4 * g;
+    const int32_t j0 = tpos - p.bos;
+    for (int sb = tid >> 4; sb < kRawTB; sb += kThreads / 16) {
+        uint32_t w = kNone * 0x01010101u;
+        if (b0 + sb < p.B) {
+            const int64_t start = s_off[sb];
+            const int32_t L = clamp_len(p, s_off[sb + 1] - start);
+            uint32_t cw = 0, mw = 0xFFFFFFFFu;
+            if (j0 + 4 > 0 && j0 < L) {
+                const int32_t jlo = j0 < 0 ? 0 : j0, jhi = (j0 + 4 < L) ? j0 + 4 : L;
+                const uintptr_t base = chars + static_cast<uintptr_t>(start);
+                cw = load4_unaligned(base + j0, base + jlo, base + jhi);
+                if (mask) {
+                    const uintptr_t mb = mask + static_cast<uintptr_t>(start);
+                    mw = load4_unaligned(mb + j0, mb + jlo, mb + jhi);
+                }
             }
+            w = static_cast<uint32_t>(s_lut[cw & 0xFFu]) | (static_cast<uint32_t>(s_lut[(cw >> 8) & 0xFFu]) << 8) |
+                (static_cast<uint32_t>(s_lut[(cw >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(s_lut[cw >> 24]) << 24);
+            // mask byte == 0 -> kNone (exact zero-byte detection)
+            uint32_t z = (mw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+            z = ~(z | mw | 0x7F7F7F7Fu);          // 0x80 in every byte of mw that is zero
+            w |= (z >> 7) * 0xFFu;
+            const int32_t nv = L - j0;            // characters left from the word's first byte
+            if (nv < 4) {
+                const uint32_t m = nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u);
+                w = (w & m) | (fill_w & ~m);
+                if (nv >= 0) w = (w & ~(0xFFu << (8 * nv))) | (at_len << (8 * nv));
+            }
+            if (j0 < 0) w = (w & ~0xFFu) | static_cast<uint32_t>(p.bos_id);
+        }
+        uint8_t *col = s_t + (4 * g) * kRawStride + sb;
+        col[0] = static_cast<uint8_t>(w);
+        col[kRawStride] = static_cast<uint8_t>(w >> 8);
+        col[2 * kRawStride] = static_cast<uint8_t>(w >> 16);
+        col[3 * kRawStride] = static_cast<uint8_t>(w >> 24);
+    }
+    __syncthreads();
+    uint8_t *out = static_cast<uint8_t *>(p.out);
+    for (int f = tid; f < kTT * (kRawTB / 16); f += kThreads) {
+        const int32_t tl = f >> 4, q = f & 15;
+        const int64_t t = static_cast<int64_t>(t0) + tl;
+        if (t >= p.P) continue;
+        const uint8_t *src = s_t + tl * kRawStride + q * 16;
+        uint8_t *dst = out + t * p.B + b0 + q * 16;
+        if (p.aligned && b0 + q * 16 + 16 <= p.B) {
+            uint4 v;  // LDS rows are only 4-byte aligned (stride 260): four dword reads
+            v.x = *reinterpret_cast<const uint32_t *>(src);
+            v.y = *reinterpret_cast<const uint32_t *>(src + 4);
+            v.z = *reinterpret_cast<const uint32_t *>(src + 8);
+            v.w = *reinterpret_cast<const uint32_t *>(src + 12);
+            *reinterpret_cast<uint4 *>(dst) = v;
+        } else {
+            for (int i = 0; i < 16; ++i)
+                if (b0 + q * 16 + i < p.B) dst[i] = src[i];
         }
     }
 }
@@ -1012,8 +1087,7 @@ bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
 
 template <typename ST>
 bsq_status launch_expand(const EParams &e, hipStream_t s) {
-    const int64_t per_class = (e.nchunks + 7) / 8;
-    const int64_t groups = (per_class + int64_t(4) * e.cpw - 1) / (int64_t(4) * e.cpw);
+    const int64_t groups = ((e.nchunks + 7) / 8 + 3) / 4;
     const dim3 grid(unsigned(groups * 8));
     if (bsq_internal::nontemporal_stores())
         hipLaunchKernelGGL((k_expand_chunks<ST, true>), grid, dim3(kThreads), 0, s, e);
@@ -1027,11 +1101,9 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
     void *out = k.out;
     k.out = workspace;
     k.aligned = (reinterpret_cast<uintptr_t>(workspace) % 16 == 0) && (k.B % 16 == 0);
-    k.ntb = int32_t((k.B + 255) / 256);
-    const size_t smem = tile_fixed_bytes<256>();
-    hipLaunchKernelGGL((k_tokenize_tile<uint8_t, 256, true>), dim3(unsigned(int64_t(k.ntb) * k.ntt)), dim3(kThreads),
-                       smem, s, k);
-    bsq_status st = check_launch("k_tokenize_tile<raw>");
+    k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
+    hipLaunchKernelGGL(k_tokens_raw, dim3(unsigned(int64_t(k.ntb) * k.ntt)), dim3(kThreads), 0, s, k);
+    bsq_status st = check_launch("k_tokens_raw");
     if (st != BSQ_OK) return st;
     EParams e;
     e.tok = static_cast<const uint8_t *>(workspace);
@@ -1042,8 +1114,7 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
     e.nchunks = (e.head + e.total + kChunk - 1) / kChunk;
     e.C = k.C;
     e.one_bits = k.one_bits;
-    int cpw = bsq_internal::tuning("expand_cpw");
-    e.cpw = cpw > 0 ? cpw : 4;
+    e.cpw = 1;
     switch (sz) {
     case 1: return launch_expand<uint8_t>(e, s);
     case 2: return launch_expand<uint16_t>(e, s);
@@ -1100,9 +1171,21 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P) {
     if (!tiled_ok) return 0;
     int path = bsq_internal::tuning("onehot_path");
     if (path == 0) {
-        const int64_t rowbytes = C * int64_t(sz), pitch = B * rowbytes;
+        // Measured on MI355X over 17 shapes (profiles/r01/sweep_shapes2.txt):
+        //  3 chunk-owner: ~7 TB/s when a row is >= 48 B and its per-position gather set stays L2-resident, i.e.
+        //                 the pitch is a multiple of 32 KiB (each XCD keeps to its own chunk columns) and
+        //                 B <= 128k, or B <= 16k whatever the pitch;
+        //  2 two-pass   : 5.5-6.3 TB/s for any pitch once rows are >= 16 B and the output is large enough to
+        //                 amortise the second launch;
+        //  1 tiled      : the rest (tiny rows such as int8 DNA, small outputs).
+        const int64_t rowbytes = C * int64_t(sz), pitch = B * rowbytes, total = pitch * P;
         const bool pinned_columns = pitch % (8 * kChunk) == 0;
-        path = (rowbytes >= 48 && ((pinned_columns && B <= 262144) || B <= 16384)) ? 3 : 1;
+        if (rowbytes >= 48 && ((pinned_columns && B <= 131072) || B <= 16384))
+            path = 3;
+        else if (rowbytes >= 16 && total >= (int64_t(256) << 20))
+            path = 2;
+        else
+            path = 1;
     }
     return path;
 }
@@ -1111,7 +1194,7 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
     if (!d) return "";
     switch (choose_onehot_path(bsq_alphabet_size(d), bsq_dtype_size(t), B, P)) {
     case 1: return "k_onehot_tile";
-    case 2: return "k_tokenize_tile+k_expand_chunks";
+    case 2: return "k_tokens_raw+k_expand_chunks";
     case 3: return "k_onehot_chunks";
     default: return "k_onehot_generic";
     }
