@@ -39,6 +39,7 @@ WORKLOADS = {
     "cfg4f": ("cfg4", "onehot", "f", False),
     "cfg4b": ("cfg4", "onehot", "B", False),
     "cfg5": ("cfg5", "tokenize", "B", True),
+    "cfg5aug": ("cfg5", "augment+tokenize", "B", True),  # BASELINE config 5: BLOSUM62 augmentation, then SEB8 tokens
 }
 
 
@@ -140,7 +141,12 @@ def main():
     stream = torch.cuda.current_stream()
     sh = ctypes.c_void_p(stream.cuda_stream)
 
+    aug_seed = [0]
+
     def step():
+        if op == "augment+tokenize":  # AugmentedSeqDataset defaults (loaders.py:117-119): chain_len 1, frac 0.5
+            aug_seed[0] += 1
+            capi.check(lib.bsq_augment_device(d_chars.data_ptr(), d_offs.data_ptr(), n, 1, 0.5, aug_seed[0], sh))
         if op == "onehot":
             st = lib.bsq_onehot_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), None, n, P,
                                        dt_code, out.data_ptr(), sh)
@@ -214,7 +220,9 @@ def main():
             except Exception:
                 traffic = None
         kernel_name = (lib.bsq_onehot_kernel_name(ctypes.byref(desc), n, P, dt_code).decode() if op == "onehot"
-                       else ("k_tokenize_rows" if batch_first else "k_tokenize_tile"))
+                       else ("k_tokenize_chunks" if batch_first else "k_tokenize_tile"))
+        if op == "augment+tokenize":
+            kernel_name = "k_augment+" + kernel_name
         res = {
             "metric": "Gseq-chars/s + GB/s one-hot written, 64k x 1024 AMINO20" if args.workload == "cfg3"
                       else "Gseq-chars/s + GB/s written (%s)" % args.workload,
@@ -226,7 +234,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f": "f32", "B": "u8"}.get(destchar, destchar), "data": "synthetic",
             "config": {"workload": "%s: %s %s, %d seqs/GPU len~U(%d,%d), padlen %d, C=%d, %s output %s" % (
-                args.workload, cfg["key"], "batch_onehot_encode" if op == "onehot" else "batch_tokenize", n,
+                args.workload, cfg["key"], {"onehot": "batch_onehot_encode", "tokenize": "batch_tokenize"}.get(op, "BLOSUM62 augment + batch_tokenize"), n,
                 cfg["lo"], cfg["hi"], P, C, str(tdt).replace("torch.", ""),
                 "(P,B,C)" if op == "onehot" else ("(B,P)" if batch_first else "(P,B)")),
                 "sequences_per_gpu": n, "padlen": P, "channels": C, "input_chars_per_gpu": total,

@@ -17,8 +17,6 @@ Additions over the reference surface (all keyword-only / new names, defaults unc
 """
 from __future__ import annotations
 
-import os as _os
-
 from . import _hipruntime as _hipruntime
 
 _hipruntime.preload()  # share torch's bundled HIP runtime when torch is installed (see _hipruntime.py)
@@ -33,6 +31,7 @@ except ImportError as _e:  # fail loudly: the HIP extension IS the product
 
 from .cbioseq import Threading, Tokenizer, get_num_threads, set_num_threads  # noqa: F401
 from . import synth  # noqa: F401
+from . import blosum, sharding  # noqa: F401
 
 __version__ = "0.1.0"
 
@@ -154,4 +153,4 @@ __all__ = ["onehot_encode", "cbioseq", "f_encode", "Tokenizer", "make_embedding"
            "pos_tokenizers", "default_tokenizers", "total_tokenizer_dict", "get_tokenizer_dict", "DNATokenizer",
            "AmineTokenizer", "Reduced6Tokenizer", "Reduced8Tokenizer", "Reduced10Tokenizer", "Reduced14Tokenizer",
            "DayhoffTokenizer", "LIATokenizer", "LIBTokenizer", "torchify", "set_num_threads", "get_num_threads",
-           "Threading", "device_count", "synth"]
+           "Threading", "device_count", "synth", "blosum", "sharding"]

@@ -1,0 +1,177 @@
+// BLOSUM62 point-mutation augmentation on the device.
+//
+// Replaces the per-sequence pure-Python chain of /root/reference/bioseq/blosum.py:63-87
+// (`augment_seq`) and its table construction (:36-48 `normrows`): callers apply it to the byte strings
+// right before batch_tokenize / batch_onehot_encode (bioseq/loaders.py:83,102;
+// training/cnnpretrain.py:115-117).  Here it runs in place on the packed batch already in HBM.
+//
+// Algorithm per sequence (same as the reference): with probability `frac` mutate the sequence;
+// repeat chain_len times { repeat { idx = uniform position; new = draw from normrows[row(seq[idx])] }
+// until new != seq[idx]; seq[idx] = new }.  Unknown residues (anything outside the 20 letters, incl.
+// lower case) use the 'X' row, as probdict.get(c, default_transitions) does.
+// The random STREAM is our own (counter-based splitmix64 keyed by seed / sequence / mutation /
+// attempt; the reference uses a module-global numpy PCG64 that also depends on import order), so
+// parity is defined on the table (bit-exact), the invariants and the substitution statistics.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "bsq.h"
+#include "bsq_internal.h"
+
+namespace {
+
+constexpr int kRows = 21, kCols = 20;
+constexpr char kLetters[] = "ARNDCQEGHILKMFPSTWYV";  // column order; row order is the same + 'X'
+
+// BLOSUM62 scores, rows ARNDCQEGHILKMFPSTWYV + X, columns ARNDCQEGHILKMFPSTWYV (public NCBI matrix).
+constexpr int8_t kBlosum62[kRows][kCols] = {
+    /*A*/ {4, -1, -2, -2, 0, -1, -1, 0, -2, -1, -1, -1, -1, -2, -1, 1, 0, -3, -2, 0},
+    /*R*/ {-1, 5, 0, -2, -3, 1, 0, -2, 0, -3, -2, 2, -1, -3, -2, -1, -1, -3, -2, -3},
+    /*N*/ {-2, 0, 6, 1, -3, 0, 0, 0, 1, -3, -3, 0, -2, -3, -2, 1, 0, -4, -2, -3},
+    /*D*/ {-2, -2, 1, 6, -3, 0, 2, -1, -1, -3, -4, -1, -3, -3, -1, 0, -1, -4, -3, -3},
+    /*C*/ {0, -3, -3, -3, 9, -3, -4, -3, -3, -1, -1, -3, -1, -2, -3, -1, -1, -2, -2, -1},
+    /*Q*/ {-1, 1, 0, 0, -3, 5, 2, -2, 0, -3, -2, 1, 0, -3, -1, 0, -1, -2, -1, -2},
+    /*E*/ {-1, 0, 0, 2, -4, 2, 5, -2, 0, -3, -3, 1, -2, -3, -1, 0, -1, -3, -2, -2},
+    /*G*/ {0, -2, 0, -1, -3, -2, -2, 6, -2, -4, -4, -2, -3, -3, -2, 0, -2, -2, -3, -3},
+    /*H*/ {-2, 0, 1, -1, -3, 0, 0, -2, 8, -3, -3, -1, -2, -1, -2, -1, -2, -2, 2, -3},
+    /*I*/ {-1, -3, -3, -3, -1, -3, -3, -4, -3, 4, 2, -3, 1, 0, -3, -2, -1, -3, -1, 3},
+    /*L*/ {-1, -2, -3, -4, -1, -2, -3, -4, -3, 2, 4, -2, 2, 0, -3, -2, -1, -2, -1, 1},
+    /*K*/ {-1, 2, 0, -1, -3, 1, 1, -2, -1, -3, -2, 5, -1, -3, -1, 0, -1, -3, -2, -2},
+    /*M*/ {-1, -1, -2, -3, -1, 0, -2, -3, -2, 1, 2, -1, 5, 0, -2, -1, -1, -1, -1, 1},
+    /*F*/ {-2, -3, -3, -3, -2, -3, -3, -3, -1, 0, 0, -3, 0, 6, -4, -2, -2, 1, 3, -1},
+    /*P*/ {-1, -2, -2, -1, -3, -1, -1, -2, -2, -3, -3, -1, -2, -4, 7, -1, -1, -4, -3, -2},
+    /*S*/ {1, -1, 1, 0, -1, 0, 0, 0, -1, -2, -2, 0, -1, -2, -1, 4, 1, -3, -2, -2},
+    /*T*/ {0, -1, 0, -1, -1, -1, -1, -2, -2, -1, -1, -1, -1, -2, -1, 1, 5, -2, -2, 0},
+    /*W*/ {-3, -3, -4, -4, -2, -2, -3, -2, -2, -3, -2, -3, -1, 1, -4, -3, -2, 11, 2, -3},
+    /*Y*/ {-2, -2, -2, -3, -2, -1, -2, -3, 2, -1, -1, -2, -1, 3, -3, -2, -2, 2, 7, -1},
+    /*V*/ {0, -3, -3, -3, -1, -2, -2, -3, -3, 3, 1, -2, 1, -1, -2, -2, 0, -3, -1, 4},
+    /*X*/ {0, -1, -1, -1, -2, -1, -1, -1, -1, -1, -1, -1, -1, -1, -2, 0, 0, -2, -1, -1},
+};
+
+// normrows[a][:] = 2^score / sum(2^score)  (blosum.py:41-45).  Every 2^score is a power of two in
+// [2^-4, 2^11], so the row sum is exact in double whatever the summation order, and the quotient is one
+// correctly rounded IEEE division: bit-identical to numpy's result.
+void make_normrows(double out[kRows * kCols]) {
+    for (int r = 0; r < kRows; ++r) {
+        double sum = 0.0;
+        for (int c = 0; c < kCols; ++c) sum += std::ldexp(1.0, kBlosum62[r][c]);
+        for (int c = 0; c < kCols; ++c) out[r * kCols + c] = std::ldexp(1.0, kBlosum62[r][c]) / sum;
+    }
+}
+
+struct AugTable {
+    double cdf[kRows][kCols];  // inclusive prefix sums of normrows (left to right)
+    uint8_t row_of[256];       // byte -> row (20 = 'X' row for everything unknown)
+    uint8_t letter[kCols];
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// i-th 64-bit word of the stream keyed by (seed, sequence).  Host twin: tests/test_augment.py.
+__device__ __forceinline__ uint64_t rnd(uint64_t seed, uint64_t seq, uint64_t i) {
+    return mix64(mix64(seed + 0x9E3779B97F4A7C15ull * (seq + 1)) + 0xD1342543DE82EF95ull * (i + 1));
+}
+__device__ __forceinline__ double unit(uint64_t x) { return static_cast<double>(x >> 11) * 0x1.0p-53; }
+
+constexpr int kMaxAttempts = 1 << 14;  // rejection loop like the reference's `while inchar == outchar` (an all-W sequence accepts with p = 0.006 per try)
+
+__global__ __launch_bounds__(256) void k_augment(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len,
+                                                 double frac, uint64_t seed, const AugTable *tab) {
+    __shared__ AugTable s_tab;
+    for (int i = threadIdx.x; i < int(sizeof(AugTable) / 4); i += 256)
+        reinterpret_cast<uint32_t *>(&s_tab)[i] = reinterpret_cast<const uint32_t *>(tab)[i];
+    __syncthreads();
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int64_t start = offsets[b];
+    const int64_t L = offsets[b + 1] - start;
+    if (L <= 0) return;
+    uint64_t ctr = 0;
+    if (frac < 1.0 && !(unit(rnd(seed, b, ctr++)) < frac)) return;  // word 0 decides whether b is augmented
+    ctr = 1;
+    for (int32_t m = 0; m < chain_len; ++m) {
+        for (int a = 0; a < kMaxAttempts; ++a) {
+            const uint64_t r1 = rnd(seed, b, ctr++), r2 = rnd(seed, b, ctr++);
+            const int64_t idx = static_cast<int64_t>(__umul64hi(r1, static_cast<uint64_t>(L)));  // uniform in [0, L)
+            const uint8_t old = chars[start + idx];
+            const double *cdf = s_tab.cdf[s_tab.row_of[old]];
+            const double u = unit(r2) * cdf[kCols - 1];
+            int k = 0;
+            while (k < kCols - 1 && !(u < cdf[k])) ++k;
+            const uint8_t neu = s_tab.letter[k];
+            if (neu != old) {
+                chars[start + idx] = neu;
+                break;
+            }
+        }
+    }
+}
+
+AugTable *g_dev_table[16] = {};
+
+bsq_status device_table(AugTable **out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipGetDevice", e);
+    if (dev < 0 || dev >= 16) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "device ordinal out of range");
+    if (!g_dev_table[dev]) {
+        AugTable h;
+        double nr[kRows * kCols];
+        make_normrows(nr);
+        for (int r = 0; r < kRows; ++r) {
+            double acc = 0.0;
+            for (int c = 0; c < kCols; ++c) {
+                acc += nr[r * kCols + c];
+                h.cdf[r][c] = acc;
+            }
+        }
+        std::memset(h.row_of, kRows - 1, sizeof(h.row_of));
+        for (int c = 0; c < kCols; ++c) {
+            h.row_of[static_cast<unsigned char>(kLetters[c])] = static_cast<uint8_t>(c);
+            h.letter[c] = static_cast<uint8_t>(kLetters[c]);
+        }
+        AugTable *d = nullptr;
+        e = hipMalloc(reinterpret_cast<void **>(&d), sizeof(AugTable));
+        if (e != hipSuccess) return bsq_internal::set_hip_error("hipMalloc(augment table)", e);
+        e = hipMemcpy(d, &h, sizeof(AugTable), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("hipMemcpy(augment table)", e);
+        g_dev_table[dev] = d;
+    }
+    *out = g_dev_table[dev];
+    return BSQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+bsq_status bsq_blosum62_normrows(double *out21x20) {
+    if (!out21x20) return BSQ_ERR_INVALID_ARG;
+    make_normrows(out21x20);
+    return BSQ_OK;
+}
+
+bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len, double frac,
+                              uint64_t seed, void *hip_stream) {
+    if (!offsets || B < 0 || chain_len < 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bad augment arguments");
+    if (B == 0 || chain_len == 0 || !(frac > 0.0)) return BSQ_OK;
+    if (!chars) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "chars is null");
+    AugTable *tab = nullptr;
+    const bsq_status st = device_table(&tab);
+    if (st != BSQ_OK) return st;
+    const int64_t blocks = (B + 255) / 256;
+    if (blocks >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "batch too large");
+    hipLaunchKernelGGL(k_augment, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
+                       offsets, B, chain_len, frac, seed, tab);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return bsq_internal::set_hip_error("k_augment", e);
+    return BSQ_OK;
+}
+
+}  // extern "C"

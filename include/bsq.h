@@ -128,6 +128,16 @@ bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip
 bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32_t seg, int32_t rows_per_wave,
                                    int32_t order, int32_t interleave, int32_t nt, void *hip_stream);
 
+/* ---- BLOSUM62 augmentation (the pre-step of BASELINE config 5): replaces bioseq/blosum.py:36-87.
+ * bsq_blosum62_normrows: the 21x20 float64 transition table `normrows` (rows ARNDCQEGHILKMFPSTWYV+X,
+ * columns ARNDCQEGHILKMFPSTWYV), bit-identical to the reference's numpy result.
+ * bsq_augment_device: in place on a packed batch in device memory; every sequence is mutated with
+ * probability `frac` (>= 1: always) by `chain_len` BLOSUM62-weighted point substitutions (new != old),
+ * unknown residues use the X row.  Deterministic in (seed, sequence index); stream-ordered. */
+bsq_status bsq_blosum62_normrows(double *out21x20);
+bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len, double frac,
+                              uint64_t seed, void *hip_stream);
+
 /* ---- host entry points: packed batch in HOST memory (pageable or pinned).  The library stages
  * it through its own pinned + device buffers on the current HIP device, runs the device entry
  * point on `hip_stream`, and leaves the result in `out`:
