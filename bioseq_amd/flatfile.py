@@ -1,0 +1,183 @@
+"""FlatFile: the reference's random-access sequence store as a ZERO-COPY batch source.
+
+On-disk format (/root/reference/src/fxstats.cpp:33-64, reader :66-75):
+
+    uint64 nseqs | uint64 offsets[nseqs + 1] | sequence bytes, concatenated
+
+which is exactly the packed batch (`chars`, `offsets`) the device kernels consume.  The reference
+materialises a `bytearray` per sequence (`access`, fxstats.cpp:128-133) and the tokenizer then
+re-extracts the pointers; here `packed(start, stop)` hands a slice of the memory-mapped file straight
+to `Tokenizer.tokenize_packed` / `onehot_packed`, and `to_device()` uploads the whole store once so
+that batches are encoded from HBM with no per-batch host work at all.
+
+Same Python surface as `cbioseq.FlatFile` (fxstats.cpp:166-200): `FlatFile(path, maxseqlen=-1)` opens
+a `.ff`, `FlatFile(fastx, out)` builds it from FASTA/FASTQ (optionally gzipped) first; `access`,
+`__getitem__` (int / slice / index array), `nseqs()`, `size()`, `len()`, `seq_offset()`, `indptr()`,
+`maxseqlen` / `max_seq_len`, `path`.
+"""
+from __future__ import annotations
+
+import gzip
+import os
+
+import numpy as np
+
+
+def _read_fastx(path):
+    """Sequences of a FASTA / FASTQ file (plain or gzip), kseq.h semantics: a record starts at a '>' or
+    '@' line; its sequence is every following line up to the next '>' / '@' / '+' line, whitespace
+    dropped; after '+' as many quality characters as sequence characters are skipped."""
+    with open(path, "rb") as f:
+        gz = f.read(2) == b"\x1f\x8b"
+    with (gzip.open if gz else open)(path, "rb") as f:
+        lines = [l.rstrip(b"\r") for l in f.read().split(b"\n")]
+    seqs, i, n = [], 0, len(lines)
+    while i < n:
+        if lines[i][:1] not in (b">", b"@"):
+            i += 1
+            continue
+        i += 1
+        parts = []
+        while i < n and lines[i][:1] not in (b">", b"@", b"+"):
+            parts.append(b"".join(lines[i].split()))
+            i += 1
+        seq = b"".join(parts)
+        seqs.append(seq)
+        if i < n and lines[i][:1] == b"+":
+            i += 1
+            got = 0
+            while i < n and got < len(seq):
+                got += len(lines[i])
+                i += 1
+    return seqs
+
+
+def write_flatfile(seqs, path):
+    """Write sequences (bytes / str) in the FlatFile format; returns `path`."""
+    items = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offsets = np.zeros(len(items) + 1, dtype="<u8")
+    if items:
+        np.cumsum([len(x) for x in items], out=offsets[1:])
+    with open(path, "wb") as f:
+        f.write(np.array([len(items)], dtype="<u8").tobytes())
+        f.write(offsets.tobytes())
+        for x in items:
+            f.write(x)
+    return path
+
+
+class FlatFile:
+    def __init__(self, inputfile, maxseqlen=-1):
+        """FlatFile(path_to_ff, maxseqlen=-1) opens a store; FlatFile(fastx_path, out_path) builds one first
+        (`out_path == ''` -> fastx_path + '.ff'), as the reference's two constructors do."""
+        if isinstance(maxseqlen, str):
+            out = maxseqlen or inputfile + ".ff"
+            write_flatfile(_read_fastx(inputfile), out)
+            inputfile, maxseqlen = out, -1
+        self.path = inputfile
+        self._mm = np.memmap(inputfile, mode="r", dtype=np.uint8) if os.path.getsize(inputfile) else np.zeros(8, np.uint8)
+        self._n = int(self._mm[:8].view("<u8")[0])
+        self._seq_offset = (self._n + 2) * 8
+        self._offsets = self._mm[8:self._seq_offset].view("<u8").astype(np.int64)  # small copy: B+1 entries
+        self._chars = self._mm[self._seq_offset:self._seq_offset + int(self._offsets[-1])]
+        if maxseqlen is None or maxseqlen < 0:
+            maxseqlen = int(np.diff(self._offsets).max()) if self._n else 0
+        self._maxseqlen = int(maxseqlen)
+        self._dev = {}
+
+    # ---- reference surface ------------------------------------------------------------------
+    def nseqs(self):
+        return self._n
+
+    size = nseqs
+
+    def __len__(self):
+        return self._n
+
+    def seq_offset(self):
+        return self._seq_offset
+
+    def indptr(self):
+        return self._offsets.astype(np.uint64)
+
+    @property
+    def maxseqlen(self):
+        return self._maxseqlen
+
+    max_seq_len = maxseqlen
+
+    def _one(self, i):
+        if i < 0 or i >= self._n:
+            raise IndexError("Accessing sequence out of range")
+        return bytearray(self._chars[self._offsets[i]:self._offsets[i + 1]].tobytes())
+
+    def access(self, start, stop=None, step=1):
+        if isinstance(start, slice):
+            return [self._one(i) for i in range(*start.indices(self._n))]
+        if stop is None:
+            return self._one(int(start))
+        if step == 0:
+            raise ValueError("step must be nonzero")
+        return [self._one(i) for i in range(int(start), int(stop), int(step))]
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            return self.access(idx)
+        if isinstance(idx, (np.ndarray, list, tuple)):
+            return [self[int(i)] for i in np.asarray(idx).ravel()]
+        idx = int(idx)
+        if idx < 0:
+            if idx < -self._n:
+                raise IndexError("For a negative index, idx must be >= -len(x)")
+            idx += self._n
+        return self._one(idx)
+
+    def __iter__(self):
+        for i in range(self._n):
+            yield self._one(i)
+
+    # ---- zero-copy batch source -------------------------------------------------------------
+    def packed(self, start=0, stop=None):
+        """(chars uint8 view into the mapped file, offsets int64 rebased to 0) of sequences [start, stop)."""
+        stop = self._n if stop is None else min(int(stop), self._n)
+        start = max(0, int(start))
+        offs = self._offsets[start:stop + 1]
+        return self._chars[offs[0]:offs[-1]], offs - offs[0]
+
+    def to_device(self, device="cuda"):
+        """Upload the whole store once; returns (chars, offsets) device tensors (cached per device)."""
+        import torch
+        dev = torch.device(device)
+        if dev not in self._dev:
+            self._dev[dev] = (torch.from_numpy(np.ascontiguousarray(self._chars)).to(dev),
+                              torch.from_numpy(self._offsets).to(dev))
+        return self._dev[dev]
+
+    def packed_device(self, start=0, stop=None, device="cuda"):
+        """Device-resident packed batch of sequences [start, stop): views of the uploaded store + a
+        rebased offsets tensor -- no host work, no copy of the characters."""
+        chars, offs = self.to_device(device)
+        stop = self._n if stop is None else min(int(stop), self._n)
+        o = offs[start:stop + 1]
+        c0, c1 = int(self._offsets[start]), int(self._offsets[stop])
+        return chars[c0:c1], o - o[0]
+
+    def batch_tokenize(self, tokenizer, start=0, stop=None, padlen=None, destchar="B", batch_first=True, device=None):
+        """`tokenizer.batch_tokenize(ff.access(start, stop), ...)` without materialising the sequences
+        (cf. FF2NP, bioseq/loaders.py:11-26).  padlen defaults to maxseqlen + bos + eos."""
+        if padlen is None:
+            padlen = self._maxseqlen + tokenizer.includes_bos() + tokenizer.includes_eos()
+        if device is not None:
+            c, o = self.packed_device(start, stop, device)
+        else:
+            c, o = self.packed(start, stop)
+        return tokenizer.tokenize_packed(c, o, padlen, destchar, batch_first)
+
+    def batch_onehot_encode(self, tokenizer, start=0, stop=None, padlen=None, destchar="B", device=None):
+        if padlen is None:
+            padlen = self._maxseqlen + tokenizer.includes_bos() + tokenizer.includes_eos()
+        if device is not None:
+            c, o = self.packed_device(start, stop, device)
+        else:
+            c, o = self.packed(start, stop)
+        return tokenizer.onehot_packed(c, o, padlen, destchar)

@@ -2,7 +2,7 @@
 """Generate the committed golden fixtures from the REAL reference (build container only).
 
 Needs /root/reference and oracle/_ref/cbioseq*.so (`make -C oracle ref`): the reference's own
-src/tokenize.cpp + src/omp.cpp compiled in place, plus the reference's pure-Python package
+src/tokenize.cpp + src/omp.cpp + src/fxstats.cpp compiled in place, plus the reference's pure-Python package
 imported from /root/reference for the module-level facade (bioseq/__init__.py:36-168) and the
 BLOSUM table (bioseq/blosum.py:36-48).  Only DATA is written here (inputs are regenerated from
 bioseq_amd/synth.py seeds; expected outputs are stored as raw arrays or sha256 digests).
@@ -16,6 +16,7 @@ Files written next to this script:
     small_cases.npz  raw expected arrays for small ragged/dirty batches (all dtypes, layouts, masks)
     facade.npz/json  outputs of bioseq.onehot_encode / f_encode and the tokenizer-dict key lists
     blosum_normrows.npy
+    flatfile_small.fa/.ff  a small FASTA/FASTQ text and the FlatFile the reference writes from it
 """
 import argparse
 import hashlib
@@ -222,6 +223,17 @@ def facade():
     np.save(os.path.join(HERE, "blosum_normrows.npy"), blosum.normrows.astype("<f8"))
 
 
+def flatfile_fixture():
+    """tests/golden/flatfile_small.{fa,ff}: the .ff is written by the reference's own FlatFile
+    (src/fxstats.cpp:33-64) from the small FASTA/FASTQ text next to it."""
+    fa = os.path.join(HERE, "flatfile_small.fa")
+    with open(fa, "w") as f:
+        f.write(">sp|P1|first protein\nMKVLAAGIVGLLLA\nQPSNA\n>empty\n\n>third x\nACDEFGHIKLMNPQRSTVWY\nacdef\n"
+                "@read1\nACGTN\n+\nIIIII\n>last\nWWWW\n")
+    cbioseq.FlatFile(fa, os.path.join(HERE, "flatfile_small.ff"))
+
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -229,5 +241,7 @@ if __name__ == "__main__":
     alphabets()
     small_cases()
     facade()
+    flatfile_fixture()
     kats(a.full)
     print("golden fixtures written to", HERE)
+
