@@ -35,6 +35,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 WORKLOADS = {
     #        synth config, op, destchar, batch_first
     "cfg3": ("cfg3", "onehot", "f", False),
+    "cfg3bcl": ("cfg3", "onehot_bcl", "f", False),  # channels-first (B,C,P) written directly (loader layout)
     "cfg2": ("cfg2", "tokenize", "B", True),
     "cfg4f": ("cfg4", "onehot", "f", False),
     "cfg4b": ("cfg4", "onehot", "B", False),
@@ -130,8 +131,8 @@ def main():
 
     d_chars = torch.from_numpy(chars).to(dev)
     d_offs = torch.from_numpy(offsets).to(dev)
-    if op == "onehot":
-        out = torch.empty((P, n, C), dtype=tdt, device=dev)
+    if op in ("onehot", "onehot_bcl"):
+        out = torch.empty((P, n, C) if op == "onehot" else (n, C, P), dtype=tdt, device=dev)
         out_bytes = P * n * C * sz
     else:
         out = torch.empty((n, P) if batch_first else (P, n), dtype=tdt, device=dev)
@@ -150,6 +151,9 @@ def main():
         if op == "onehot":
             st = lib.bsq_onehot_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), None, n, P,
                                        dt_code, out.data_ptr(), sh)
+        elif op == "onehot_bcl":
+            st = lib.bsq_onehot_bcl_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), None, n, P,
+                                           dt_code, out.data_ptr(), sh)
         else:
             st = lib.bsq_tokenize_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), n, P,
                                          int(batch_first), dt_code, out.data_ptr(), sh)
@@ -167,7 +171,7 @@ def main():
     out.fill_(7)
     step()
     torch.cuda.synchronize()
-    if op == "onehot":
+    if op in ("onehot", "onehot_bcl"):
         ones = int(out.sum(dtype=torch.float64).item())
         expect = total + (n if desc.bos else 0) + (n if desc.eos else 0)
         if desc.padchar:
@@ -223,6 +227,8 @@ def main():
                        else ("k_tokenize_chunks" if batch_first else "k_tokenize_tile"))
         if op == "augment+tokenize":
             kernel_name = "k_augment+" + kernel_name
+        if op == "onehot_bcl":
+            kernel_name = "k_tokenize_chunks<onehot bcl>"
         res = {
             "metric": "Gseq-chars/s + GB/s one-hot written, 64k x 1024 AMINO20" if args.workload == "cfg3"
                       else "Gseq-chars/s + GB/s written (%s)" % args.workload,
@@ -234,9 +240,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f": "f32", "B": "u8"}.get(destchar, destchar), "data": "synthetic",
             "config": {"workload": "%s: %s %s, %d seqs/GPU len~U(%d,%d), padlen %d, C=%d, %s output %s" % (
-                args.workload, cfg["key"], {"onehot": "batch_onehot_encode", "tokenize": "batch_tokenize"}.get(op, "BLOSUM62 augment + batch_tokenize"), n,
+                args.workload, cfg["key"], {"onehot": "batch_onehot_encode", "tokenize": "batch_tokenize", "onehot_bcl": "batch_onehot_encode(layout=bcl)"}.get(op, "BLOSUM62 augment + batch_tokenize"), n,
                 cfg["lo"], cfg["hi"], P, C, str(tdt).replace("torch.", ""),
-                "(P,B,C)" if op == "onehot" else ("(B,P)" if batch_first else "(P,B)")),
+                "(P,B,C)" if op == "onehot" else "(B,C,P)" if op == "onehot_bcl" else ("(B,P)" if batch_first else "(P,B)")),
                 "sequences_per_gpu": n, "padlen": P, "channels": C, "input_chars_per_gpu": total,
                 "output_bytes_per_gpu": out_bytes, "sharding": "by sequence, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

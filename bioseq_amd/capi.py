@@ -67,6 +67,7 @@ def load():
         "bsq_validate_lengths_device": (i32, [vp, i64, i64, i32, i32, i64p, vp]),
         "bsq_tokenize_device": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, vp]),
         "bsq_onehot_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
+        "bsq_onehot_bcl_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
         "bsq_onehot_kernel_name": (ctypes.c_char_p, [dp, i64, i64, c_int]),
         "bsq_tokenize_device_generic": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, vp]),
         "bsq_onehot_device_generic": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
@@ -76,6 +77,7 @@ def load():
         "bsq_augment_device": (i32, [vp, vp, i64, i32, ctypes.c_double, ctypes.c_uint64, vp]),
         "bsq_tokenize_host": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, c_int, vp, i64p]),
         "bsq_onehot_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),
+        "bsq_onehot_bcl_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),
         "bsq_pinned_scratch": (vp, [sz]),
         "bsq_release_staging": (None, []),
     }

@@ -337,4 +337,17 @@ bsq_status bsq_onehot_host(const bsq_desc *d, const uint8_t *chars, const int64_
                     });
 }
 
+bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                               const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                               bsq_space out_space, void *hip_stream, int64_t *first_bad) {
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    const size_t C = d ? size_t(bsq_alphabet_size(d)) : 0;
+    const size_t out_bytes = (B > 0 && P > 0) ? size_t(P) * size_t(B) * C * sz : 0;
+    return run_host(d, chars, offsets, mask_or_null, B, P, d ? d->bos : 0, d ? d->eos : 0, out_bytes, out,
+                    out_space, hip_stream, first_bad, [&](const DeviceBatch &db, void *dev_out, hipStream_t s) {
+                        return bsq_onehot_bcl_device(d, db.chars, db.offsets, db.mask, B, P, t, dev_out, s);
+                    });
+}
+
 }  // extern "C"

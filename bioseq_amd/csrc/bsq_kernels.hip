@@ -553,6 +553,10 @@ struct TParams {
     int32_t bos;
     uint32_t bos_id, at_len_id, fill_id;
     int32_t room;
+    // one-hot (B,C,P) mode only:
+    const uint8_t *mask;
+    int32_t C;
+    uint64_t one_bits;
 };
 
 // N characters held as whole words (bytes are extracted only where they are consumed, so the loads
@@ -579,24 +583,30 @@ struct __attribute__((packed, aligned(1))) UBytes<2> {
     __device__ __forceinline__ void clear() { h = 0; }
 };
 
-template <typename T, bool NT>
+// HOT = false: (B,P) tokens of type T.  HOT = true: the "channels-first" one-hot (B,C,P) that conv nets
+// consume (the reference gets it with einops.rearrange('length batch emb -> batch emb length') + .float(),
+// bioseq/loaders.py:74): row = b*C + c of the flat (B*C, P) matrix holds (token(b,t) == c) -- the same
+// character-row reader, compared against the row's channel instead of converted to a value.
+template <typename T, bool NT, bool HOT>
 __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     __shared__ __align__(16) uint8_t s_lut4[4][256];
     constexpr int SZ = static_cast<int>(sizeof(T));
     constexpr int EPL = 16 / SZ;  // elements (= characters) per lane per store
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint8_t *lut = s_lut4[wave];
-    {   // wave-private table of token VALUES: unmapped / >= 0x80 -> 0 (the memset value of tokenize.h:427)
+    {   // wave-private table: token VALUES (unmapped / >= 0x80 -> 0, the memset value of tokenize.h:427),
+        // or raw ids with kNone for the one-hot mode
         uint32_t w = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int idx = lane * 4 + q;
             const int8_t v = p.lut[idx];
-            const uint32_t e = (idx < 128 && v >= 0) ? static_cast<uint32_t>(v) : 0u;
+            const uint32_t e = (idx < 128 && v >= 0) ? static_cast<uint32_t>(v) : (HOT ? kNone : 0u);
             w |= e << (8 * q);
         }
         reinterpret_cast<uint32_t *>(lut)[lane] = w;
     }
+    const int64_t nrows = HOT ? p.B * p.C : p.B;
     const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave);
     if (k >= p.nchunks) return;
     const int64_t total_chars = p.offsets[p.B];
@@ -606,7 +616,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     const int64_t e0 = (lo + lane * 16) / SZ;
     int64_t b0;
     int32_t t00;
-    if (p.B * p.P < (int64_t(1) << 32)) {
+    if (nrows * p.P < (int64_t(1) << 32)) {
         const uint32_t q = static_cast<uint32_t>(e0) / static_cast<uint32_t>(p.P);
         b0 = q;
         t00 = static_cast<int32_t>(static_cast<uint32_t>(e0) - q * static_cast<uint32_t>(p.P));
@@ -617,15 +627,22 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     // stage A: row coordinates + offsets of all four stores (unconditional: 8 independent loads in flight)
     bool live[4];
     int32_t t0[4];
+    uint32_t chan[4];
     int64_t start[4], stop[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t tt = static_cast<uint32_t>(t00) + static_cast<uint32_t>(u) * EPS;
         const uint32_t q = tt / static_cast<uint32_t>(p.P);
-        int64_t b = b0 + q;
+        int64_t b = b0 + q;  // row of the flat matrix
         t0[u] = static_cast<int32_t>(tt - q * static_cast<uint32_t>(p.P));
-        live[u] = b < p.B;
-        b = live[u] ? b : p.B - 1;
+        live[u] = b < nrows;
+        b = live[u] ? b : nrows - 1;
+        chan[u] = 0;
+        if constexpr (HOT) {  // row = sequence * C + channel
+            const int64_t seq = b / p.C;
+            chan[u] = static_cast<uint32_t>(b - seq * p.C);
+            b = seq;
+        }
         start[u] = p.offsets[b];
         stop[u] = p.offsets[b + 1];
     }
@@ -648,10 +665,17 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
         fast[u] = can_vec && need && a >= 0 && a + EPL <= total_chars;
         slow[u] = need && !fast[u];
     }
+    UBytes<EPL> mw[4];  // mask bytes (one-hot mode with a mask): 0 -> the position is an all-zero row
+    const bool has_mask = HOT && p.mask != nullptr;
     if (can_vec) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             cw[u] = *reinterpret_cast<const UBytes<EPL> *>(p.chars + (fast[u] ? start[u] + t0[u] - p.bos : 0));
+        if (has_mask) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                mw[u] = *reinterpret_cast<const UBytes<EPL> *>(p.mask + (fast[u] ? start[u] + t0[u] - p.bos : 0));
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) cw[u].clear();
@@ -661,17 +685,22 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
         if (slow[u]) {  // first / last bytes of the buffer: never read outside it
             const int32_t j0 = t0[u] - p.bos;
             cw[u].clear();
+            if (has_mask) mw[u].clear();
 #pragma unroll
             for (int i = 0; i < EPL; ++i)
-                if (j0 + i >= 0 && j0 + i < L[u]) cw[u].set_byte(i, p.chars[start[u] + j0 + i]);
+                if (j0 + i >= 0 && j0 + i < L[u]) {
+                    cw[u].set_byte(i, p.chars[start[u] + j0 + i]);
+                    if (has_mask) mw[u].set_byte(i, p.mask[start[u] + j0 + i]);
+                }
         }
     }
     // stage C: LUT lookups packed 4 (or 2) per word; BOS / EOS / PAD folded in with word masks
     constexpr int WB = EPL >= 4 ? 4 : EPL;  // characters per word
     const uint32_t ones = WB == 4 ? 0x01010101u : 0x0101u;
-    const uint32_t fill_v = p.fill_id == kNone ? 0u : p.fill_id;
-    const uint32_t at_len_v = p.at_len_id == kNone ? 0u : p.at_len_id;
+    const uint32_t fill_v = (!HOT && p.fill_id == kNone) ? 0u : p.fill_id;
+    const uint32_t at_len_v = (!HOT && p.at_len_id == kNone) ? 0u : p.at_len_id;
     const uint32_t fill_w = fill_v * ones;
+    const T hot_one = static_cast<T>(p.one_bits);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (!live[u]) continue;
@@ -681,7 +710,11 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
         for (int q = 0; q < EPL / WB; ++q) {
             uint32_t w = 0;
 #pragma unroll
-            for (int i = 0; i < WB; ++i) w |= static_cast<uint32_t>(lut[cw[u].byte(q * WB + i)]) << (8 * i);
+            for (int i = 0; i < WB; ++i) {
+                uint32_t tk = lut[cw[u].byte(q * WB + i)];
+                if (has_mask && mw[u].byte(q * WB + i) == 0) tk = kNone;
+                w |= tk << (8 * i);
+            }
             const int32_t jf = j0 + q * WB;  // character index of the word's first byte
             const int32_t nv = L[u] - jf;    // characters of the sequence left from there
             if (nv < WB) {
@@ -691,7 +724,13 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
             }
             if (jf < 0) w = (w & ~0xFFu) | p.bos_id;  // position 0 with BOS
 #pragma unroll
-            for (int i = 0; i < WB; ++i) vals[q * WB + i] = static_cast<T>((w >> (8 * i)) & 0xFFu);
+            for (int i = 0; i < WB; ++i) {
+                const uint32_t tk = (w >> (8 * i)) & 0xFFu;
+                if constexpr (HOT)
+                    vals[q * WB + i] = tk == chan[u] ? hot_one : T(0);
+                else
+                    vals[q * WB + i] = static_cast<T>(tk);
+            }
         }
         store16<NT>(p.out + lo + u * 1024 + lane * 16, *reinterpret_cast<const uint4 *>(vals));
     }
@@ -733,9 +772,19 @@ __global__ __launch_bounds__(kThreads) void k_onehot_generic(const GParams p) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
     T *out = static_cast<T *>(p.out);
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; e < n; e += stride) {
-        const int64_t r = e / p.C;
-        const int32_t c = static_cast<int32_t>(e - r * p.C);
-        const int64_t t = r / p.B, b = r - t * p.B;
+        int64_t t, b;
+        int32_t c;
+        if (p.batch_first == 2) {  // (B, C, P)
+            const int64_t r = e / p.P;
+            t = e - r * p.P;
+            b = r / p.C;
+            c = static_cast<int32_t>(r - b * p.C);
+        } else {  // (P, B, C)
+            const int64_t r = e / p.C;
+            c = static_cast<int32_t>(e - r * p.C);
+            t = r / p.B;
+            b = r - t * p.B;
+        }
         const int32_t tk = token_at(p, b, t);
         out[e] = (tk == c) ? T(1) : T(0);
     }
@@ -1132,16 +1181,19 @@ bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
     return check_launch("k_tokenize_tile");
 }
 
-template <typename T>
+template <typename T, bool HOT>
 bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     TParams c;
     for (int i = 0; i < 256; ++i) c.lut[i] = k.lut[i];
     c.chars = k.chars;
     c.offsets = k.offsets;
+    c.mask = HOT ? k.mask : nullptr;
     c.out = static_cast<uint8_t *>(k.out);
     c.B = k.B;
     c.P = k.P;
-    c.total = k.B * k.P * int64_t(sizeof(T));
+    c.C = k.C;
+    c.one_bits = k.one_bits;
+    c.total = k.B * k.P * int64_t(sizeof(T)) * (HOT ? k.C : 1);
     c.nchunks = (c.total + kChunk - 1) / kChunk;
     c.bos = k.bos;
     c.bos_id = uint32_t(k.bos_id);
@@ -1153,10 +1205,10 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
     if (bsq_internal::nontemporal_stores())
-        hipLaunchKernelGGL((k_tokenize_chunks<T, true>), grid, dim3(kThreads), 0, s, c);
+        hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT>), grid, dim3(kThreads), 0, s, c);
     else
-        hipLaunchKernelGGL((k_tokenize_chunks<T, false>), grid, dim3(kThreads), 0, s, c);
-    return check_launch("k_tokenize_chunks");
+        hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT>), grid, dim3(kThreads), 0, s, c);
+    return check_launch(HOT ? "k_tokenize_chunks<onehot bcl>" : "k_tokenize_chunks");
 }
 
 }  // namespace
@@ -1252,12 +1304,12 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     if (batch_first && bsq_internal::tuning("tokenize_path") != 1 && addr % 16 == 0 &&
         P % int64_t(16 / sz) == 0) {  // chunk kernel: every lane's 16 output bytes lie inside one row
         switch (t) {
-        case BSQ_I8: return launch_tokenize_chunks<int8_t>(k, s);
-        case BSQ_I16: return launch_tokenize_chunks<int16_t>(k, s);
-        case BSQ_I32: return launch_tokenize_chunks<int32_t>(k, s);
-        case BSQ_U64: return launch_tokenize_chunks<uint64_t>(k, s);
-        case BSQ_F32: return launch_tokenize_chunks<float>(k, s);
-        case BSQ_F64: return launch_tokenize_chunks<double>(k, s);
+        case BSQ_I8: return launch_tokenize_chunks<int8_t, false>(k, s);
+        case BSQ_I16: return launch_tokenize_chunks<int16_t, false>(k, s);
+        case BSQ_I32: return launch_tokenize_chunks<int32_t, false>(k, s);
+        case BSQ_U64: return launch_tokenize_chunks<uint64_t, false>(k, s);
+        case BSQ_F32: return launch_tokenize_chunks<float, false>(k, s);
+        case BSQ_F64: return launch_tokenize_chunks<double, false>(k, s);
         }
     }
     if (batch_first) {
@@ -1286,6 +1338,43 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     case BSQ_F64: return launch_tokenize_tile<double, 64>(k, s);
     }
     return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+}
+
+// Channels-first one-hot (B, C, P).  Fast path: chunk kernel (needs P % (16/sizeof(T)) == 0, a 16-byte
+// aligned base and 8-bit ids); otherwise the generic element kernel.
+bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                 const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                                 void *hip_stream) {
+    KParams k;
+    bsq_status st = fill_common(k, d, chars, offsets, mask_or_null, B, P, out);
+    if (st != BSQ_OK) return st;
+    if (B == 0) return BSQ_OK;
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    k.one_bits = one_bits_of(t);
+    if (k.C <= 250 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && P % int64_t(16 / sz) == 0) {
+        switch (sz) {
+        case 1: return launch_tokenize_chunks<uint8_t, true>(k, s);
+        case 2: return launch_tokenize_chunks<uint16_t, true>(k, s);
+        case 4: return launch_tokenize_chunks<uint32_t, true>(k, s);
+        default: return launch_tokenize_chunks<uint64_t, true>(k, s);
+        }
+    }
+    GParams g;
+    fill_generic(g, d, chars, offsets, mask_or_null, B, P, 2, out);
+    const unsigned grid = generic_grid(P * B * g.C);
+#define BSQ_GEN(T) hipLaunchKernelGGL((k_onehot_generic<T>), dim3(grid), dim3(kThreads), 0, s, g)
+    switch (t) {
+    case BSQ_I8: BSQ_GEN(int8_t); break;
+    case BSQ_I16: BSQ_GEN(int16_t); break;
+    case BSQ_I32: BSQ_GEN(int32_t); break;
+    case BSQ_U64: BSQ_GEN(uint64_t); break;
+    case BSQ_F32: BSQ_GEN(float); break;
+    case BSQ_F64: BSQ_GEN(double); break;
+    }
+#undef BSQ_GEN
+    return check_launch("k_onehot_generic<bcl>");
 }
 
 bsq_status bsq_onehot_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,

@@ -338,8 +338,15 @@ class Tokenizer {
     }
 
     // batch_onehot_encode (tokenize.cpp:65-81 -> tokenize.h:283-371); always (P, B, C)
+    static bool parse_layout(const std::string &layout) {  // true: channels-first (B, C, P)
+        if (layout == "tbc" || layout == "seq_first" || layout.empty()) return false;
+        if (layout == "bcl" || layout == "channels_first") return true;
+        throw std::invalid_argument("layout must be 'tbc' (padlen, batch, channels) or 'bcl' (batch, channels, padlen)");
+    }
+
     py::object batch_onehot_encode(py::sequence batch, py::ssize_t padlen, const std::string &dt, int nthreads,
-                                   const py::object &mask, const py::object &device) const {
+                                   const py::object &mask, const py::object &device, const std::string &layout) const {
+        const bool bcl = parse_layout(layout);
         const bsq_dtype t = parse_dtype(dt);
         check_padlen(padlen);
         if (nthreads <= 0) nthreads = 1;
@@ -348,13 +355,14 @@ class Tokenizer {
         PackLock lock;
         const Packed p = pack(g, nthreads);
         OutBuf out;
-        make_out(out, {padlen, p.B, py::ssize_t(bsq_alphabet_size(&desc))}, t, device);
+        const py::ssize_t C = py::ssize_t(bsq_alphabet_size(&desc));
+        make_out(out, bcl ? std::vector<py::ssize_t>{p.B, C, padlen} : std::vector<py::ssize_t>{padlen, p.B, C}, t, device);
         int64_t bad = -1;
         bsq_status st;
         {
             py::gil_scoped_release nogil;
-            st = bsq_onehot_host(&desc, p.chars, p.offsets, p.mask, p.B, padlen, t, out.ptr, out.space, out.stream,
-                                 &bad);
+            st = (bcl ? bsq_onehot_bcl_host : bsq_onehot_host)(&desc, p.chars, p.offsets, p.mask, p.B, padlen, t, out.ptr,
+                                                               out.space, out.stream, &bad);
         }
         if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(p.offsets, bad, padlen);
         if (st != BSQ_OK) throw_status(st);
@@ -366,7 +374,7 @@ class Tokenizer {
     // the layout of the reference's FlatFile, fxstats.cpp:33-64).
     py::object encode_packed(bool onehot, const py::object &chars_o, const py::object &offsets_o,
                              py::ssize_t padlen, const std::string &dt, bool batch_first, const py::object &mask_o,
-                             const py::object &device_o, bool validate) const {
+                             const py::object &device_o, bool validate, bool bcl = false) const {
         const bsq_dtype t = parse_dtype(dt);
         check_padlen(padlen);
         ArrayArg chars = as_array(chars_o, "uint8", 1, "chars");
@@ -387,7 +395,7 @@ class Tokenizer {
                 throw std::invalid_argument("device= differs from the device of the packed batch");
         }
         const py::ssize_t C = bsq_alphabet_size(&desc);
-        std::vector<py::ssize_t> shape = onehot ? std::vector<py::ssize_t>{padlen, B, C}
+        std::vector<py::ssize_t> shape = onehot ? (bcl ? std::vector<py::ssize_t>{B, C, padlen} : std::vector<py::ssize_t>{padlen, B, C})
                                                 : (batch_first ? std::vector<py::ssize_t>{B, padlen}
                                                                : std::vector<py::ssize_t>{padlen, B});
         PackLock lock;
@@ -403,9 +411,10 @@ class Tokenizer {
                 st = BSQ_OK;
                 if (validate) st = bsq_validate_lengths_device(offs, B, padlen, desc.bos, desc.eos, &bad, out.stream);
                 if (st == BSQ_OK)
-                    st = onehot ? bsq_onehot_device(&desc, static_cast<const uint8_t *>(chars.ptr), offs,
-                                                    has_mask ? static_cast<const uint8_t *>(mask.ptr) : nullptr, B,
-                                                    padlen, t, out.ptr, out.stream)
+                    st = onehot ? (bcl ? bsq_onehot_bcl_device : bsq_onehot_device)(
+                                      &desc, static_cast<const uint8_t *>(chars.ptr), offs,
+                                      has_mask ? static_cast<const uint8_t *>(mask.ptr) : nullptr, B, padlen, t, out.ptr,
+                                      out.stream)
                                 : bsq_tokenize_device(&desc, static_cast<const uint8_t *>(chars.ptr), offs, B, padlen,
                                                       batch_first, t, out.ptr, out.stream);
             }
@@ -421,9 +430,10 @@ class Tokenizer {
                 if (offs[i + 1] < offs[i]) throw std::invalid_argument("offsets must be non-decreasing");
             {
                 py::gil_scoped_release nogil;
-                st = onehot ? bsq_onehot_host(&desc, static_cast<const uint8_t *>(chars.ptr), offs,
-                                              has_mask ? static_cast<const uint8_t *>(mask.ptr) : nullptr, B, padlen, t,
-                                              out.ptr, out.space, out.stream, &bad)
+                st = onehot ? (bcl ? bsq_onehot_bcl_host : bsq_onehot_host)(
+                                  &desc, static_cast<const uint8_t *>(chars.ptr), offs,
+                                  has_mask ? static_cast<const uint8_t *>(mask.ptr) : nullptr, B, padlen, t, out.ptr,
+                                  out.space, out.stream, &bad)
                             : bsq_tokenize_host(&desc, static_cast<const uint8_t *>(chars.ptr), offs, B, padlen,
                                                 batch_first, t, out.ptr, out.space, out.stream, &bad);
             }
@@ -553,7 +563,7 @@ PYBIND11_MODULE(cbioseq, m) {
              py::arg("device") = py::none())
         .def("batch_onehot_encode", &Tokenizer::batch_onehot_encode, py::arg("batch"), py::arg("padlen") = -1,
              py::arg("destchar") = "B", py::arg("nthreads") = 1, py::arg("mask") = py::none(), py::kw_only(),
-             py::arg("device") = py::none())
+             py::arg("device") = py::none(), py::arg("layout") = "tbc")
         .def("tokenize_packed",
              [](const Tokenizer &t, const py::object &chars, const py::object &offsets, py::ssize_t padlen,
                 const std::string &dt, bool batch_first, const py::object &device, bool validate) {
@@ -563,11 +573,14 @@ PYBIND11_MODULE(cbioseq, m) {
              py::arg("batch_first") = false, py::arg("device") = py::none(), py::arg("validate") = true)
         .def("onehot_packed",
              [](const Tokenizer &t, const py::object &chars, const py::object &offsets, py::ssize_t padlen,
-                const std::string &dt, const py::object &mask, const py::object &device, bool validate) {
-                 return t.encode_packed(true, chars, offsets, padlen, dt, false, mask, device, validate);
+                const std::string &dt, const py::object &mask, const py::object &device, bool validate,
+                const std::string &layout) {
+                 return t.encode_packed(true, chars, offsets, padlen, dt, false, mask, device, validate,
+                                        Tokenizer::parse_layout(layout));
              },
              py::arg("chars"), py::arg("offsets"), py::arg("padlen"), py::arg("destchar") = "B",
-             py::arg("mask") = py::none(), py::arg("device") = py::none(), py::arg("validate") = true)
+             py::arg("mask") = py::none(), py::arg("device") = py::none(), py::arg("validate") = true,
+             py::arg("layout") = "tbc")
         .def("onehot_encode",
              [](const Tokenizer &t, py::str s, py::ssize_t padlen, const std::string &dt) {
                  Py_ssize_t n = 0;

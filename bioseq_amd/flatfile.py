@@ -149,7 +149,7 @@ class FlatFile:
         import torch
         dev = torch.device(device)
         if dev not in self._dev:
-            self._dev[dev] = (torch.from_numpy(np.ascontiguousarray(self._chars)).to(dev),
+            self._dev[dev] = (torch.from_numpy(np.array(self._chars, copy=True)).to(dev),
                               torch.from_numpy(self._offsets).to(dev))
         return self._dev[dev]
 

@@ -1,0 +1,115 @@
+"""Dataset layer over FlatFile + Tokenizer -- the surface of /root/reference/bioseq/loaders.py, with the
+batch as the unit of work.
+
+The reference's `FlatFileDataset.__getitem__` tokenises ONE sequence per call on the host
+(`batch_tokenize([seq], ...)`, loaders.py:84,103) and the DataLoader stacks the results.  Here a batch is
+encoded by ONE launch from the FlatFile's packed bytes (`get_batch`, and `__getitems__` for
+torch >= 2 DataLoader batched fetching), optionally after BLOSUM62 augmentation on the device, and the
+conv-net layout 'length batch emb -> batch emb length' + .float() (loaders.py:74) is written directly
+by the kernel (`layout="bcl"`, float32) instead of being produced by a permute + cast.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import blosum
+from .flatfile import FlatFile
+
+
+def FF2NP(x, tokenizer, destfile, *, batch_size=8192):
+    """FlatFile -> (nseqs, maxseqlen + bos + eos) uint8 token memmap (loaders.py:11-26), one encode per batch."""
+    assert isinstance(x, FlatFile)
+    msl = x.maxseqlen
+    total_msl = msl + tokenizer.includes_bos() + tokenizer.includes_eos()
+    nseqs = x.nseqs()
+    retmat = np.memmap(destfile, mode='w+', dtype=np.uint8, shape=(nseqs, total_msl))
+    for start in range(0, nseqs, batch_size):
+        stop = min(start + batch_size, nseqs)
+        retmat[start:stop] = x.batch_tokenize(tokenizer, start, stop, padlen=total_msl, destchar='B',
+                                              batch_first=True).view(np.uint8)
+    return (retmat, destfile)
+
+
+class FlatFileDataset(torch.utils.data.Dataset):
+    """FlatFile + Tokenizer dataset (loaders.py:29-115).
+
+    cnn=False: items are token rows (max_seq_len,) int64; cnn=True: one-hot (C, max_seq_len) float32.
+    `augment` BLOSUM62 point mutations are applied to a sequence with probability `augment_frac`
+    (>= 1: always) before encoding.  `get_batch(start, stop)` / `__getitems__(indices)` return the
+    stacked batch -- (B, P) int64 or (B, C, P) float32 on `device` -- from a single encode.
+    """
+
+    def __init__(self, ff, tokenizer, *, augment=0, augment_frac=0.5, cnn=False, device=None, maskfrac=0.15, seed=13):
+        super().__init__()
+        assert isinstance(ff, FlatFile)
+        if device is None:
+            device = torch.device("cuda")
+        self.device = torch.device(device)
+        self.ff = ff
+        self.tokenizer = tokenizer
+        self.max_seq_len = ff.maxseqlen + tokenizer.includes_bos() + tokenizer.includes_eos()
+        self.maxseqlen = self.max_seq_len
+        self.augment = augment
+        self.augment_frac = augment_frac
+        self.cnn = cnn
+        self.maskfrac = maskfrac
+        self._seed = int(seed)
+        self._calls = 0
+
+    def __len__(self):
+        return self.ff.nseqs()
+
+    def _packed_device(self, start, stop, indices=None):
+        if indices is None:
+            chars, offs = self.ff.packed_device(start, stop, self.device)
+            if self.augment:
+                chars = chars.clone()  # never mutate the resident store
+        else:  # arbitrary index set: gather on the host side of the mapped file, one upload
+            hc, ho = self.ff.packed(0, None)
+            lens = (ho[1:] - ho[:-1])[indices]
+            offs_np = np.zeros(len(indices) + 1, dtype=np.int64)
+            np.cumsum(lens, out=offs_np[1:])
+            buf = np.empty(int(offs_np[-1]), dtype=np.uint8)
+            for k, i in enumerate(indices):
+                buf[offs_np[k]:offs_np[k + 1]] = hc[ho[i]:ho[i + 1]]
+            chars, offs = torch.from_numpy(buf).to(self.device), torch.from_numpy(offs_np).to(self.device)
+        if self.augment:
+            self._calls += 1
+            blosum.augment_packed(chars, offs, self.augment, self.augment_frac, self._seed + self._calls)
+        return chars, offs
+
+    def _encode(self, chars, offs):
+        if self.cnn:
+            return self.tokenizer.onehot_packed(chars, offs, self.max_seq_len, "f", layout="bcl")
+        return self.tokenizer.tokenize_packed(chars, offs, self.max_seq_len, "B", True).to(torch.long)
+
+    def get_batch(self, start, stop):
+        """Sequences [start, stop) as one encoded batch on the device."""
+        return self._encode(*self._packed_device(start, stop))
+
+    def __getitems__(self, indices):
+        idx = [int(i) % len(self) for i in indices]
+        if idx and idx == list(range(idx[0], idx[0] + len(idx))):
+            return self.get_batch(idx[0], idx[-1] + 1)
+        return self._encode(*self._packed_device(0, 0, idx))
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            s, e, st = index.indices(len(self))
+            return self.__getitems__(list(range(s, e, st)))
+        index = int(index) % len(self)
+        return self.get_batch(index, index + 1)[0]
+
+    def access(self, slc, stop=None, step=None):
+        if isinstance(slc, int):
+            slc = slice(slc, stop, step)
+        return self[slc]
+
+    def cleanup(self):
+        pass
+
+
+class AugmentedSeqDataset(FlatFileDataset):
+    def __init__(self, ff, tokenizer, augment=1, augment_frac=.5, **kw):
+        super().__init__(ff, tokenizer, augment=augment, augment_frac=augment_frac, **kw)

@@ -109,6 +109,12 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
 bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                              const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                              void *hip_stream);
+/* Channels-first one-hot (B, C, P): out[(b*C + c)*P + t] = (token(b,t) == c) -- what the reference's conv
+ * models get from rearrange('length batch emb -> batch emb length') (bioseq/loaders.py:74), written
+ * directly.  Same semantics (mask, BOS/EOS/PAD, unmapped -> zero row) as bsq_onehot_device. */
+bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                 const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                                 void *hip_stream);
 /* Name of the kernel(s) bsq_onehot_device would launch for this shape (profiling / bench labels). */
 const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_dtype t);
 /* Same results through the simple one-thread-per-element kernels (any shape/alignment/alphabet).
@@ -150,6 +156,10 @@ bsq_status bsq_tokenize_host(const bsq_desc *d, const uint8_t *chars, const int6
 bsq_status bsq_onehot_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                            const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                            bsq_space out_space, void *hip_stream, int64_t *first_bad);
+
+bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                               const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
+                               bsq_space out_space, void *hip_stream, int64_t *first_bad);
 
 /* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer):
  * returns a buffer of at least nbytes that stays valid until the next call on this thread. */

@@ -1,0 +1,67 @@
+"""Channels-first (B,C,P) one-hot written directly by the kernel, and the batch-granular dataset layer
+(SURVEY.md 8f-3).  Expected values: the oracle's (P,B,C) tensor, transposed."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("key,flags,d", [("AMINO20", (0, 0, 0), "f"), ("DNA", (1, 1, 1), "b"), ("SEB8", (1, 0, 1), "d"),
+                                          ("DNA5", (0, 1, 0), "h"), ("BYTES", (1, 1, 1), "i")])
+def test_bcl_equals_transposed_reference_layout(gpu, bsq, oracle, key, flags, d):
+    import torch
+    from bioseq_amd import synth
+    for B, P, hi in ((257, 64, 60), (33, 200, 198), (5, 17, 10), (1000, 16, 14)):
+        chars, offs = synth.synth_packed(B + P, B, 0, hi, synth.DIRTY)
+        seqs = synth.unpack(chars, offs)
+        tok, ora = bsq.Tokenizer(key, *flags), oracle.OracleTokenizer(key, *flags)
+        mask_b = (np.arange(chars.size) % 5 != 0).astype(np.uint8)
+        mask = [mask_b[offs[i]:offs[i + 1]].copy() for i in range(B)]
+        for m, mb in ((None, None), (mask, mask_b)):
+            exp = np.ascontiguousarray(ora.batch_onehot_encode(seqs, padlen=P, destchar=d, mask=m).transpose(1, 2, 0))
+            got = tok.batch_onehot_encode(seqs, padlen=P, destchar=d, mask=m, layout="bcl")
+            assert got.dtype == exp.dtype and got.shape == exp.shape == (B, tok.alphabet_size(), P)
+            assert got.tobytes() == exp.tobytes()
+            dev = tok.onehot_packed(torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu), P, d,
+                                    mask=None if mb is None else torch.from_numpy(mb).to(gpu), layout="bcl")
+            assert dev.is_cuda and dev.cpu().numpy().tobytes() == exp.tobytes()
+    with pytest.raises(ValueError, match="layout"):
+        tok.batch_onehot_encode(seqs, padlen=P, layout="cbl")
+
+
+def test_dataset_batches_match_per_item_reference_semantics(gpu, bsq, oracle, tmp_path):
+    import torch
+    from bioseq_amd import synth
+    from bioseq_amd.flatfile import FlatFile, write_flatfile
+    from bioseq_amd.loaders import FF2NP, AugmentedSeqDataset, FlatFileDataset
+    chars, offs = synth.synth_packed(12, 500, 1, 120, synth.AA)
+    seqs = synth.unpack(chars, offs)
+    ff = FlatFile(write_flatfile(seqs, str(tmp_path / "d.ff")))
+    tok, ora = bsq.pbeos_tokenizers["PROTEIN"], oracle.OracleTokenizer("PROTEIN", 1, 1, 1)
+    P = ff.maxseqlen + 2
+    exp_tok = ora.batch_tokenize(seqs, padlen=P, batch_first=True)
+    exp_oh = np.ascontiguousarray(ora.batch_onehot_encode(seqs, padlen=P, destchar="f").transpose(1, 2, 0))
+    ds = FlatFileDataset(ff, tok, device=gpu)
+    assert len(ds) == 500 and ds.max_seq_len == P
+    b = ds.get_batch(100, 228)
+    assert b.dtype == torch.long and tuple(b.shape) == (128, P) and (b.cpu().numpy() == exp_tok[100:228]).all()
+    assert (ds[7].cpu().numpy() == exp_tok[7]).all() and tuple(ds[7].shape) == (P,)           # reference item shape
+    assert (ds.__getitems__([5, 499, 17]).cpu().numpy() == exp_tok[[5, 499, 17]]).all()       # scattered indices
+    assert (ds[10:20].cpu().numpy() == exp_tok[10:20]).all()
+    dl = torch.utils.data.DataLoader(ds, batch_size=64, shuffle=False, collate_fn=lambda x: x)
+    got = torch.cat([x for x in dl]).cpu().numpy()
+    assert (got == exp_tok).all()
+    cnn = FlatFileDataset(ff, tok, cnn=True, device=gpu)
+    o = cnn.get_batch(0, 500)
+    assert o.dtype == torch.float32 and o.is_contiguous() and tuple(o.shape) == (500, tok.alphabet_size(), P)
+    assert o.cpu().numpy().tobytes() == exp_oh.tobytes()
+    assert cnn[3].cpu().numpy().tobytes() == exp_oh[3].tobytes()
+    # augmentation: ~half of the sequences differ in exactly one residue; the resident store is untouched
+    aug = AugmentedSeqDataset(ff, tok, device=gpu)
+    a = aug.get_batch(0, 500).cpu().numpy()
+    ndiff = (a != exp_tok).sum(axis=1)
+    assert set(np.unique(ndiff)) <= {0, 1} and 180 < (ndiff == 1).sum() < 320
+    assert (ds.get_batch(0, 500).cpu().numpy() == exp_tok).all()
+    # FF2NP: token memmap of the whole store
+    mat, path = FF2NP(ff, tok, str(tmp_path / "toks.u8"), batch_size=128)
+    assert mat.shape == (500, P) and (np.asarray(mat).view(np.int8) == exp_tok).all()
