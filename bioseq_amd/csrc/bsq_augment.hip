@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 
 #include "bsq.h"
 #include "bsq_internal.h"
@@ -114,8 +115,10 @@ __global__ __launch_bounds__(256) void k_augment(uint8_t *chars, const int64_t *
 }
 
 AugTable *g_dev_table[16] = {};
+std::mutex g_table_mu;
 
 bsq_status device_table(AugTable **out) {
+    std::lock_guard<std::mutex> lock(g_table_mu);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return bsq_internal::set_hip_error("hipGetDevice", e);

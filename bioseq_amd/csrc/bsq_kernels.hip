@@ -355,24 +355,31 @@ struct EParams {
     uint64_t one_bits;
 };
 
-template <typename ST, bool NT>
+// WPC = waves per chunk: 1 -> a wave writes a whole 4-KiB chunk (4 stores); 4 -> the workgroup's four waves
+// write one chunk, 1 KiB (one store) each -- the exact shape of the fastest plain fill.
+template <typename ST, bool NT, int WPC>
 __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
-    __shared__ __align__(16) uint8_t s_img[4][kChunk];
+    constexpr int PIECE = kChunk / WPC;       // bytes per wave
+    constexpr int NS = PIECE / 1024;          // 16-byte stores per lane
+    __shared__ __align__(16) uint8_t s_img[4][PIECE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint8_t *img = s_img[wave];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
+    for (int u = 0; u < NS; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
 
-    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave);
-    if (k >= p.nchunks) return;  // one chunk per wave, then the wave retires
+    // chunk of this wave: class = blockIdx % 8 (pinned to the XCD the block lands on)
+    const int64_t slot = static_cast<int64_t>(blockIdx.x >> 3) * (4 / WPC) + (WPC == 1 ? wave : 0);
+    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot;
+    if (k >= p.nchunks) return;
     const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
     const ST one = static_cast<ST>(p.one_bits);
-    int64_t lo = k * kChunk - p.head, hi = lo + kChunk;  // byte range of the chunk relative to `out`
+    int64_t lo = k * kChunk - p.head + (WPC == 1 ? 0 : wave * PIECE), hi = lo + PIECE;  // byte range relative to `out`
     if (lo < 0) lo = 0;
     if (hi > p.total) hi = p.total;
+    if (hi <= lo) return;
     const int32_t len = static_cast<int32_t>(hi - lo);
-    const int64_t r_lo = lo / rowbytes;                               // first row intersecting the chunk
-    const int32_t skip = static_cast<int32_t>(lo - r_lo * rowbytes);  // bytes of row r_lo before the chunk
+    const int64_t r_lo = lo / rowbytes;                               // first row intersecting the piece
+    const int32_t skip = static_cast<int32_t>(lo - r_lo * rowbytes);  // bytes of row r_lo before the piece
     const int32_t nr = (skip + len + rowbytes - 1) / rowbytes;        // rows intersecting it
     const uint8_t *tok = p.tok + r_lo;
     // scatter: row r_lo + i has its one at image byte i*rowbytes - skip + tok*sizeof(ST).
@@ -394,16 +401,13 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint8_t *g = p.out + lo;
-    if (len == kChunk) {
-        const uint4 v0 = *reinterpret_cast<const uint4 *>(img + lane * 16);
-        const uint4 v1 = *reinterpret_cast<const uint4 *>(img + 1024 + lane * 16);
-        const uint4 v2 = *reinterpret_cast<const uint4 *>(img + 2048 + lane * 16);
-        const uint4 v3 = *reinterpret_cast<const uint4 *>(img + 3072 + lane * 16);
-        store16<NT>(g + lane * 16, v0);
-        store16<NT>(g + 1024 + lane * 16, v1);
-        store16<NT>(g + 2048 + lane * 16, v2);
-        store16<NT>(g + 3072 + lane * 16, v3);
-    } else {  // clipped first / last chunk of the tensor
+    if (len == PIECE && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        uint4 v[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) v[u] = *reinterpret_cast<const uint4 *>(img + u * 1024 + lane * 16);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) store16<NT>(g + u * 1024 + lane * 16, v[u]);
+    } else {  // clipped first / last piece of the tensor
         for (int32_t o = lane * static_cast<int32_t>(sizeof(ST)); o < len; o += 64 * static_cast<int32_t>(sizeof(ST)))
             *reinterpret_cast<ST *>(g + o) = *reinterpret_cast<const ST *>(img + o);
     }
@@ -1136,12 +1140,21 @@ bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
 
 template <typename ST>
 bsq_status launch_expand(const EParams &e, hipStream_t s) {
-    const int64_t groups = ((e.nchunks + 7) / 8 + 3) / 4;
+    // One wave per chunk by default; "expand_cpw" = 44 selects 4 waves per chunk (measured 1.6x slower:
+    // every wave then pays the token-load latency for a single 1-KiB store).
+    const bool quarter = bsq_internal::tuning("expand_cpw") == 44;
+    const int64_t per_class = (e.nchunks + 7) / 8;
+    const int64_t groups = quarter ? per_class : (per_class + 3) / 4;
+    if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
-    if (bsq_internal::nontemporal_stores())
-        hipLaunchKernelGGL((k_expand_chunks<ST, true>), grid, dim3(kThreads), 0, s, e);
-    else
-        hipLaunchKernelGGL((k_expand_chunks<ST, false>), grid, dim3(kThreads), 0, s, e);
+    const bool nt = bsq_internal::nontemporal_stores();
+    if (quarter) {
+        if (nt) hipLaunchKernelGGL((k_expand_chunks<ST, true, 4>), grid, dim3(kThreads), 0, s, e);
+        else hipLaunchKernelGGL((k_expand_chunks<ST, false, 4>), grid, dim3(kThreads), 0, s, e);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_expand_chunks<ST, true, 1>), grid, dim3(kThreads), 0, s, e);
+        else hipLaunchKernelGGL((k_expand_chunks<ST, false, 1>), grid, dim3(kThreads), 0, s, e);
+    }
     return check_launch("k_expand_chunks");
 }
 

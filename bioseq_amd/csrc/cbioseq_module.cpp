@@ -480,7 +480,11 @@ class Tokenizer {
     }
 
     // decode_tokens (tokenize.h:131-183): 1-D -> str, 2-D -> list of str.
-    py::object decode_tokens(py::array array) const {
+    py::object decode_tokens(py::object obj) const {
+        if (py::hasattr(obj, "detach") && py::hasattr(obj, "cpu"))  // torch tensor (possibly on the device)
+            obj = obj.attr("detach")().attr("cpu")().attr("numpy")();
+        py::array array = py::array::ensure(obj);
+        if (!array) throw std::invalid_argument("decode_tokens expects a numpy array or torch tensor");
         py::buffer_info info = array.request();
         if (info.ptr == nullptr) throw std::invalid_argument("Empty array cannot yield a decoded string");
         if (info.ndim > 2 || info.ndim == 0)
