@@ -111,11 +111,19 @@ def main():
 
     if not torch.cuda.is_available() or bioseq_amd.device_count() < 1:
         sys.exit("bench.py needs a HIP device: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BSQ_BENCH_BACKEND=gloo + BSQ_BENCH_SHARE_GPU=1: smoke-test the N > 1 code path on a 1-GPU box
+    # (ranks share device 0; never a measurement).  The driver's runs use nccl = RCCL, one GPU per rank.
+    backend = os.environ.get("BSQ_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("BSQ_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tiny timing reductions live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
+        else:
+            dist.init_process_group(backend)
 
     cfg_name, op, destchar, batch_first = WORKLOADS[args.workload]
     cfg = synth.CONFIGS[cfg_name]
@@ -228,15 +236,15 @@ def main():
             assert full.shape[1 if (op == "onehot" or (op == "tokenize" and not batch_first)) else 0] == n * world
             del full
         gms = gms[1:]  # first one warms RCCL up
-        gt = torch.tensor([float(np.mean(gms))], dtype=torch.float64, device=dev)
+        gt = torch.tensor([float(np.mean(gms))], dtype=torch.float64, device=red_dev)
         dist.all_reduce(gt, op=dist.ReduceOp.MAX)
         gather_info = {"ms": float(gt.item()), "bytes_received_per_rank": out_bytes * (world - 1),
                        "gb_per_s_into_each_rank": out_bytes * (world - 1) / (float(gt.item()) * 1e-3) / 1e9,
                        "what": "all_gather of every rank's shard into a staging list + concatenation along the batch axis "
                                "(whole batch on every rank); encode time excluded"}
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    tot_t = torch.tensor([float(total), float(out_bytes)], dtype=torch.float64, device=dev)
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
+    tot_t = torch.tensor([float(total), float(out_bytes)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_t, op=dist.ReduceOp.SUM)
