@@ -76,17 +76,6 @@ __device__ __forceinline__ uint32_t load_u32_aligned(uintptr_t addr) {
     return *reinterpret_cast<global_u32_ptr>(addr);
 }
 
-// Four consecutive bytes starting at the arbitrary address `x`, of which only [lo, hi) are
-// needed (and valid).  Reads at most the two naturally aligned words that contain a needed byte,
-// so it never touches a word that lies wholly outside the caller's buffer.
-__device__ __forceinline__ uint32_t load4_unaligned(uintptr_t x, uintptr_t lo, uintptr_t hi) {
-    const uintptr_t w0 = x & ~uintptr_t(3);
-    uint32_t a = 0, b = 0;
-    if (lo < w0 + 4) a = load_u32_aligned(w0);
-    if (hi > w0 + 4) b = load_u32_aligned(w0 + 4);
-    return __builtin_amdgcn_alignbyte(b, a, static_cast<uint32_t>(x & 3));
-}
-
 // Tokens of positions tpos..tpos+3 of one sequence, packed little-endian into a dword.
 // s_lut holds the alphabet table with unmapped == kNone.  Semantics follow
 // /root/reference/src/tokenize.h:342-369 (one-hot) and :454-479 (tokens):
@@ -108,31 +97,71 @@ __device__ __forceinline__ TokenRule make_rule(const KParams &k) {
     return r;
 }
 
+// The raw words behind 4 consecutive characters (and their mask bytes).  fetch4 issues its loads
+// UNCONDITIONALLY -- a word that holds no needed byte is replaced by a load of the word containing
+// chars[0] -- so that callers can keep many fetch4's in flight before the first finish4 consumes one.
+// Still never touches a word that lies wholly outside the buffer.
+struct Raw4 {
+    uint32_t a, b, ma, mb, sh;
+};
+
+template <bool MASK = true>
+__device__ __forceinline__ Raw4 fetch4(const TokenRule p, int64_t start, int32_t L, int32_t tpos) {
+    const int32_t j0 = tpos - p.bos;
+    const uintptr_t base = p.chars + static_cast<uintptr_t>(start);
+    const uintptr_t x = base + j0;
+    const uintptr_t w0 = x & ~uintptr_t(3);
+    const bool any = j0 + 4 > 0 && j0 < L;
+    const uintptr_t lo = base + (j0 < 0 ? 0 : j0), hi = base + ((j0 + 4 < L) ? j0 + 4 : L);
+    const bool need_a = any && lo < w0 + 4, need_b = any && hi > w0 + 4;
+    const uintptr_t safe = p.chars & ~uintptr_t(3);  // the aligned word holding chars[0]
+    Raw4 r;
+    r.sh = static_cast<uint32_t>(x & 3);
+    r.a = load_u32_aligned(need_a ? w0 : safe);
+    r.b = load_u32_aligned(need_b ? w0 + 4 : safe);
+    r.ma = r.mb = 0xFFFFFFFFu;
+    if (MASK && p.mask) {  // wave-uniform
+        const uintptr_t d = p.mask - p.chars;  // same offsets in the mask array
+        const uintptr_t msafe = p.mask & ~uintptr_t(3);
+        const uintptr_t mw0 = (x + d) & ~uintptr_t(3);
+        // the mask array may be aligned differently from chars: redo the need tests on its own words
+        const uintptr_t mlo = lo + d, mhi = hi + d;
+        r.ma = load_u32_aligned((any && mlo < mw0 + 4) ? mw0 : msafe);
+        r.mb = load_u32_aligned((any && mhi > mw0 + 4) ? mw0 + 4 : msafe);
+        r.sh |= static_cast<uint32_t>((x + d) & 3) << 8;
+    }
+    return r;
+}
+
+// Tokens of positions tpos..tpos+3 from the fetched words: four LUT lookups packed into one word, then
+// mask / PAD / EOS / BOS applied to the packed word.  Bytes fetched from outside [0, L) are garbage but
+// every such position is overwritten by the rules below.
+template <bool MASK = true>
+__device__ __forceinline__ uint32_t finish4(const TokenRule p, const uint8_t *s_lut, const Raw4 r, int32_t L,
+                                            int32_t tpos) {
+    const int32_t j0 = tpos - p.bos;
+    const uint32_t cw = __builtin_amdgcn_alignbyte(r.b, r.a, r.sh & 3u);
+    uint32_t w = static_cast<uint32_t>(s_lut[cw & 0xFFu]) | (static_cast<uint32_t>(s_lut[(cw >> 8) & 0xFFu]) << 8) |
+                 (static_cast<uint32_t>(s_lut[(cw >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(s_lut[cw >> 24]) << 24);
+    if (MASK && p.mask) {
+        const uint32_t mw = __builtin_amdgcn_alignbyte(r.mb, r.ma, (r.sh >> 8) & 3u);
+        uint32_t z = (mw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;  // exact zero-byte detection:
+        z = ~(z | mw | 0x7F7F7F7Fu);                     // 0x80 in every byte of mw that is zero
+        w |= (z >> 7) * 0xFFu;                           // masked position -> kNone
+    }
+    const int32_t nv = L - j0;  // characters of the sequence left from the word's first byte
+    if (nv < 4) {
+        const uint32_t m = nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u);
+        w = (w & m) | ((p.fill_id * 0x01010101u) & ~m);                             // beyond bos+L: PAD / none
+        if (nv >= 0) w = (w & ~(0xFFu << (8 * nv))) | (p.at_len_id << (8 * nv));  // position bos+L: EOS
+    }
+    if (j0 < 0) w = (w & ~0xFFu) | p.bos_id;  // position 0 with BOS
+    return w;
+}
+
 __device__ __forceinline__ uint32_t resolve4(const TokenRule p, const uint8_t *s_lut, int64_t start, int32_t L,
                                              int32_t tpos) {
-    const int32_t j0 = tpos - p.bos;  // character index of the first position (-1 only for BOS)
-    uint32_t cw = 0, mw = 0xFFFFFFFFu;
-    if (j0 + 4 > 0 && j0 < L) {
-        const uintptr_t base = p.chars + static_cast<uintptr_t>(start);
-        const int32_t jlo = j0 < 0 ? 0 : j0;
-        const int32_t jhi = (j0 + 4 < L) ? j0 + 4 : L;
-        cw = load4_unaligned(base + j0, base + jlo, base + jhi);
-        if (p.mask) {
-            const uintptr_t mbase = p.mask + static_cast<uintptr_t>(start);
-            mw = load4_unaligned(mbase + j0, mbase + jlo, mbase + jhi);
-        }
-    }
-    uint32_t packed = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int32_t j = j0 + i;
-        uint32_t tk = s_lut[(cw >> (8 * i)) & 0xFFu];
-        if (((mw >> (8 * i)) & 0xFFu) == 0) tk = kNone;
-        if (j >= L) tk = (j == L) ? p.at_len_id : p.fill_id;
-        if (j < 0) tk = p.bos_id;
-        packed |= (tk & 0xFFu) << (8 * i);
-    }
-    return packed;
+    return finish4(p, s_lut, fetch4(p, start, L, tpos), L, tpos);
 }
 
 __device__ __forceinline__ void stage_lut(const KParams &p, uint8_t *s_lut) {
@@ -163,14 +192,27 @@ __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, i
     }
     __syncthreads();
     const int g = tid & 15;  // 16 lanes x 4 characters cover the 64 positions of one sequence
-    for (int sb = tid >> 4; sb < TB; sb += kThreads / 16) {
-        uint32_t packed = kNone * 0x01010101u;
-        if (b0 + sb < p.B) {
-            const int64_t start = s_off[sb];
-            const int32_t L = clamp_len(p, s_off[sb + 1] - start);
-            packed = resolve4(rule, s_lut, start, L, t0 + 4 * g);
+    const bool have_chars = p.offsets[p.B] > 0;  // uniform; an all-empty batch has no word to read
+    constexpr int NI = TB / 16;                  // sequences per thread
+    constexpr int BATCH = NI < 4 ? NI : 4;       // fetches kept in flight (more costs occupancy: 129 VGPRs at 8)
+    for (int i0 = 0; i0 < NI; i0 += BATCH) {
+        Raw4 raw[BATCH];
+        int32_t len[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int sb = (tid >> 4) + 16 * (i0 + k);
+            const bool ok = have_chars && b0 + sb < p.B;
+            const int64_t start = ok ? s_off[sb] : 0;
+            len[k] = (b0 + sb < p.B) ? clamp_len(p, s_off[sb + 1] - s_off[sb]) : 0;
+            raw[k] = have_chars ? fetch4(rule, start, ok ? len[k] : 0, t0 + 4 * g) : Raw4{0, 0, ~0u, ~0u, 0};
         }
-        *reinterpret_cast<uint32_t *>(s_tok + sb * kTokStride + 4 * g) = packed;
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int sb = (tid >> 4) + 16 * (i0 + k);
+            uint32_t packed = kNone * 0x01010101u;
+            if (b0 + sb < p.B) packed = finish4(rule, s_lut, raw[k], len[k], t0 + 4 * g);
+            *reinterpret_cast<uint32_t *>(s_tok + sb * kTokStride + 4 * g) = packed;
+        }
     }
     __syncthreads();
 }
@@ -344,7 +386,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
 constexpr int kChunk = 4096;
 
 struct EParams {
-    const uint8_t *tok;  // nrows raw tokens (kNone = no one)
+    const uint8_t *tok;  // nrows = P*B raw tokens in (P,B) order (kNone = no one)
     uint8_t *out;        // output base (any alignment that is a multiple of sizeof(ST))
     int64_t total;       // output bytes
     int64_t nrows;       // P * B
@@ -414,12 +456,17 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
 }
 
 // Raw (P,B) uint8 tokens (kNone kept) for k_expand_chunks.  Workgroup = 256 sequences x 64 positions.
-// Phase 1: 4 characters per lane (two aligned words + alignbyte), 4 LUT lookups packed into a word, BOS /
-// EOS / PAD / mask folded in with byte masks, written TRANSPOSED into LDS (row = position).  Phase 2:
-// each position row of the tile is 256 contiguous bytes of the output: ds_read_b128 -> 16-byte stores.
+// Phase 1: 4 characters per lane (two aligned words + alignbyte, 8 fetches of a thread in flight together),
+// 4 LUT lookups packed into a word, mask / PAD / EOS / BOS applied to the packed word, bytes written
+// TRANSPOSED into LDS (row = position; the four sequences a wave handles per step are 4 apart so the 64
+// byte-writes of an instruction fall on 32 banks).  Phase 2: each position row of the tile is 256 contiguous
+// bytes of the output: dword LDS reads -> 16-byte stores.
+// (Measured alternatives that did NOT help: a tile-major scratch written as whole 4-KiB chunks, 16 fetches in
+// flight per thread -- the kernel is bound by its ~17 VALU instructions per token, not by memory.)
 constexpr int kRawTB = 256;
-constexpr int kRawStride = kRawTB + 4;  // 65 dwords: odd stride -> the 4 byte-writes of a lane spread over banks
+constexpr int kRawStride = kRawTB + 4;  // 65 dwords: odd stride
 
+template <bool MASK>
 __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     __shared__ __align__(16) uint8_t s_lut[256];
     __shared__ __align__(16) int64_t s_off[kRawTB + 1];
@@ -435,46 +482,35 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
         s_off[i] = p.offsets[b <= p.B ? b : p.B];
     }
     __syncthreads();
-    const uintptr_t chars = reinterpret_cast<uintptr_t>(p.chars), mask = reinterpret_cast<uintptr_t>(p.mask);
-    const uint32_t fill_w = static_cast<uint32_t>(p.fill_id) * 0x01010101u;
-    const uint32_t at_len = p.eos ? static_cast<uint32_t>(p.eos_id) : static_cast<uint32_t>(p.fill_id);
+    const TokenRule rule = make_rule(p);
     const int g = tid & 15;
     const int32_t tpos = t0 + 4 * g;
-    const int32_t j0 = tpos - p.bos;
-    for (int sb = tid >> 4; sb < kRawTB; sb += kThreads / 16) {
-        uint32_t w = kNone * 0x01010101u;
-        if (b0 + sb < p.B) {
-            const int64_t start = s_off[sb];
-            const int32_t L = clamp_len(p, s_off[sb + 1] - start);
-            uint32_t cw = 0, mw = 0xFFFFFFFFu;
-            if (j0 + 4 > 0 && j0 < L) {
-                const int32_t jlo = j0 < 0 ? 0 : j0, jhi = (j0 + 4 < L) ? j0 + 4 : L;
-                const uintptr_t base = chars + static_cast<uintptr_t>(start);
-                cw = load4_unaligned(base + j0, base + jlo, base + jhi);
-                if (mask) {
-                    const uintptr_t mb = mask + static_cast<uintptr_t>(start);
-                    mw = load4_unaligned(mb + j0, mb + jlo, mb + jhi);
-                }
-            }
-            w = static_cast<uint32_t>(s_lut[cw & 0xFFu]) | (static_cast<uint32_t>(s_lut[(cw >> 8) & 0xFFu]) << 8) |
-                (static_cast<uint32_t>(s_lut[(cw >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(s_lut[cw >> 24]) << 24);
-            // mask byte == 0 -> kNone (exact zero-byte detection)
-            uint32_t z = (mw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-            z = ~(z | mw | 0x7F7F7F7Fu);          // 0x80 in every byte of mw that is zero
-            w |= (z >> 7) * 0xFFu;
-            const int32_t nv = L - j0;            // characters left from the word's first byte
-            if (nv < 4) {
-                const uint32_t m = nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u);
-                w = (w & m) | (fill_w & ~m);
-                if (nv >= 0) w = (w & ~(0xFFu << (8 * nv))) | (at_len << (8 * nv));
-            }
-            if (j0 < 0) w = (w & ~0xFFu) | static_cast<uint32_t>(p.bos_id);
+    const bool have_chars = p.offsets[p.B] > 0;
+    constexpr int NI = kRawTB / 16, BATCH = 8;
+    // Sequence of (thread group tg = tid/16, step k): 4*(tg&3) + (tg>>2) + 16k.
+    const int sb0 = 4 * ((tid >> 4) & 3) + (tid >> 6);
+    for (int i0 = 0; i0 < NI; i0 += BATCH) {
+        Raw4 raw[BATCH];
+        int32_t len[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int sb = sb0 + 16 * (i0 + k);
+            const bool ok = have_chars && b0 + sb < p.B;
+            const int64_t start = ok ? s_off[sb] : 0;
+            len[k] = (b0 + sb < p.B) ? clamp_len(p, s_off[sb + 1] - s_off[sb]) : 0;
+            raw[k] = have_chars ? fetch4<MASK>(rule, start, ok ? len[k] : 0, tpos) : Raw4{0, 0, ~0u, ~0u, 0};
         }
-        uint8_t *col = s_t + (4 * g) * kRawStride + sb;
-        col[0] = static_cast<uint8_t>(w);
-        col[kRawStride] = static_cast<uint8_t>(w >> 8);
-        col[2 * kRawStride] = static_cast<uint8_t>(w >> 16);
-        col[3 * kRawStride] = static_cast<uint8_t>(w >> 24);
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int sb = sb0 + 16 * (i0 + k);
+            uint32_t w = kNone * 0x01010101u;
+            if (b0 + sb < p.B) w = finish4<MASK>(rule, s_lut, raw[k], len[k], tpos);
+            uint8_t *col = s_t + (4 * g) * kRawStride + sb;
+            col[0] = static_cast<uint8_t>(w);
+            col[kRawStride] = static_cast<uint8_t>(w >> 8);
+            col[2 * kRawStride] = static_cast<uint8_t>(w >> 16);
+            col[3 * kRawStride] = static_cast<uint8_t>(w >> 24);
+        }
     }
     __syncthreads();
     uint8_t *out = static_cast<uint8_t *>(p.out);
@@ -1007,6 +1043,8 @@ struct CParams {
     uint64_t one_bits;
 };
 
+// Occupancy does not matter here (measured: 2..8 workgroups per CU, 54..90 VGPRs: 0.78-0.80 ms on cfg3;
+// forcing 8 waves/SIMD is 2 % slower): the kernel sits on the HBM write roof.
 template <typename ST, bool NT>
 __global__ __launch_bounds__(kThreads) void k_onehot_chunks(const CParams p) {
     __shared__ __align__(16) uint8_t s_img[4][kChunk];
@@ -1159,12 +1197,18 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
 }
 
 // Two-pass one-hot: raw (P,B) tokens into `workspace` (P*B bytes), then the chunk expansion.
+size_t two_pass_workspace_bytes(int64_t B, int64_t P) { return size_t(B) * size_t(P); }
+
 bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s) {
     void *out = k.out;
     k.out = workspace;
     k.aligned = (reinterpret_cast<uintptr_t>(workspace) % 16 == 0) && (k.B % 16 == 0);
     k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
-    hipLaunchKernelGGL(k_tokens_raw, dim3(unsigned(int64_t(k.ntb) * k.ntt)), dim3(kThreads), 0, s, k);
+    const dim3 grid(unsigned(int64_t(k.ntb) * k.ntt));
+    if (k.mask)
+        hipLaunchKernelGGL(k_tokens_raw<true>, grid, dim3(kThreads), 0, s, k);
+    else
+        hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
     bsq_status st = check_launch("k_tokens_raw");
     if (st != BSQ_OK) return st;
     EParams e;
@@ -1288,7 +1332,7 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     if (path == 3) return onehot_chunk_owner(k, sz, s);
     if (path == 2) {
         void *ws = nullptr;
-        bsq_status wst = bsq_internal::workspace_acquire(size_t(P) * size_t(B), s, &ws);
+        bsq_status wst = bsq_internal::workspace_acquire(two_pass_workspace_bytes(B, P), s, &ws);
         if (wst != BSQ_OK) return wst;
         wst = onehot_two_pass(k, sz, ws, s);
         bsq_internal::workspace_release(ws, s);

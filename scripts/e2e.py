@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""End-to-end (PCIe-inclusive) timing of the Python list-of-bytes API on cfg3 / cfg2 -- never the bench `value`."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bioseq_amd as bsq
+from bioseq_amd import synth
+c = synth.CONFIGS["cfg3"]
+chars, offs = synth.synth_packed(c["seed"], c["n"], c["lo"], c["hi"], c["letters"])
+seqs = synth.unpack(chars, offs)
+strs = synth.unpack(chars, offs, as_str=True)
+tok = bsq.Tokenizer("AMINO20")
+P = 1024
+def t(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0); del r
+    return np.median(ts) * 1e3
+print("host cpus", os.cpu_count())
+for nt in (1, 8, 32):
+    print("onehot list[bytes] -> device tensor, nthreads=%d : %.2f ms" % (nt, t(lambda: tok.batch_onehot_encode(seqs, padlen=P, destchar="f", nthreads=nt, device="cuda"))))
+print("onehot list[str]   -> device tensor, nthreads=8 : %.2f ms" % t(lambda: tok.batch_onehot_encode(strs, padlen=P, destchar="f", nthreads=8, device="cuda")))
+print("tokens list[bytes] -> device tensor (B,P)       : %.2f ms" % t(lambda: tok.batch_tokenize(seqs, padlen=P, batch_first=True, nthreads=8, device="cuda")))
+print("tokens list[bytes] -> numpy (B,P) incl. D2H     : %.2f ms" % t(lambda: tok.batch_tokenize(seqs, padlen=P, batch_first=True, nthreads=8)))
+print("onehot packed numpy -> device tensor            : %.2f ms" % t(lambda: tok.onehot_packed(chars, offs, P, "f", device="cuda")))
+dch, dof = torch.from_numpy(chars).cuda(), torch.from_numpy(offs).cuda()
+print("onehot packed device -> device tensor (alloc+kernel): %.2f ms" % t(lambda: tok.onehot_packed(dch, dof, P, "f")))
+print("onehot packed device, validate=False            : %.2f ms" % t(lambda: tok.onehot_packed(dch, dof, P, "f", validate=False)))
+t0 = time.perf_counter(); o = tok.batch_onehot_encode(seqs[:8192], padlen=P, destchar="f"); print("onehot 8192 seqs -> numpy (0.67 GB D2H): %.1f ms" % ((time.perf_counter() - t0) * 1e3))
