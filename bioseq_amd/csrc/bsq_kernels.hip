@@ -466,7 +466,9 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
 constexpr int kRawTB = 256;
 constexpr int kRawStride = kRawTB + 4;  // 65 dwords: odd stride
 
-template <bool MASK>
+// RAW = false: the same kernel produces the final int8 (P,B) token matrix of batch_tokenize(batch_first=False)
+// (unmapped / unpadded positions are 0 instead of kNone).
+template <bool MASK, bool RAW = true>
 __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     __shared__ __align__(16) uint8_t s_lut[256];
     __shared__ __align__(16) int64_t s_off[kRawTB + 1];
@@ -482,7 +484,18 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
         s_off[i] = p.offsets[b <= p.B ? b : p.B];
     }
     __syncthreads();
-    const TokenRule rule = make_rule(p);
+    TokenRule rule = make_rule(p);
+    if (!RAW) {  // value space: "no token" is the memset 0 of tokenize.h:427
+        if (tid < 64) {  // s_lut was staged with kNone markers: rewrite them (one dword per lane)
+            uint32_t w = reinterpret_cast<uint32_t *>(s_lut)[tid];
+            uint32_t z = (~w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;   // bytes equal to 0xFF <=> ~byte == 0
+            z = ~(z | ~w | 0x7F7F7F7Fu);
+            reinterpret_cast<uint32_t *>(s_lut)[tid] = w & ~((z >> 7) * 0xFFu);
+        }
+        __syncthreads();
+        if (rule.fill_id == kNone) rule.fill_id = 0;
+        if (rule.at_len_id == kNone) rule.at_len_id = 0;
+    }
     const int g = tid & 15;
     const int32_t tpos = t0 + 4 * g;
     const bool have_chars = p.offsets[p.B] > 0;
@@ -1386,6 +1399,11 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         return check_launch("k_tokenize_rows");
     }
     k.aligned = (addr % 16 == 0) && ((B * int64_t(sz)) % 16 == 0);
+    if (t == BSQ_I8 && bsq_internal::tuning("tokenize_path") != 1) {  // int8 (P,B): the raw-token kernel in value mode
+        k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
+        hipLaunchKernelGGL((k_tokens_raw<false, false>), dim3(unsigned(int64_t(k.ntb) * k.ntt)), dim3(kThreads), 0, s, k);
+        return check_launch("k_tokens_raw<value>");
+    }
     switch (t) {
     case BSQ_I8: return launch_tokenize_tile<int8_t, 256>(k, s);
     case BSQ_I16: return launch_tokenize_tile<int16_t, 128>(k, s);
