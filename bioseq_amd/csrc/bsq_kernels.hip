@@ -56,6 +56,7 @@ struct KParams {
     int32_t ntt;      // number of position tiles
     int32_t order;    // 0: sequence-tile index fastest over blockIdx, 1: position-tile index fastest
     int32_t variant;  // A/B knob: 1 = interleave a wave's rows (w, w+4, ...) instead of 16 contiguous rows
+    int64_t out_pitch;  // k_tokens_raw only: bytes between two position rows of its output
     uint64_t one_bits;
 };
 
@@ -386,7 +387,9 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
 constexpr int kChunk = 4096;
 
 struct EParams {
-    const uint8_t *tok;  // nrows = P*B raw tokens in (P,B) order (kNone = no one)
+    const uint8_t *tok;  // raw tokens (kNone = no one), row t at tok + t*Bp (Bp = B rounded up to 256: every
+                         // row of the scratch is 256-byte aligned whatever B is)
+    int64_t B, Bp;
     uint8_t *out;        // output base (any alignment that is a multiple of sizeof(ST))
     int64_t total;       // output bytes
     int64_t nrows;       // P * B
@@ -423,7 +426,10 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     const int64_t r_lo = lo / rowbytes;                               // first row intersecting the piece
     const int32_t skip = static_cast<int32_t>(lo - r_lo * rowbytes);  // bytes of row r_lo before the piece
     const int32_t nr = (skip + len + rowbytes - 1) / rowbytes;        // rows intersecting it
-    const uint8_t *tok = p.tok + r_lo;
+    const int64_t t_lo = r_lo / p.B;  // flat row r = t*B + b
+    const int64_t b_lo = r_lo - t_lo * p.B;
+    const uint8_t *tok = p.tok + t_lo * p.Bp + b_lo;
+    const int64_t wrap_at = p.B - b_lo;  // rows i >= wrap_at belong to position t_lo + 1 (or later)
     // scatter: row r_lo + i has its one at image byte i*rowbytes - skip + tok*sizeof(ST).
     // 4 coalesced token loads in flight per step.
     for (int32_t i0 = 0; i0 < nr; i0 += 256) {
@@ -431,7 +437,12 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int32_t i = i0 + 64 * q + lane;
-            tk[q] = i < nr ? static_cast<uint32_t>(tok[i]) : kNone;
+            int64_t a = i;
+            if (i >= wrap_at) {  // the piece runs over the end of position t_lo's rows
+                const int64_t w = (i - wrap_at) / p.B + 1;
+                a = i + w * (p.Bp - p.B);
+            }
+            tk[q] = i < nr ? static_cast<uint32_t>(tok[a]) : kNone;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -532,8 +543,8 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
         const int64_t t = static_cast<int64_t>(t0) + tl;
         if (t >= p.P) continue;
         const uint8_t *src = s_t + tl * kRawStride + q * 16;
-        uint8_t *dst = out + t * p.B + b0 + q * 16;
-        if (p.aligned && b0 + q * 16 + 16 <= p.B) {
+        uint8_t *dst = out + t * p.out_pitch + b0 + q * 16;
+        if (p.aligned && b0 + q * 16 + 16 <= p.out_pitch) {
             uint4 v;  // LDS rows are only 4-byte aligned (stride 260): four dword reads
             v.x = *reinterpret_cast<const uint32_t *>(src);
             v.y = *reinterpret_cast<const uint32_t *>(src + 4);
@@ -972,6 +983,7 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     k.order = bsq_internal::tuning("tile_order");
     k.variant = bsq_internal::tuning("variant");
     k.aligned = 0;
+    k.out_pitch = B;
     k.one_bits = 1;
     return BSQ_OK;
 }
@@ -1210,12 +1222,14 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
 }
 
 // Two-pass one-hot: raw (P,B) tokens into `workspace` (P*B bytes), then the chunk expansion.
-size_t two_pass_workspace_bytes(int64_t B, int64_t P) { return size_t(B) * size_t(P); }
+int64_t two_pass_pitch(int64_t B) { return (B + kRawTB - 1) / kRawTB * kRawTB; }
+size_t two_pass_workspace_bytes(int64_t B, int64_t P) { return size_t(two_pass_pitch(B)) * size_t(P); }
 
 bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s) {
     void *out = k.out;
     k.out = workspace;
-    k.aligned = (reinterpret_cast<uintptr_t>(workspace) % 16 == 0) && (k.B % 16 == 0);
+    k.out_pitch = two_pass_pitch(k.B);  // padded: every scratch row is aligned, full-width vector stores
+    k.aligned = reinterpret_cast<uintptr_t>(workspace) % 16 == 0;
     k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
     const dim3 grid(unsigned(int64_t(k.ntb) * k.ntt));
     if (k.mask)
@@ -1226,6 +1240,8 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
     if (st != BSQ_OK) return st;
     EParams e;
     e.tok = static_cast<const uint8_t *>(workspace);
+    e.B = k.B;
+    e.Bp = k.out_pitch;
     e.out = static_cast<uint8_t *>(out);
     e.nrows = k.P * k.B;
     e.total = e.nrows * k.C * int64_t(sz);
