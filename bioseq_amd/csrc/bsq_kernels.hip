@@ -84,6 +84,7 @@ __device__ __forceinline__ uint32_t load_u32_aligned(uintptr_t addr) {
 //   pos bos+L -> EOS (if eos); later positions -> PAD id (if padchar) or none.
 struct TokenRule {
     uintptr_t chars, mask;  // mask == 0: none
+    bool nonempty;          // the batch holds at least one character (else chars may be a null pointer)
     int32_t bos;
     uint32_t bos_id, at_len_id, fill_id;  // ids at position 0 (BOS), bos+L (EOS or fill) and beyond
 };
@@ -91,6 +92,7 @@ __device__ __forceinline__ TokenRule make_rule(const KParams &k) {
     TokenRule r;
     r.chars = reinterpret_cast<uintptr_t>(k.chars);
     r.mask = reinterpret_cast<uintptr_t>(k.mask);
+    r.nonempty = k.offsets[k.B] > 0;
     r.bos = k.bos;
     r.bos_id = static_cast<uint32_t>(k.bos_id);
     r.fill_id = static_cast<uint32_t>(k.fill_id);
@@ -108,6 +110,7 @@ struct Raw4 {
 
 template <bool MASK = true>
 __device__ __forceinline__ Raw4 fetch4(const TokenRule p, int64_t start, int32_t L, int32_t tpos) {
+    if (!p.nonempty) return Raw4{0, 0, ~0u, ~0u, 0};  // wave-uniform: nothing to read, `safe` would be invalid
     const int32_t j0 = tpos - p.bos;
     const uintptr_t base = p.chars + static_cast<uintptr_t>(start);
     const uintptr_t x = base + j0;
