@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU: product (all kernel paths, all entry points) vs the CPU oracle.
+   python tests/fuzz_gpu.py [seconds] [seed]      -- prints a one-line summary; exit 1 on the first mismatch."""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bioseq_amd as bsq
+from bioseq_amd import capi, synth
+from oracle import oracle as O
+
+def run(budget=120.0, seed=1):
+    rng = np.random.default_rng(seed)
+    lib = capi.load()
+    KEYS = O.keys()
+    ALPH = [synth.DIRTY, synth.AA, "ACGT", "ACGTNacgtn", synth.DIRTY + "".join(chr(c) for c in range(33, 64))]
+    dev = torch.device("cuda:0")
+    n = 0
+    t_end = time.time() + budget
+    while time.time() < t_end:
+        key = KEYS[rng.integers(len(KEYS))]
+        eos, bos, pad = (int(x) for x in rng.integers(0, 2, 3))
+        B = int(rng.choice([1, 2, 7, 63, 64, 65, 200, 255, 256, 257, 1000, 4096, 5000, 20000]))
+        P = int(rng.choice([1, 3, 15, 16, 17, 63, 64, 65, 100, 128, 255, 300, 512])) + eos + bos
+        hi = P - eos - bos
+        lo = int(rng.integers(0, hi + 1))
+        if B * P > 6_000_000:
+            B = max(1, 6_000_000 // P)
+        d = "bhiqfd"[rng.integers(6)]
+        if key == "BYTES" and d == "b":
+            d = "h"
+        chars, offs = synth.synth_packed(int(rng.integers(1 << 30)), B, lo, hi, ALPH[rng.integers(len(ALPH))])
+        use_mask = rng.random() < 0.3
+        mask = (rng.random(chars.size) < 0.7).astype(np.uint8) if use_mask else None
+        path = int(rng.integers(0, 4))
+        capi.check(lib.bsq_tuning_set(b"onehot_path", path))
+        capi.check(lib.bsq_tuning_set(b"tokenize_path", int(rng.integers(0, 2))))
+        tok, ora = bsq.Tokenizer(key, eos, bos, pad), O.OracleTokenizer(key, eos, bos, pad)
+        shift = int(rng.integers(0, 4))  # misaligned device views of the inputs
+        dch = torch.from_numpy(np.concatenate([np.zeros(shift, np.uint8), chars])).to(dev)[shift:]
+        dof = torch.from_numpy(offs).to(dev)
+        dm = None if mask is None else torch.from_numpy(np.concatenate([np.zeros(5 - shift, np.uint8), mask])).to(dev)[5 - shift:]
+        desc = (key, eos, bos, pad, B, P, lo, hi, d, path, use_mask, shift)
+        with open("/tmp/fuzz_last.txt", "w") as f:  # survives a GPU fault that kills the process
+            f.write(repr(desc) + " total_chars=%d\n" % chars.size)
+        try:
+            bf = bool(rng.integers(0, 2))
+            e = ora.tokenize_packed(chars, offs, P, d, bf)
+            g = tok.tokenize_packed(dch, dof, P, d, bf).cpu().numpy()
+            assert g.dtype == e.dtype and g.tobytes() == e.tobytes(), ("tokenize", bf)
+            e = ora.onehot_packed(chars, offs, P, d, mask=mask)
+            g = tok.onehot_packed(dch, dof, P, d, mask=dm).cpu().numpy()
+            assert g.dtype == e.dtype and g.shape == e.shape and g.tobytes() == e.tobytes(), "onehot"
+            g = tok.onehot_packed(dch, dof, P, d, mask=dm, layout="bcl").cpu().numpy()
+            assert g.tobytes() == np.ascontiguousarray(e.transpose(1, 2, 0)).tobytes(), "onehot bcl"
+            if B * P < 400_000:  # host entry points (list of bytes -> numpy)
+                seqs = synth.unpack(chars, offs)
+                ml = None if mask is None else [mask[offs[i]:offs[i + 1]].copy() for i in range(B)]
+                g = tok.batch_onehot_encode(seqs, padlen=P, destchar=d, mask=ml)
+                assert g.tobytes() == e.tobytes(), "host onehot"
+        except AssertionError as ex:
+            raise AssertionError("MISMATCH %s %r" % (ex, desc))
+        n += 1
+    capi.check(lib.bsq_tuning_set(b"onehot_path", 0)); capi.check(lib.bsq_tuning_set(b"tokenize_path", 0))
+    return n
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    try:
+        n = run(budget, seed)
+    except AssertionError as ex:
+        print(ex, flush=True)
+        sys.exit(1)
+    print("fuzz ok: %d random configurations, %.0f s, all bit-exact vs the oracle" % (n, budget))
