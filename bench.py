@@ -75,7 +75,13 @@ def cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, cap_threads=Non
         dt = time.perf_counter() - t0
     nbytes = out.nbytes
     del out
-    return {"value": total / dt / 1e9, "unit": "Gseq-chars/s", "cores": nthreads, "kind": kind,
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"cpu_model": model, "value": total / dt / 1e9, "unit": "Gseq-chars/s", "cores": nthreads, "kind": kind,
             "gb_per_s_written": nbytes / dt / 1e9, "seconds": dt, "host_cpus": cores,
             "sample": "the full batch of this workload (%d sequences, %d chars, %.2f GB output), one call incl. "
                       "result allocation as the reference does per call, nthreads=%d"

@@ -199,6 +199,7 @@ __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, i
     const bool have_chars = p.offsets[p.B] > 0;  // uniform; an all-empty batch has no word to read
     constexpr int NI = TB / 16;                  // sequences per thread
     constexpr int BATCH = NI < 4 ? NI : 4;       // fetches kept in flight (more costs occupancy: 129 VGPRs at 8)
+#pragma unroll 1
     for (int i0 = 0; i0 < NI; i0 += BATCH) {
         Raw4 raw[BATCH];
         int32_t len[BATCH];
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     constexpr int NI = kRawTB / 16, BATCH = 8;
     // Sequence of (thread group tg = tid/16, step k): 4*(tg&3) + (tg>>2) + 16k.
     const int sb0 = 4 * ((tid >> 4) & 3) + (tid >> 6);
+#pragma unroll 1
     for (int i0 = 0; i0 < NI; i0 += BATCH) {
         Raw4 raw[BATCH];
         int32_t len[BATCH];
