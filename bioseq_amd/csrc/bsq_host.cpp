@@ -196,7 +196,6 @@ Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
                   {"onehot_tb", "BSQ_ONEHOT_TB", 0, false},
                   {"tile_order", "BSQ_TILE_ORDER", 0, false},
                   {"fill_mode", "BSQ_FILL_MODE", 0, false},
-                  {"variant", "BSQ_VARIANT", 0, false},
                   {"onehot_path", "BSQ_ONEHOT_PATH", 0, false},
                   {"expand_cpw", "BSQ_EXPAND_CPW", 0, false},
                   {"tokenize_path", "BSQ_TOKENIZE_PATH", 0, false}};

@@ -3,24 +3,29 @@
 // The path is byte-LUT + streaming stores: HBM-bound, no MFMA.  Traffic per call is
 //     sum(L) chars + 8(B+1) offsets  read once,   P*B*C'*sizeof(T) output  written once
 // and the one-hot output is ~150x the input, so everything is organised around the WRITE side:
-// every output element is produced exactly once by a 16-byte coalesced store, there is no
-// memset pass and no scattered store to global memory (the reference's structure,
-// /root/reference/src/tokenize.h:332 + :342-369, is memset + one 4-byte scattered store per
-// residue at stride B*C*sizeof(T)).
+// every output element is produced exactly once by a 16-byte store, there is no memset pass and no
+// scattered store to global memory (the reference's structure, /root/reference/src/tokenize.h:332 +
+// :342-369, is memset + one 4-byte scattered store per residue at stride B*C*sizeof(T)).
+//
+// What the write side needs on this part (measured): naturally aligned 4-KiB
+// chunks, each XCD writing its own residue class (chunk id % 8 == blockIdx % 8 under round-robin
+// dispatch), one chunk per wave, non-temporal stores.  Speed only -- results never depend on it.
 //
 // Kernel inventory
-//   k_onehot_tile      (P,B,C) one-hot.  A workgroup owns a tile of TB sequences x 64 positions:
-//                      phase 1 resolves the tile's tokens into LDS (coalesced uint32 reads of the
-//                      packed characters, alphabet LUT in LDS, BOS/EOS/PAD/mask folded in);
-//                      phase 2: each wave owns 16 of the 64 rows and a private LDS image of one
-//                      output row segment (TB*C elements).  Per row it scatters TB "ones" into the
-//                      image (one ds_write per sequence), streams the image out with ds_read_b128 ->
-//                      global_store_dwordx4, and clears the TB ones again.  No per-element VALU.
-//   k_tokenize_rows    (B,P) tokens: one wave per sequence row, 4 characters per lane per step.
-//   k_tokenize_tile    (P,B) tokens: same phase 1 as k_onehot_tile, transposed write through LDS.
-//   k_*_generic        one thread per output element; any shape / alignment / alphabet (BYTES has
-//                      ids > 255).  Fallback and in-library cross-check of the tiled kernels.
-//   k_fill             write-bandwidth yardstick.
+//   k_onehot_chunks    (P,B,C) one-hot, chunk-owner form: a wave gathers the characters of the ~4096/rowbytes
+//                      rows of its chunk (consecutive sequences at one position), LUT from a wave-private
+//                      LDS table, scatters the ones into a 4-KiB LDS image, streams it out.  cfg3: 88 % of HBM peak.
+//   k_tokens_raw +     two-pass (P,B,C) one-hot for any pitch: raw uint8 tokens through tiled, coalesced
+//   k_expand_chunks    character reads into a scratch matrix, then the chunk-wise flat expansion of it.
+//   k_onehot_tile      (P,B,C) one-hot, tiled: workgroup = TB sequences x 64 positions, per-wave LDS row
+//                      images; small rows / small outputs.
+//   k_tokenize_chunks  (B,P) tokens and the channels-first (B,C,P) one-hot: flat chunk stream, a lane owns 16
+//                      output bytes of one sequence row, unaligned vector loads of its characters.
+//   k_tokenize_rows    (B,P) tokens for odd padlen / unaligned bases.
+//   k_tokens_raw<value>, k_tokenize_tile   (P,B) tokens (int8 / wider types): tiled transpose through LDS.
+//   k_*_generic        one thread per output element; any shape / alignment / alphabet (BYTES has ids > 255).
+//                      Fallback and in-library cross-check of the fast kernels.
+//   k_fill*, k_fill_pattern   write-bandwidth yardsticks and the store-pattern diagnostics.
 //   k_first_too_long   device-side length validation.
 #include <hip/hip_runtime.h>
 
@@ -55,7 +60,6 @@ struct KParams {
     int32_t aligned;  // 1: every output row segment is 16-byte aligned -> vector stores
     int32_t ntt;      // number of position tiles
     int32_t order;    // 0: sequence-tile index fastest over blockIdx, 1: position-tile index fastest
-    int32_t variant;  // A/B knob: 1 = interleave a wave's rows (w, w+4, ...) instead of 16 contiguous rows
     int64_t out_pitch;  // k_tokens_raw only: bytes between two position rows of its output
     uint64_t one_bits;
 };
@@ -283,12 +287,9 @@ __global__ __launch_bounds__(kThreads) void k_onehot_tile(const KParams p) {
     constexpr int kRowsPerWave = kTT / 4;
     constexpr int kSeqPerLane = TB / 64;
     for (int r = 0; r < kRowsPerWave; ++r) {
-        const int32_t tl = p.variant == 1 ? r * 4 + wave : wave * kRowsPerWave + r;
+        const int32_t tl = wave * kRowsPerWave + r;
         const int64_t t = static_cast<int64_t>(t0) + tl;
-        if (t >= p.P) {  // wave-uniform
-            if (p.variant == 1) break;
-            break;
-        }
+        if (t >= p.P) break;  // wave-uniform
         // 1. scatter the ones of this row into the wave's LDS image
         int32_t hot[kSeqPerLane];
 #pragma unroll
@@ -336,7 +337,7 @@ __device__ __forceinline__ T token_value(uint32_t tk) {
     return tk == kNone ? T(0) : static_cast<T>(tk);  // unmapped / unpadded positions keep the memset 0
 }
 
-template <typename T, int TB, bool RAW = false>  // RAW: keep kNone (0xFF) markers -- feeds k_expand_chunks
+template <typename T, int TB>
 __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     int64_t *s_off = reinterpret_cast<int64_t *>(smem);
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
 #pragma unroll
         for (int i = 0; i < EPC; ++i) {
             const uint32_t tk = s_tok[(sb0 + i) * kTokStride + tl];
-            vals[i] = RAW ? static_cast<T>(tk) : token_value<T>(tk);
+            vals[i] = token_value<T>(tk);
         }
         T *dst = out + t * p.B + b0 + sb0;
         if (p.aligned && b0 + sb0 + EPC <= p.B) {
@@ -396,11 +397,9 @@ struct EParams {
     int64_t B, Bp;
     uint8_t *out;        // output base (any alignment that is a multiple of sizeof(ST))
     int64_t total;       // output bytes
-    int64_t nrows;       // P * B
     int64_t nchunks;     // chunks intersecting [out, out + total)
     int32_t head;        // out & 4095
     int32_t C;
-    int32_t cpw;         // chunks per wave
     uint64_t one_bits;
 };
 
@@ -986,7 +985,6 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     k.ntb = 1;
     k.ntt = int32_t((P + kTT - 1) / kTT);
     k.order = bsq_internal::tuning("tile_order");
-    k.variant = bsq_internal::tuning("variant");
     k.aligned = 0;
     k.out_pitch = B;
     k.one_bits = 1;
@@ -1248,13 +1246,11 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
     e.B = k.B;
     e.Bp = k.out_pitch;
     e.out = static_cast<uint8_t *>(out);
-    e.nrows = k.P * k.B;
-    e.total = e.nrows * k.C * int64_t(sz);
+    e.total = k.P * k.B * k.C * int64_t(sz);
     e.head = int32_t(reinterpret_cast<uintptr_t>(out) & (kChunk - 1));
     e.nchunks = (e.head + e.total + kChunk - 1) / kChunk;
     e.C = k.C;
     e.one_bits = k.one_bits;
-    e.cpw = 1;
     switch (sz) {
     case 1: return launch_expand<uint8_t>(e, s);
     case 2: return launch_expand<uint16_t>(e, s);

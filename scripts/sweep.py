@@ -34,7 +34,7 @@ def run():
         capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), n, P, int(op == "tokenize"), dt, out.data_ptr(), None))
 
 def setk(**kw):
-    for k in ("nt_stores", "onehot_tb", "tile_order", "variant", "onehot_path", "expand_cpw"):
+    for k in ("nt_stores", "onehot_tb", "tile_order", "onehot_path", "expand_cpw"):
         capi.check(lib.bsq_tuning_set(k.encode(), int(kw.get(k, 0))))
 
 variants = [dict()]
