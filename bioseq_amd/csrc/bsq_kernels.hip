@@ -157,13 +157,16 @@ __device__ __forceinline__ uint32_t finish4(const TokenRule p, const uint8_t *s_
         z = ~(z | mw | 0x7F7F7F7Fu);                     // 0x80 in every byte of mw that is zero
         w |= (z >> 7) * 0xFFu;                           // masked position -> kNone
     }
-    const int32_t nv = L - j0;  // characters of the sequence left from the word's first byte
-    if (nv < 4) {
-        const uint32_t m = nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u);
-        w = (w & m) | ((p.fill_id * 0x01010101u) & ~m);                             // beyond bos+L: PAD / none
-        if (nv >= 0) w = (w & ~(0xFFu << (8 * nv))) | (p.at_len_id << (8 * nv));  // position bos+L: EOS
-    }
-    if (j0 < 0) w = (w & ~0xFFu) | p.bos_id;  // position 0 with BOS
+    // Branch-free position rules (bytes are positions tpos..tpos+3, nv = characters left from the first one):
+    //   byte >= nv      -> fill (PAD id / none)      byte == nv -> EOS (or fill)      j0 < 0: byte 0 -> BOS
+    const int32_t nv = L - j0;
+    const int32_t nvc = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+    const uint32_t keep = static_cast<uint32_t>((uint64_t(1) << (8 * nvc)) - 1u);  // low nvc bytes
+    w = (w & keep) | ((p.fill_id * 0x01010101u) & ~keep);
+    const uint32_t at = (nv >= 0 && nv < 4) ? (0xFFu << (8 * nvc)) : 0u;
+    w = (w & ~at) | ((p.at_len_id * 0x01010101u) & at);
+    const uint32_t first = j0 < 0 ? 0xFFu : 0u;
+    w = (w & ~first) | (p.bos_id & first);
     return w;
 }
 
@@ -200,7 +203,6 @@ __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, i
     }
     __syncthreads();
     const int g = tid & 15;  // 16 lanes x 4 characters cover the 64 positions of one sequence
-    const bool have_chars = p.offsets[p.B] > 0;  // uniform; an all-empty batch has no word to read
     constexpr int NI = TB / 16;                  // sequences per thread
     constexpr int BATCH = NI < 4 ? NI : 4;       // fetches kept in flight (more costs occupancy: 129 VGPRs at 8)
 #pragma unroll 1
@@ -210,17 +212,15 @@ __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, i
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int sb = (tid >> 4) + 16 * (i0 + k);
-            const bool ok = have_chars && b0 + sb < p.B;
-            const int64_t start = ok ? s_off[sb] : 0;
-            len[k] = (b0 + sb < p.B) ? clamp_len(p, s_off[sb + 1] - s_off[sb]) : 0;
-            raw[k] = have_chars ? fetch4(rule, start, ok ? len[k] : 0, t0 + 4 * g) : Raw4{0, 0, ~0u, ~0u, 0};
+            const int64_t start = s_off[sb];  // entries past the batch repeat offsets[B]: length 0, nothing read
+            len[k] = clamp_len(p, s_off[sb + 1] - start);
+            raw[k] = fetch4(rule, start, len[k], t0 + 4 * g);
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int sb = (tid >> 4) + 16 * (i0 + k);
-            uint32_t packed = kNone * 0x01010101u;
-            if (b0 + sb < p.B) packed = finish4(rule, s_lut, raw[k], len[k], t0 + 4 * g);
-            *reinterpret_cast<uint32_t *>(s_tok + sb * kTokStride + 4 * g) = packed;
+            const uint32_t w = finish4(rule, s_lut, raw[k], len[k], t0 + 4 * g);
+            *reinterpret_cast<uint32_t *>(s_tok + sb * kTokStride + 4 * g) = (b0 + sb < p.B) ? w : kNone * 0x01010101u;
         }
     }
     __syncthreads();
@@ -512,7 +512,6 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     }
     const int g = tid & 15;
     const int32_t tpos = t0 + 4 * g;
-    const bool have_chars = p.offsets[p.B] > 0;
     constexpr int NI = kRawTB / 16, BATCH = 8;
     // Sequence of (thread group tg = tid/16, step k): 4*(tg&3) + (tg>>2) + 16k.
     const int sb0 = 4 * ((tid >> 4) & 3) + (tid >> 6);
@@ -523,16 +522,14 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int sb = sb0 + 16 * (i0 + k);
-            const bool ok = have_chars && b0 + sb < p.B;
-            const int64_t start = ok ? s_off[sb] : 0;
-            len[k] = (b0 + sb < p.B) ? clamp_len(p, s_off[sb + 1] - s_off[sb]) : 0;
-            raw[k] = have_chars ? fetch4<MASK>(rule, start, ok ? len[k] : 0, tpos) : Raw4{0, 0, ~0u, ~0u, 0};
+            const int64_t start = s_off[sb];  // entries past the batch repeat offsets[B]: length 0, nothing read
+            len[k] = clamp_len(p, s_off[sb + 1] - start);
+            raw[k] = fetch4<MASK>(rule, start, len[k], tpos);
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int sb = sb0 + 16 * (i0 + k);
-            uint32_t w = kNone * 0x01010101u;
-            if (b0 + sb < p.B) w = finish4<MASK>(rule, s_lut, raw[k], len[k], tpos);
+            const uint32_t w = finish4<MASK>(rule, s_lut, raw[k], len[k], tpos);  // columns >= B are never read
             uint8_t *col = s_t + (4 * g) * kRawStride + sb;
             col[0] = static_cast<uint8_t>(w);
             col[kRawStride] = static_cast<uint8_t>(w >> 8);
