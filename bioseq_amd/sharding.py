@@ -65,17 +65,35 @@ def _all_gather_padded(local, batch_axis: int, B: int, group=None):
     return [b.narrow(batch_axis, 0, sizes[r]) for r, b in enumerate(bufs)]
 
 
-def gather_tokens(local, B: int, batch_first: bool, group=None):
-    """Whole-batch token matrix on every rank from per-rank shards ((B_g,P) or (P,B_g))."""
+def _gather(local, batch_axis: int, B: int, group=None):
     import torch
-    axis = 0 if batch_first else 1
-    return torch.cat(_all_gather_padded(local, axis, B, group), dim=axis)
+    dist = _dist()
+    world = dist.get_world_size(group)
+    if B % world == 0 and local.is_contiguous():
+        # equal shards: one all_gather straight into the result (batch-first slabs) or into a (G, ...) staging
+        # tensor that is permuted into place (seq-first column blocks)
+        try:
+            if batch_axis == 0:
+                full = local.new_empty((B,) + tuple(local.shape[1:]))
+                dist.all_gather_into_tensor(full, local, group=group)
+                return full
+            stage = local.new_empty((world,) + tuple(local.shape))
+            dist.all_gather_into_tensor(stage, local, group=group)
+            return torch.cat(list(stage.unbind(0)), dim=batch_axis)
+        except (RuntimeError, NotImplementedError):  # backend without the flat all-gather: generic path below
+            pass
+    return torch.cat(_all_gather_padded(local, batch_axis, B, group), dim=batch_axis)
+
+
+def gather_tokens(local, B: int, batch_first: bool, group=None):
+    """Whole-batch token matrix on every rank from per-rank shards ((B_g,P) or (P,B_g));
+    also used for channels-first one-hot (B_g, C, P) with batch_first=True."""
+    return _gather(local, 0 if batch_first else 1, B, group)
 
 
 def gather_onehot(local, B: int, group=None):
     """Whole-batch (P, B, C) one-hot on every rank from per-rank (P, B_g, C) shards."""
-    import torch
-    return torch.cat(_all_gather_padded(local, 1, B, group), dim=1)
+    return _gather(local, 1, B, group)
 
 
 def encode_sharded(encode: Callable, chars, offsets, gather: Optional[str] = None, group=None):
