@@ -44,6 +44,15 @@ WORKLOADS = {
 }
 
 
+def baseline_metric():
+    """The headline metric string of BASELINE.json (the default workload measures exactly that config)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "Gseq-chars/s + GB/s one-hot written, 64k\u00d71024 AMINO20, 1/2/4/8 GPU"
+
+
 def cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, cap_threads=None):
     """Time the reference CPU path once on the full batch (bounded: one call)."""
     from bioseq_amd import synth
@@ -273,7 +282,7 @@ def main():
         if op == "onehot_bcl":
             kernel_name = "k_tokenize_chunks<onehot bcl>"
         res = {
-            "metric": "Gseq-chars/s + GB/s one-hot written, 64k x 1024 AMINO20" if args.workload == "cfg3"
+            "metric": baseline_metric() if args.workload == "cfg3"
                       else "Gseq-chars/s + GB/s written (%s)" % args.workload,
             "value": job_chars * args.steps / wall_max / 1e9,
             "unit": "Gseq-chars/s",
