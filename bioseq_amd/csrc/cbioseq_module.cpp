@@ -321,10 +321,11 @@ class Tokenizer {
         Gathered g;
         gather(batch, py::none(), g);
         PackLock lock;
+        OutBuf out;  // first: it makes `device=` the current device, so the pinned scratch and the staging
+                     // buffers used by pack() and by the encode call belong to the same device
+        const py::ssize_t nb = py::ssize_t(g.items.size());
+        make_out(out, batch_first ? std::vector<py::ssize_t>{nb, padlen} : std::vector<py::ssize_t>{padlen, nb}, t, device);
         const Packed p = pack(g, nthreads);
-        OutBuf out;
-        make_out(out, batch_first ? std::vector<py::ssize_t>{p.B, padlen} : std::vector<py::ssize_t>{padlen, p.B}, t,
-                 device);
         int64_t bad = -1;
         bsq_status st;
         {
@@ -353,10 +354,10 @@ class Tokenizer {
         Gathered g;
         gather(batch, mask, g);
         PackLock lock;
+        OutBuf out;  // before pack(): see batch_tokenize
+        const py::ssize_t C = py::ssize_t(bsq_alphabet_size(&desc)), nb = py::ssize_t(g.items.size());
+        make_out(out, bcl ? std::vector<py::ssize_t>{nb, C, padlen} : std::vector<py::ssize_t>{padlen, nb, C}, t, device);
         const Packed p = pack(g, nthreads);
-        OutBuf out;
-        const py::ssize_t C = py::ssize_t(bsq_alphabet_size(&desc));
-        make_out(out, bcl ? std::vector<py::ssize_t>{p.B, C, padlen} : std::vector<py::ssize_t>{padlen, p.B, C}, t, device);
         int64_t bad = -1;
         bsq_status st;
         {
