@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 
 #include "bsq.h"
 #include "bsq_internal.h"
@@ -1563,9 +1564,19 @@ bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, in
     *first_bad = -1;
     if (B == 0) return BSQ_OK;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    unsigned long long *flag = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&flag), sizeof(*flag));
-    if (e != hipSuccess) return bsq_internal::set_hip_error("hipMalloc", e);
+    // one 8-byte flag per device, allocated once (a hipMalloc/hipFree pair per call costs ~25 us)
+    static unsigned long long *flags[16] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);  // the flag is shared: one validation at a time per process
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipGetDevice", e);
+    if (dev < 0 || dev >= 16) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "device ordinal out of range");
+    if (!flags[dev]) {
+        e = hipMalloc(reinterpret_cast<void **>(&flags[dev]), sizeof(unsigned long long));
+        if (e != hipSuccess) return bsq_internal::set_hip_error("hipMalloc", e);
+    }
+    unsigned long long *flag = flags[dev];
     e = hipMemsetAsync(flag, 0xFF, sizeof(*flag), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_first_too_long, dim3(generic_grid(B)), dim3(kThreads), 0, s, offsets_dev, B,
@@ -1575,7 +1586,6 @@ bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, in
     unsigned long long host = ~0ull;
     if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(host), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(flag);
     if (e != hipSuccess) return bsq_internal::set_hip_error("bsq_validate_lengths_device", e);
     if (host != ~0ull) {
         *first_bad = static_cast<int64_t>(host);
