@@ -26,7 +26,7 @@ try:
 except ImportError as _e:  # fail loudly: the HIP extension IS the product
     raise ImportError(
         "bioseq_amd: the native extension is missing or failed to load (%s). Build it in-tree with "
-        "`python -m bioseq_amd.build` (needs hipcc; gfx950 code objects cross-compile without a GPU)." % (_e,)
+        "`python bioseq_amd/build.py` (needs hipcc; gfx950 code objects cross-compile without a GPU)." % (_e,)
     ) from _e
 
 from .cbioseq import Threading, Tokenizer, get_num_threads, set_num_threads  # noqa: F401

@@ -3,7 +3,7 @@
     bioseq_amd/libbsq_hip.so                      C-ABI library: HIP kernels for gfx950 + host staging
     bioseq_amd/cbioseq.cpython-*.so               pybind11 host layer (links libbsq_hip.so, rpath $ORIGIN)
 
-`python -m bioseq_amd.build` or `bioseq_amd.build.build_all()`.  hipcc cross-compiles gfx950 code
+`python bioseq_amd/build.py` or `bioseq_amd.build.build_all()`.  hipcc cross-compiles gfx950 code
 objects without a GPU, so this runs in the build container; the .so files travel to the GPU box.
 """
 from __future__ import annotations

@@ -39,7 +39,7 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m bioseq_amd.build`")
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python bioseq_amd/build.py`")
     from . import _hipruntime
     _hipruntime.preload()
     L = ctypes.CDLL(LIB_PATH)
