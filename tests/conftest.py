@@ -15,7 +15,21 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _ensure_built():
+    """A fresh checkout has no .so files (they are git-ignored): build them once (hipcc cross-compiles)."""
+    import glob
+    import importlib.util
+    pkg = os.path.join(ROOT, "bioseq_amd")
+    if os.path.exists(os.path.join(pkg, "libbsq_hip.so")) and glob.glob(os.path.join(pkg, "cbioseq*.so")):
+        return
+    spec = importlib.util.spec_from_file_location("bsq_build", os.path.join(pkg, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build_all()
+
+
 def pytest_configure(config):
+    _ensure_built()
     config.addinivalue_line("markers", "gpu: needs a HIP device (run on the MI355X box with -m gpu)")
     config.addinivalue_line("markers", "slow: full BASELINE-size case")
 
