@@ -32,6 +32,7 @@ except ImportError as _e:  # fail loudly: the HIP extension IS the product
 from .cbioseq import Threading, Tokenizer, get_num_threads, set_num_threads  # noqa: F401
 from . import synth  # noqa: F401
 from . import blosum, sharding  # noqa: F401
+from .flatfile import FlatFile  # noqa: F401  (bioseq.FlatFile, /root/reference/src/fxstats.cpp:166-200)
 
 __version__ = "0.1.0"
 
@@ -148,9 +149,17 @@ def torchify(arr):
     return from_numpy(arr)
 
 
+def __getattr__(name):
+    """`bioseq_amd.loaders` (FlatFileDataset, FF2NP, ...) imports torch: load it on first use only."""
+    if name == "loaders":
+        import importlib
+        return importlib.import_module(".loaders", __name__)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
+
+
 __all__ = ["onehot_encode", "cbioseq", "f_encode", "Tokenizer", "make_embedding", "bos_tokenizers",
            "eos_tokenizers", "beos_tokenizers", "pbeos_tokenizers", "peos_tokenizers", "pbos_tokenizers",
            "pos_tokenizers", "default_tokenizers", "total_tokenizer_dict", "get_tokenizer_dict", "DNATokenizer",
            "AmineTokenizer", "Reduced6Tokenizer", "Reduced8Tokenizer", "Reduced10Tokenizer", "Reduced14Tokenizer",
            "DayhoffTokenizer", "LIATokenizer", "LIBTokenizer", "torchify", "set_num_threads", "get_num_threads",
-           "Threading", "device_count", "synth", "blosum", "sharding"]
+           "Threading", "device_count", "synth", "blosum", "sharding", "FlatFile", "loaders"]
