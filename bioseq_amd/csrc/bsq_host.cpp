@@ -198,7 +198,9 @@ Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
                   {"fill_mode", "BSQ_FILL_MODE", 0, false},
                   {"onehot_path", "BSQ_ONEHOT_PATH", 0, false},
                   {"expand_cpw", "BSQ_EXPAND_CPW", 0, false},
-                  {"tokenize_path", "BSQ_TOKENIZE_PATH", 0, false}};
+                  {"tokenize_path", "BSQ_TOKENIZE_PATH", 0, false},
+                  {"fill_pad", "BSQ_FILL_PAD", 0, false},
+                  {"chunks_pad", "BSQ_CHUNKS_PAD", 0, false}};
 std::mutex g_knob_mu;
 Knob *find_knob(const char *name) {
     for (Knob &k : g_knobs)

@@ -1067,10 +1067,11 @@ struct CParams {
     int32_t room;     // P - bos - eos (length clamp)
     int32_t cpw;
     uint64_t one_bits;
+    const uint8_t *tok;  // experiment: when set, tokens come from a (P, Bp) scratch instead of the gather
+    int64_t Bp;
 };
 
-// Occupancy does not matter here (measured: 2..8 workgroups per CU, 54..90 VGPRs: 0.78-0.80 ms on cfg3;
-// forcing 8 waves/SIMD is 2 % slower): the kernel sits on the HBM write roof.
+// Fewer resident workgroups stream faster (see launch_chunks): the launch caps the occupancy at 4 per CU.
 template <typename ST, bool NT>
 __global__ __launch_bounds__(kThreads) void k_onehot_chunks(const CParams p) {
     __shared__ __align__(16) uint8_t s_img[4][kChunk];
@@ -1117,10 +1118,13 @@ __global__ __launch_bounds__(kThreads) void k_onehot_chunks(const CParams p) {
                     t += q;
                     b -= q * p.B;
                 }
+                uint32_t tk;
+                if (p.tok) {
+                    tk = p.tok[t * p.Bp + b];
+                } else {
                 const int64_t start = p.offsets[b];
                 int64_t L = p.offsets[b + 1] - start;
                 L = L > p.room ? p.room : L;
-                uint32_t tk;
                 const int64_t jj = t - p.bos;
                 if (jj < 0) {
                     tk = p.bos_id;
@@ -1129,6 +1133,7 @@ __global__ __launch_bounds__(kThreads) void k_onehot_chunks(const CParams p) {
                     if (p.mask && p.mask[start + jj] == 0) tk = kNone;
                 } else {
                     tk = (jj == L) ? p.at_len_id : p.fill_id;
+                }
                 }
                 const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
                 if (tk != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
@@ -1164,15 +1169,22 @@ bsq_status launch_chunks(const CParams &c, hipStream_t s) {
     const int64_t per_class = (c.nchunks + 7) / 8;
     const int64_t groups = (per_class + int64_t(4) * c.cpw - 1) / (int64_t(4) * c.cpw);
     const dim3 grid(unsigned(groups * 8));
+    // Occupancy cap through unused dynamic LDS: 4 workgroups per CU (17 KiB + 22 KiB each) stream at 7.2 TB/s
+    // on cfg3; 5 (the VGPR limit) at 6.9, 3 at 6.6, 2 at 4.8 (profiles/r01/chunks_occupancy.txt).  The same
+    // holds for a plain fill: 6.8 TB/s at 8 workgroups per CU, 7.4 at 3.  Knob "chunks_pad" overrides (bytes).
+    const int padv = bsq_internal::tuning("chunks_pad");
+    const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : size_t(22528));
     if (bsq_internal::nontemporal_stores())
-        hipLaunchKernelGGL((k_onehot_chunks<ST, true>), grid, dim3(kThreads), 0, s, c);
+        hipLaunchKernelGGL((k_onehot_chunks<ST, true>), grid, dim3(kThreads), pad, s, c);
     else
-        hipLaunchKernelGGL((k_onehot_chunks<ST, false>), grid, dim3(kThreads), 0, s, c);
+        hipLaunchKernelGGL((k_onehot_chunks<ST, false>), grid, dim3(kThreads), pad, s, c);
     return check_launch("k_onehot_chunks");
 }
 
-bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
+bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s, const uint8_t *tok = nullptr, int64_t Bp = 0) {
     CParams c;
+    c.tok = tok;
+    c.Bp = Bp;
     for (int i = 0; i < 256; ++i) c.lut[i] = k.lut[i];
     c.chars = k.chars;
     c.offsets = k.offsets;
@@ -1212,12 +1224,19 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
     const bool nt = bsq_internal::nontemporal_stores();
+    // Occupancy cap: with 8 workgroups per CU this kernel streams at 6.3 TB/s, with 4 at 6.7, with 3 at 7.2
+    // (2 is too few: 5.2) -- measured on cfg3, profiles/r01/expand_occupancy.txt -- when rows are >= 64 bytes;
+    // with smaller rows (more token loads and scatters per chunk) it needs the full occupancy instead
+    // (profiles/r01/sweep_shapes4.txt).  Unused dynamic LDS is the cheapest way to hold it at 3 (3 x (16 KiB image + 36 KiB) = 156 KiB <= 160 KiB; 37 KiB already rounds up to 2 per CU).  "expand_cpw" >= 1000 overrides.
+    const int padv = bsq_internal::tuning("expand_cpw");
+    const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;  // <= 65 rows per chunk: one token load per lane
+    const size_t pad = padv >= 1000 ? size_t(padv) : (big_rows ? size_t(36864) : size_t(0));
     if (quarter) {
-        if (nt) hipLaunchKernelGGL((k_expand_chunks<ST, true, 4>), grid, dim3(kThreads), 0, s, e);
-        else hipLaunchKernelGGL((k_expand_chunks<ST, false, 4>), grid, dim3(kThreads), 0, s, e);
+        if (nt) hipLaunchKernelGGL((k_expand_chunks<ST, true, 4>), grid, dim3(kThreads), pad, s, e);
+        else hipLaunchKernelGGL((k_expand_chunks<ST, false, 4>), grid, dim3(kThreads), pad, s, e);
     } else {
-        if (nt) hipLaunchKernelGGL((k_expand_chunks<ST, true, 1>), grid, dim3(kThreads), 0, s, e);
-        else hipLaunchKernelGGL((k_expand_chunks<ST, false, 1>), grid, dim3(kThreads), 0, s, e);
+        if (nt) hipLaunchKernelGGL((k_expand_chunks<ST, true, 1>), grid, dim3(kThreads), pad, s, e);
+        else hipLaunchKernelGGL((k_expand_chunks<ST, false, 1>), grid, dim3(kThreads), pad, s, e);
     }
     return check_launch("k_expand_chunks");
 }
@@ -1239,6 +1258,11 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
         hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
     bsq_status st = check_launch("k_tokens_raw");
     if (st != BSQ_OK) return st;
+    if (bsq_internal::tuning("onehot_path") == 4) {  // experiment: the chunk-owner kernel as pass 2
+        KParams k2 = k;
+        k2.out = out;
+        return onehot_chunk_owner(k2, sz, s, static_cast<const uint8_t *>(workspace), k.out_pitch);
+    }
     EParams e;
     e.tok = static_cast<const uint8_t *>(workspace);
     e.B = k.B;
@@ -1358,7 +1382,7 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     // row is >= 48 bytes and its per-position gather set stays L2-resident -- i.e. the row pitch is a
     // multiple of 32 KiB (each XCD then keeps to its own chunk columns) and B is moderate, or B is small.
     if (path == 3) return onehot_chunk_owner(k, sz, s);
-    if (path == 2) {
+    if (path == 2 || path == 4) {
         void *ws = nullptr;
         bsq_status wst = bsq_internal::workspace_acquire(two_pass_workspace_bytes(B, P), s, &ws);
         if (wst != BSQ_OK) return wst;
@@ -1524,7 +1548,8 @@ bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip
     const int mode = bsq_internal::tuning("fill_mode");
     if (blocks >= (size_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "fill too large");
     switch (mode) {
-    case 1: hipLaunchKernelGGL((k_fill_blocks<1, false>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, d4, n16, pattern); break;
+    case 1: hipLaunchKernelGGL((k_fill_blocks<1, false>), dim3(unsigned(blocks)), dim3(kThreads),
+                               size_t(bsq_internal::tuning("fill_pad")), s, d4, n16, pattern); break;
     case 2: hipLaunchKernelGGL((k_fill_blocks<4, false>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;
     case 3: hipLaunchKernelGGL((k_fill_blocks<1, true>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, d4, n16, pattern); break;
     case 4: hipLaunchKernelGGL((k_fill_blocks<4, true>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;

@@ -44,7 +44,7 @@ for si, (key, flags, B, lo, hi, P, dc) in enumerate(SHAPES):
     algo = int(offs[-1]) + 8 * (B + 1) + ob
     def run(): capi.check(lib.bsq_onehot_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), None, B, P, dt, out.data_ptr(), None))
     res = []
-    for path in (1, 2, 3):
+    for path in (1, 2, 3, 4):
         for nt in (1,):
             setk(onehot_path=path, nt_stores=nt)
             out.fill_(5); run(); torch.cuda.synchronize()
