@@ -46,7 +46,7 @@ def build_lib(force=False):
     deps = [os.path.join(CSRC, f) for f in LIB_DEPS] + [os.path.join(INCLUDE, "bsq.h")]
     if force or _newer(LIB, deps):
         _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
-              "-I" + INCLUDE, "-I" + CSRC, "-o", LIB] + os.environ.get("BSQ_EXTRA_HIPCC_FLAGS", "").split() +
+              "-pthread", "-I" + INCLUDE, "-I" + CSRC, "-o", LIB] + os.environ.get("BSQ_EXTRA_HIPCC_FLAGS", "").split() +
              [os.path.join(CSRC, f) for f in LIB_SRCS])
     return LIB
 

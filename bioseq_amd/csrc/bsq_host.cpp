@@ -10,10 +10,14 @@
 // point returns BSQ_ERR_NO_DEVICE.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "bsq.h"
 #include "bsq_internal.h"
@@ -34,7 +38,12 @@ struct Staging {
     size_t d_out_cap = 0;
     hipEvent_t busy = nullptr;
     bool busy_pending = false;
+    // device -> pageable host results: ring of pinned bounce slots (see download())
+    void *bounce = nullptr;
+    hipEvent_t slot_done[4] = {nullptr, nullptr, nullptr, nullptr};
 };
+constexpr int kSlots = 4;
+constexpr size_t kSlotBytes = size_t(8) << 20;
 constexpr int kMaxDevices = 16;
 Staging g_staging[kMaxDevices];
 std::mutex g_mu;
@@ -120,6 +129,81 @@ bsq_status upload(Staging &s, const uint8_t *chars, const int64_t *offsets, cons
     return BSQ_OK;
 }
 
+// Result -> caller's (pageable) host buffer.  A plain hipMemcpy into pageable memory runs at ~16 GB/s on
+// the MI355X box (the runtime bounces through its own staging, and the first touch of a fresh numpy
+// buffer page-faults inside that single thread).  Here the copy is pipelined instead: the stream DMAs
+// 8-MiB pieces into a ring of 4 pinned slots while `nthreads` workers memcpy finished slots into the
+// destination (every worker takes its 1/n of each piece, so the page faults of the destination are spread
+// over the workers too).  Small results take the plain path.  Knob "host_copy_threads" (default 8, 1 = plain).
+bsq_status download(Staging &s, void *out, const void *dev_out, size_t nbytes, hipStream_t stream) {
+    int nthreads = bsq_internal::tuning("host_copy_threads");
+    if (nthreads <= 0) nthreads = 8;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && unsigned(nthreads) > hw) nthreads = int(hw);
+    hipError_t e = hipSuccess;
+    if (nbytes < 4 * kSlotBytes || nthreads < 2) {
+        e = hipMemcpyAsync(out, dev_out, nbytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("D2H copy of the result", e);
+        return BSQ_OK;
+    }
+    if (!s.bounce) {
+        e = hipHostMalloc(&s.bounce, kSlots * kSlotBytes, hipHostMallocDefault);
+        for (int i = 0; i < kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s.slot_done[i], hipEventDisableTiming);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("pinned bounce buffer", e);
+    }
+    const int64_t npieces = int64_t((nbytes + kSlotBytes - 1) / kSlotBytes);
+    std::unique_ptr<std::atomic<int>[]> copied(new std::atomic<int>[size_t(npieces)]);
+    for (int64_t c = 0; c < npieces; ++c) copied[size_t(c)].store(0, std::memory_order_relaxed);
+    std::atomic<int64_t> issued{0};
+    std::atomic<int> failed{0};
+    const int device = s.device;
+    char *dst = static_cast<char *>(out);
+    char *ring = static_cast<char *>(s.bounce);
+    auto worker = [&](int j) {
+        (void)hipSetDevice(device);
+        for (int64_t c = 0; c < npieces; ++c) {
+            while (issued.load(std::memory_order_acquire) <= c) {
+                if (failed.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            if (hipEventSynchronize(s.slot_done[c % kSlots]) != hipSuccess) {
+                failed.store(1);
+                return;
+            }
+            const size_t base = size_t(c) * kSlotBytes;
+            const size_t len = nbytes - base < kSlotBytes ? nbytes - base : kSlotBytes;
+            const size_t per = (len / size_t(nthreads) + 4095) & ~size_t(4095);  // page-granular shares
+            const size_t lo = per * size_t(j) < len ? per * size_t(j) : len;
+            const size_t hi = lo + per < len ? lo + per : len;
+            if (hi > lo) std::memcpy(dst + base + lo, ring + size_t(c % kSlots) * kSlotBytes + lo, hi - lo);
+            copied[size_t(c)].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(size_t(nthreads));
+    for (int j = 0; j < nthreads; ++j) pool.emplace_back(worker, j);
+    for (int64_t c = 0; c < npieces && !failed.load(); ++c) {
+        if (c >= kSlots)  // the slot is free once every worker has drained piece c - kSlots
+            while (copied[size_t(c - kSlots)].load(std::memory_order_acquire) < nthreads && !failed.load())
+                std::this_thread::yield();
+        const size_t base = size_t(c) * kSlotBytes;
+        const size_t len = nbytes - base < kSlotBytes ? nbytes - base : kSlotBytes;
+        e = hipMemcpyAsync(ring + size_t(c % kSlots) * kSlotBytes, static_cast<const char *>(dev_out) + base, len,
+                           hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipEventRecord(s.slot_done[c % kSlots], stream);
+        if (e != hipSuccess) {
+            failed.store(1);
+            break;
+        }
+        issued.store(c + 1, std::memory_order_release);
+    }
+    for (std::thread &t : pool) t.join();
+    if (e != hipSuccess) return bsq_internal::set_hip_error("D2H copy of the result", e);
+    if (failed.load()) return bsq_internal::set_error(BSQ_ERR_HIP, "pipelined D2H copy failed");
+    return BSQ_OK;
+}
+
 template <typename Launch>
 bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask,
                     int64_t B, int64_t P, int32_t bos, int32_t eos, size_t out_bytes, void *out,
@@ -159,9 +243,8 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
     if (st != BSQ_OK) return st;
     hipError_t e = hipSuccess;
     if (out_space == BSQ_SPACE_HOST) {
-        e = hipMemcpyAsync(out, dev_out, out_bytes, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) return bsq_internal::set_hip_error("D2H copy of the result", e);
+        st = download(s, out, dev_out, out_bytes, stream);
+        if (st != BSQ_OK) return st;
     } else {
         e = hipEventRecord(s.busy, stream);
         if (e != hipSuccess) return bsq_internal::set_hip_error("hipEventRecord", e);
@@ -200,7 +283,8 @@ Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
                   {"expand_cpw", "BSQ_EXPAND_CPW", 0, false},
                   {"tokenize_path", "BSQ_TOKENIZE_PATH", 0, false},
                   {"fill_pad", "BSQ_FILL_PAD", 0, false},
-                  {"chunks_pad", "BSQ_CHUNKS_PAD", 0, false}};
+                  {"chunks_pad", "BSQ_CHUNKS_PAD", 0, false},
+                  {"host_copy_threads", "BSQ_HOST_COPY_THREADS", 0, false}};
 std::mutex g_knob_mu;
 Knob *find_knob(const char *name) {
     for (Knob &k : g_knobs)
@@ -307,6 +391,9 @@ void bsq_release_staging(void) {
         if (s.pinned) (void)hipHostFree(s.pinned);
         if (s.d_in) (void)hipFree(s.d_in);
         if (s.d_out) (void)hipFree(s.d_out);
+        if (s.bounce) (void)hipHostFree(s.bounce);
+        for (hipEvent_t ev : s.slot_done)
+            if (ev) (void)hipEventDestroy(ev);
         if (s.busy) (void)hipEventDestroy(s.busy);
         (void)hipSetDevice(prev);
         s = Staging();

@@ -1067,8 +1067,6 @@ struct CParams {
     int32_t room;     // P - bos - eos (length clamp)
     int32_t cpw;
     uint64_t one_bits;
-    const uint8_t *tok;  // experiment: when set, tokens come from a (P, Bp) scratch instead of the gather
-    int64_t Bp;
 };
 
 // Fewer resident workgroups stream faster (see launch_chunks): the launch caps the occupancy at 4 per CU.
@@ -1119,9 +1117,6 @@ __global__ __launch_bounds__(kThreads) void k_onehot_chunks(const CParams p) {
                     b -= q * p.B;
                 }
                 uint32_t tk;
-                if (p.tok) {
-                    tk = p.tok[t * p.Bp + b];
-                } else {
                 const int64_t start = p.offsets[b];
                 int64_t L = p.offsets[b + 1] - start;
                 L = L > p.room ? p.room : L;
@@ -1133,7 +1128,6 @@ __global__ __launch_bounds__(kThreads) void k_onehot_chunks(const CParams p) {
                     if (p.mask && p.mask[start + jj] == 0) tk = kNone;
                 } else {
                     tk = (jj == L) ? p.at_len_id : p.fill_id;
-                }
                 }
                 const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
                 if (tk != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
@@ -1181,10 +1175,8 @@ bsq_status launch_chunks(const CParams &c, hipStream_t s) {
     return check_launch("k_onehot_chunks");
 }
 
-bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s, const uint8_t *tok = nullptr, int64_t Bp = 0) {
+bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
     CParams c;
-    c.tok = tok;
-    c.Bp = Bp;
     for (int i = 0; i < 256; ++i) c.lut[i] = k.lut[i];
     c.chars = k.chars;
     c.offsets = k.offsets;
@@ -1258,11 +1250,6 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
         hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
     bsq_status st = check_launch("k_tokens_raw");
     if (st != BSQ_OK) return st;
-    if (bsq_internal::tuning("onehot_path") == 4) {  // experiment: the chunk-owner kernel as pass 2
-        KParams k2 = k;
-        k2.out = out;
-        return onehot_chunk_owner(k2, sz, s, static_cast<const uint8_t *>(workspace), k.out_pitch);
-    }
     EParams e;
     e.tok = static_cast<const uint8_t *>(workspace);
     e.B = k.B;
@@ -1382,7 +1369,7 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     // row is >= 48 bytes and its per-position gather set stays L2-resident -- i.e. the row pitch is a
     // multiple of 32 KiB (each XCD then keeps to its own chunk columns) and B is moderate, or B is small.
     if (path == 3) return onehot_chunk_owner(k, sz, s);
-    if (path == 2 || path == 4) {
+    if (path == 2) {
         void *ws = nullptr;
         bsq_status wst = bsq_internal::workspace_acquire(two_pass_workspace_bytes(B, P), s, &ws);
         if (wst != BSQ_OK) return wst;

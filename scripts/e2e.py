@@ -28,4 +28,13 @@ print("onehot packed numpy -> device tensor            : %.2f ms" % t(lambda: to
 dch, dof = torch.from_numpy(chars).cuda(), torch.from_numpy(offs).cuda()
 print("onehot packed device -> device tensor (alloc+kernel): %.2f ms" % t(lambda: tok.onehot_packed(dch, dof, P, "f")))
 print("onehot packed device, validate=False            : %.2f ms" % t(lambda: tok.onehot_packed(dch, dof, P, "f", validate=False)))
-t0 = time.perf_counter(); o = tok.batch_onehot_encode(seqs[:8192], padlen=P, destchar="f"); print("onehot 8192 seqs -> numpy (0.67 GB D2H): %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+from bioseq_amd import capi
+lib = capi.load()
+for nt in (1, 2, 4, 8, 16, 32):
+    capi.check(lib.bsq_tuning_set(b"host_copy_threads", nt))
+    for nseq in (8192, 65536):
+        ms = t(lambda: tok.batch_onehot_encode(seqs[:nseq], padlen=P, destchar="f"), n=3)
+        gb = P * nseq * 20 * 4 / 1e9
+        print("onehot %5d seqs -> numpy (%.2f GB D2H), host_copy_threads=%2d: %7.1f ms = %5.1f GB/s" % (nseq, gb, nt, ms, gb / ms * 1e3), flush=True)
+capi.check(lib.bsq_tuning_set(b"host_copy_threads", 0))
+print("tokens list[bytes] -> numpy (B,P) incl. D2H     : %.2f ms" % t(lambda: tok.batch_tokenize(seqs, padlen=P, batch_first=True, nthreads=8)))

@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""Compare the three one-hot paths (0 tile, 1 two-pass, 2 chunk-owner) over a set of shapes."""
+"""Occupancy sweep over shapes: two-pass (expansion kernel, pad via expand_cpw >= 1000) and chunk-owner
+(pad via chunks_pad) with the unused-LDS pads that give 8/7/6/5/4/3 resident workgroups per CU."""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bioseq_amd import capi, synth
+from sweep_shapes_list import SHAPES
 lib = capi.load()
 dev = torch.device("cuda:0")
-from sweep_shapes_list import SHAPES
+PADS = [(8, 1024), (6, 10240), (5, 15360), (4, 22528), (3, 36864)]
 sel = sys.argv[1:] and [int(x) for x in sys.argv[1:]]
 def setk(**kw):
-    for k in ("nt_stores", "onehot_path", "expand_cpw"):
+    for k in ("onehot_path", "expand_cpw", "chunks_pad"):
         capi.check(lib.bsq_tuning_set(k.encode(), int(kw.get(k, 0))))
 for si, (key, flags, B, lo, hi, P, dc) in enumerate(SHAPES):
     if sel and si not in sel: continue
@@ -22,23 +24,24 @@ for si, (key, flags, B, lo, hi, P, dc) in enumerate(SHAPES):
     sz = lib.bsq_dtype_size(dt)
     dch, dof = torch.from_numpy(chars).to(dev), torch.from_numpy(offs).to(dev)
     ob = P * B * C * sz
-    out = torch.empty(ob, dtype=torch.uint8, device=dev); ref = torch.empty_like(out)
+    out = torch.empty(ob, dtype=torch.uint8, device=dev)
     algo = int(offs[-1]) + 8 * (B + 1) + ob
     def run(): capi.check(lib.bsq_onehot_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), None, B, P, dt, out.data_ptr(), None))
     res = []
-    for path in (1, 2, 3):
-        for nt in (1,):
-            setk(onehot_path=path, nt_stores=nt)
-            out.fill_(5); run(); torch.cuda.synchronize()
-            if path == 1: ref.copy_(out)
-            else: assert torch.equal(out, ref), (key, path)
+    for path in (2, 3):
+        row = []
+        for wg, pad in PADS:
+            if path == 2: setk(onehot_path=2, expand_cpw=pad)
+            else: setk(onehot_path=3, chunks_pad=pad)
+            run(); torch.cuda.synchronize()
             ts = []
             for _ in range(5):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(3): run()
                 b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) / 3)
-            res.append("p%d %.3f ms %4.0f GB/s" % (path, np.median(ts), algo / np.median(ts) / 1e6))
-    print("%-8s %s B=%7d P=%4d %s C=%2d rowbytes=%3d out=%5.2f GB pitch%%32K=%5d | %s" % (key, flags, B, P, dc, C, C * sz, ob / 1e9, (B * C * sz) % 32768, " | ".join(res)), flush=True)
-    del out, ref, dch, dof
+            row.append("%d:%.3f" % (wg, np.median(ts)))
+        res.append("p%d " % path + " ".join(row))
+    print("%-8s %s B=%7d P=%4d %s rowbytes=%3d out=%5.2f GB | %s" % (key, flags, B, P, dc, C * sz, ob / 1e9, " | ".join(res)), flush=True)
+    del out, dch, dof
 setk()
