@@ -42,6 +42,7 @@ constexpr int kTT = 64;               // positions per tile
 constexpr int kTokStride = kTT + 4;   // bytes per sequence row of the LDS token tile (17 dwords:
                                       // odd dword stride -> column reads hit 32 distinct banks)
 constexpr uint32_t kNone = 0xFFu;     // "no token": all-zero one-hot row / token value 0
+constexpr int64_t kMaxTiledP = int64_t(1) << 22;  // tiled kernels: 256 sequences x padlen must fit 32-bit offsets
 
 struct KParams {
     int8_t lut[256];
@@ -75,29 +76,54 @@ __device__ __forceinline__ void tile_of_block(const KParams &p, int32_t &tb, int
     }
 }
 
-// Aligned dword load through the GLOBAL address space (a pointer rebuilt from an integer would
+// Aligned dword loads go through the GLOBAL address space (a pointer rebuilt from an integer would
 // otherwise be a flat pointer and cost a flat_load + lgkmcnt wait).
 typedef const __attribute__((address_space(1))) uint32_t *global_u32_ptr;
-__device__ __forceinline__ uint32_t load_u32_aligned(uintptr_t addr) {
-    return *reinterpret_cast<global_u32_ptr>(addr);
-}
 
 // Tokens of positions tpos..tpos+3 of one sequence, packed little-endian into a dword.
 // s_lut holds the alphabet table with unmapped == kNone.  Semantics follow
 // /root/reference/src/tokenize.h:342-369 (one-hot) and :454-479 (tokens):
 //   pos 0 -> BOS (if bos); pos bos+j -> lut[s[j]] (mask==0 or unmapped -> none);
 //   pos bos+L -> EOS (if eos); later positions -> PAD id (if padchar) or none.
+//
+// Addressing: a workgroup reads the characters of a WINDOW of consecutive sequences [b_first, b_first + n).
+// Inside the window every address is a 32-bit byte offset from a 4-byte aligned, wave-uniform base
+// (chars + offsets[b_first], rounded down), so a fetch costs a handful of 32-bit VALU operations and its
+// loads take the scalar base + 32-bit offset form.  The window spans at most n * padlen characters
+// (n <= 256, padlen <= 2^22 on these paths).
 struct TokenRule {
-    uintptr_t chars, mask;  // mask == 0: none
-    bool nonempty;          // the batch holds at least one character (else chars may be a null pointer)
+    global_u32_ptr chars_al, mask_al;  // aligned window bases (mask_al: null without a mask)
+    uint32_t mis, mis_m;               // (unaligned base) & 3
+    int32_t last, last_m;              // offset of the last dword that holds a byte of the BUFFER (clamp bound)
+    int64_t off0;                      // offsets[b_first]: sequence starts are stored relative to it
+    bool nonempty;                     // the window holds at least one character (else nothing may be read)
     int32_t bos;
     uint32_t bos_id, at_len_id, fill_id;  // ids at position 0 (BOS), bos+L (EOS or fill) and beyond
 };
-__device__ __forceinline__ TokenRule make_rule(const KParams &k) {
+__device__ __forceinline__ TokenRule make_rule(const KParams &k, int64_t b_first, int32_t n) {
     TokenRule r;
-    r.chars = reinterpret_cast<uintptr_t>(k.chars);
-    r.mask = reinterpret_cast<uintptr_t>(k.mask);
-    r.nonempty = k.offsets[k.B] > 0;
+    const int64_t bf = b_first < k.B ? b_first : k.B;
+    const int64_t bl = b_first + n < k.B ? b_first + n : k.B;
+    const int64_t total = k.offsets[k.B];
+    r.off0 = k.offsets[bf];
+    r.nonempty = k.offsets[bl] > r.off0;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(k.chars) + static_cast<uintptr_t>(r.off0);
+    const uintptr_t end_w = (reinterpret_cast<uintptr_t>(k.chars) + static_cast<uintptr_t>(total) - 1) & ~uintptr_t(3);
+    const int64_t span = static_cast<int64_t>(end_w) - static_cast<int64_t>(base & ~uintptr_t(3));  // >= 0 when nonempty
+    r.chars_al = reinterpret_cast<global_u32_ptr>(base & ~uintptr_t(3));
+    r.mis = static_cast<uint32_t>(base & 3);
+    r.last = static_cast<int32_t>(span < 0 ? 0 : (span > 0x7FFFFFF8 ? 0x7FFFFFF8 : span));
+    r.mask_al = nullptr;
+    r.mis_m = 0;
+    r.last_m = 0;
+    if (k.mask) {  // same offsets in the mask array, its own alignment
+        const uintptr_t mbase = reinterpret_cast<uintptr_t>(k.mask) + static_cast<uintptr_t>(r.off0);
+        const uintptr_t mend_w = (reinterpret_cast<uintptr_t>(k.mask) + static_cast<uintptr_t>(total) - 1) & ~uintptr_t(3);
+        const int64_t mspan = static_cast<int64_t>(mend_w) - static_cast<int64_t>(mbase & ~uintptr_t(3));
+        r.mask_al = reinterpret_cast<global_u32_ptr>(mbase & ~uintptr_t(3));
+        r.mis_m = static_cast<uint32_t>(mbase & 3);
+        r.last_m = static_cast<int32_t>(mspan < 0 ? 0 : (mspan > 0x7FFFFFF8 ? 0x7FFFFFF8 : mspan));
+    }
     r.bos = k.bos;
     r.bos_id = static_cast<uint32_t>(k.bos_id);
     r.fill_id = static_cast<uint32_t>(k.fill_id);
@@ -106,38 +132,41 @@ __device__ __forceinline__ TokenRule make_rule(const KParams &k) {
 }
 
 // The raw words behind 4 consecutive characters (and their mask bytes).  fetch4 issues its loads
-// UNCONDITIONALLY -- a word that holds no needed byte is replaced by a load of the word containing
-// chars[0] -- so that callers can keep many fetch4's in flight before the first finish4 consumes one.
-// Still never touches a word that lies wholly outside the buffer.
+// UNCONDITIONALLY so that callers can keep many fetch4's in flight before the first finish4 consumes one:
+// the two dword offsets are CLAMPED into the buffer instead of predicated.  A dword that holds a needed
+// character is never moved by the clamp (it lies inside the buffer); any other dword only supplies bytes
+// that the position rules of finish4 overwrite.  No word wholly outside the buffer is ever touched.
 struct Raw4 {
     uint32_t a, b, ma, mb, sh;
 };
 
+typedef const __attribute__((address_space(1))) uint8_t *global_u8_ptr;
+// Dword at byte offset min(off, last) from `base` (one v_min_u32 + a scalar-base load).  A "negative" offset
+// (the dword before the window: only ever behind the BOS position of the window's first sequence) wraps
+// to a huge unsigned value and is clamped to `last` like any offset past the end.
+__device__ __forceinline__ uint32_t load_clamped(global_u32_ptr base, uint32_t off, int32_t last) {
+    const uint32_t o = off < static_cast<uint32_t>(last) ? off : static_cast<uint32_t>(last);
+    return *reinterpret_cast<global_u32_ptr>(reinterpret_cast<global_u8_ptr>(base) + o);
+}
+
+// `start` = offsets[b] - rule.off0 (window-relative), tpos = first of the four positions.
 template <bool MASK = true>
-__device__ __forceinline__ Raw4 fetch4(const TokenRule p, int64_t start, int32_t L, int32_t tpos) {
-    if (!p.nonempty) return Raw4{0, 0, ~0u, ~0u, 0};  // wave-uniform: nothing to read, `safe` would be invalid
-    const int32_t j0 = tpos - p.bos;
-    const uintptr_t base = p.chars + static_cast<uintptr_t>(start);
-    const uintptr_t x = base + j0;
-    const uintptr_t w0 = x & ~uintptr_t(3);
-    const bool any = j0 + 4 > 0 && j0 < L;
-    const uintptr_t lo = base + (j0 < 0 ? 0 : j0), hi = base + ((j0 + 4 < L) ? j0 + 4 : L);
-    const bool need_a = any && lo < w0 + 4, need_b = any && hi > w0 + 4;
-    const uintptr_t safe = p.chars & ~uintptr_t(3);  // the aligned word holding chars[0]
+__device__ __forceinline__ Raw4 fetch4(const TokenRule p, uint32_t start, int32_t tpos) {
+    if (!p.nonempty) return Raw4{0, 0, ~0u, ~0u, 0};  // wave-uniform: nothing to read
+    const uint32_t j = start + static_cast<uint32_t>(tpos - p.bos);  // may be "-1" (BOS position of the first sequence)
+    const uint32_t rel = j + p.mis;
+    const uint32_t w0 = rel & ~3u;
     Raw4 r;
-    r.sh = static_cast<uint32_t>(x & 3);
-    r.a = load_u32_aligned(need_a ? w0 : safe);
-    r.b = load_u32_aligned(need_b ? w0 + 4 : safe);
+    r.sh = rel & 3u;
+    r.a = load_clamped(p.chars_al, w0, p.last);
+    r.b = load_clamped(p.chars_al, w0 + 4u, p.last);
     r.ma = r.mb = 0xFFFFFFFFu;
-    if (MASK && p.mask) {  // wave-uniform
-        const uintptr_t d = p.mask - p.chars;  // same offsets in the mask array
-        const uintptr_t msafe = p.mask & ~uintptr_t(3);
-        const uintptr_t mw0 = (x + d) & ~uintptr_t(3);
-        // the mask array may be aligned differently from chars: redo the need tests on its own words
-        const uintptr_t mlo = lo + d, mhi = hi + d;
-        r.ma = load_u32_aligned((any && mlo < mw0 + 4) ? mw0 : msafe);
-        r.mb = load_u32_aligned((any && mhi > mw0 + 4) ? mw0 + 4 : msafe);
-        r.sh |= static_cast<uint32_t>((x + d) & 3) << 8;
+    if (MASK && p.mask_al) {  // wave-uniform
+        const uint32_t relm = j + p.mis_m;
+        const uint32_t m0 = relm & ~3u;
+        r.ma = load_clamped(p.mask_al, m0, p.last_m);
+        r.mb = load_clamped(p.mask_al, m0 + 4u, p.last_m);
+        r.sh |= (relm & 3u) << 8;
     }
     return r;
 }
@@ -152,7 +181,7 @@ __device__ __forceinline__ uint32_t finish4(const TokenRule p, const uint8_t *s_
     const uint32_t cw = __builtin_amdgcn_alignbyte(r.b, r.a, r.sh & 3u);
     uint32_t w = static_cast<uint32_t>(s_lut[cw & 0xFFu]) | (static_cast<uint32_t>(s_lut[(cw >> 8) & 0xFFu]) << 8) |
                  (static_cast<uint32_t>(s_lut[(cw >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(s_lut[cw >> 24]) << 24);
-    if (MASK && p.mask) {
+    if (MASK && p.mask_al) {
         const uint32_t mw = __builtin_amdgcn_alignbyte(r.mb, r.ma, (r.sh >> 8) & 3u);
         uint32_t z = (mw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;  // exact zero-byte detection:
         z = ~(z | mw | 0x7F7F7F7Fu);                     // 0x80 in every byte of mw that is zero
@@ -171,9 +200,9 @@ __device__ __forceinline__ uint32_t finish4(const TokenRule p, const uint8_t *s_
     return w;
 }
 
-__device__ __forceinline__ uint32_t resolve4(const TokenRule p, const uint8_t *s_lut, int64_t start, int32_t L,
+__device__ __forceinline__ uint32_t resolve4(const TokenRule p, const uint8_t *s_lut, uint32_t start, int32_t L,
                                              int32_t tpos) {
-    return finish4(p, s_lut, fetch4(p, start, L, tpos), L, tpos);
+    return finish4(p, s_lut, fetch4(p, start, tpos), L, tpos);
 }
 
 __device__ __forceinline__ void stage_lut(const KParams &p, uint8_t *s_lut) {
@@ -190,18 +219,29 @@ __device__ __forceinline__ int32_t clamp_len(const KParams &p, int64_t len) {
     return static_cast<int32_t>(len < 0 ? 0 : (len > room ? (room < 0 ? 0 : room) : len));
 }
 
+// (window-relative start, clamped length) of the n sequences of a window -> LDS, one 8-byte entry each.
+// Sequences past the end of the batch get length 0.
+struct SeqSpan {
+    uint32_t start;
+    int32_t len;
+};
+__device__ __forceinline__ void stage_spans(const KParams &p, const TokenRule &rule, int64_t b0, int n, SeqSpan *s_span) {
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+        const int64_t b = b0 + i;
+        const int64_t lo = p.offsets[b <= p.B ? b : p.B], hi = p.offsets[b + 1 <= p.B ? b + 1 : p.B];
+        s_span[i] = SeqSpan{static_cast<uint32_t>(lo - rule.off0), clamp_len(p, hi - lo)};
+    }
+}
+
 // Phase 1 shared by the tiled kernels: s_tok[sb * kTokStride + tl] = token of sequence b0+sb at
 // position t0+tl, for sb < TB, tl < 64.  Sequences past the end of the batch get kNone.
 template <int TB>
 __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, int32_t t0, uint8_t *s_lut,
-                                                 int64_t *s_off, uint8_t *s_tok) {
+                                                 SeqSpan *s_span, uint8_t *s_tok) {
     const int tid = threadIdx.x;
-    const TokenRule rule = make_rule(p);
+    const TokenRule rule = make_rule(p, b0, TB);
     stage_lut(p, s_lut);
-    for (int i = tid; i <= TB; i += kThreads) {
-        const int64_t b = b0 + i;
-        s_off[i] = p.offsets[b <= p.B ? b : p.B];
-    }
+    stage_spans(p, rule, b0, TB, s_span);
     __syncthreads();
     const int g = tid & 15;  // 16 lanes x 4 characters cover the 64 positions of one sequence
     constexpr int NI = TB / 16;                  // sequences per thread
@@ -213,9 +253,9 @@ __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, i
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int sb = (tid >> 4) + 16 * (i0 + k);
-            const int64_t start = s_off[sb];  // entries past the batch repeat offsets[B]: length 0, nothing read
-            len[k] = clamp_len(p, s_off[sb + 1] - start);
-            raw[k] = fetch4(rule, start, len[k], t0 + 4 * g);
+            const SeqSpan sp = s_span[sb];
+            len[k] = sp.len;
+            raw[k] = fetch4(rule, sp.start, t0 + 4 * g);
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
@@ -258,7 +298,7 @@ __host__ __device__ constexpr int tile_fixed_bytes() {
 template <typename ST, int TB, bool NT>
 __global__ __launch_bounds__(kThreads) void k_onehot_tile(const KParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
-    int64_t *s_off = reinterpret_cast<int64_t *>(smem);
+    SeqSpan *s_span = reinterpret_cast<SeqSpan *>(smem);
     uint8_t *s_lut = smem + tile_off_bytes<TB>();
     uint8_t *s_tok = s_lut + 256;
     uint8_t *s_rows = s_tok + TB * kTokStride;
@@ -276,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_onehot_tile(const KParams p) {
     // zero this wave's row image while the tile's characters are in flight
     for (int32_t o = lane * 16; o < row_pad; o += 64 * 16) *reinterpret_cast<uint4 *>(row + o) = uint4{0, 0, 0, 0};
 
-    build_token_tile<TB>(p, b0, t0, s_lut, s_off, s_tok);
+    build_token_tile<TB>(p, b0, t0, s_lut, s_span, s_tok);
 
     const int64_t nb64 = p.B - b0;
     const int32_t nb = nb64 < TB ? static_cast<int32_t>(nb64) : TB;
@@ -341,7 +381,7 @@ __device__ __forceinline__ T token_value(uint32_t tk) {
 template <typename T, int TB>
 __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
-    int64_t *s_off = reinterpret_cast<int64_t *>(smem);
+    SeqSpan *s_span = reinterpret_cast<SeqSpan *>(smem);
     uint8_t *s_lut = smem + tile_off_bytes<TB>();
     uint8_t *s_tok = s_lut + 256;
 
@@ -350,7 +390,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
     tile_of_block(p, tb, tt);
     const int64_t b0 = static_cast<int64_t>(tb) * TB;
     const int32_t t0 = tt * kTT;
-    build_token_tile<TB>(p, b0, t0, s_lut, s_off, s_tok);
+    build_token_tile<TB>(p, b0, t0, s_lut, s_span, s_tok);
 
     constexpr int EPC = 16 / static_cast<int>(sizeof(T));  // elements per 16-byte chunk
     constexpr int CPR = TB / EPC;                          // chunks per row segment
@@ -486,7 +526,7 @@ constexpr int kRawStride = kRawTB + 4;  // 65 dwords: odd stride
 template <bool MASK, bool RAW = true>
 __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     __shared__ __align__(16) uint8_t s_lut[256];
-    __shared__ __align__(16) int64_t s_off[kRawTB + 1];
+    __shared__ __align__(16) SeqSpan s_span[kRawTB];
     __shared__ __align__(16) uint8_t s_t[kTT * kRawStride];
     const int tid = threadIdx.x;
     int32_t tb, tt;
@@ -494,12 +534,9 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     const int64_t b0 = static_cast<int64_t>(tb) * kRawTB;
     const int32_t t0 = tt * kTT;
     stage_lut(p, s_lut);
-    for (int i = tid; i <= kRawTB; i += kThreads) {
-        const int64_t b = b0 + i;
-        s_off[i] = p.offsets[b <= p.B ? b : p.B];
-    }
+    TokenRule rule = make_rule(p, b0, kRawTB);
+    stage_spans(p, rule, b0, kRawTB, s_span);
     __syncthreads();
-    TokenRule rule = make_rule(p);
     if (!RAW) {  // value space: "no token" is the memset 0 of tokenize.h:427
         if (tid < 64) {  // s_lut was staged with kNone markers: rewrite them (one dword per lane)
             uint32_t w = reinterpret_cast<uint32_t *>(s_lut)[tid];
@@ -523,9 +560,9 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int sb = sb0 + 16 * (i0 + k);
-            const int64_t start = s_off[sb];  // entries past the batch repeat offsets[B]: length 0, nothing read
-            len[k] = clamp_len(p, s_off[sb + 1] - start);
-            raw[k] = fetch4<MASK>(rule, start, len[k], tpos);
+            const SeqSpan sp = s_span[sb];
+            len[k] = sp.len;
+            raw[k] = fetch4<MASK>(rule, sp.start, tpos);
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
@@ -566,14 +603,14 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_tokenize_rows(const KParams p) {
     __shared__ __align__(16) uint8_t s_lut[256];
-    const TokenRule rule = make_rule(p);
     stage_lut(p, s_lut);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (b >= p.B) return;
-    const int64_t start = p.offsets[b];
-    const int32_t L = clamp_len(p, p.offsets[b + 1] - start);
+    const TokenRule rule = make_rule(p, b, 1);  // window = this wave's sequence
+    const uint32_t start = 0;
+    const int32_t L = clamp_len(p, p.offsets[b + 1] - rule.off0);
     T *orow = static_cast<T *>(p.out) + b * p.P;
     const int32_t P = static_cast<int32_t>(p.P);
     for (int32_t tpos = 4 * lane; tpos < P; tpos += 256) {
@@ -1300,10 +1337,12 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     const int64_t groups = ((c.nchunks + 7) / 8 + 3) / 4;
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
+    const int padv = bsq_internal::tuning("tokenize_pad");  // unused dynamic LDS = occupancy cap (experiments)
+    const size_t pad = padv > 0 ? size_t(padv) : 0;
     if (bsq_internal::nontemporal_stores())
-        hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT>), grid, dim3(kThreads), 0, s, c);
+        hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT>), grid, dim3(kThreads), pad, s, c);
     else
-        hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT>), grid, dim3(kThreads), 0, s, c);
+        hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT>), grid, dim3(kThreads), pad, s, c);
     return check_launch(HOT ? "k_tokenize_chunks<onehot bcl>" : "k_tokenize_chunks");
 }
 
@@ -1315,7 +1354,7 @@ extern "C" {
 static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P) {
     const int64_t ntiles = ((B + 63) / 64) * ((P + kTT - 1) / kTT);
     const bool tiled_ok = C <= 250 && 4 * (64 * C * int64_t(sz) + 16) + tile_fixed_bytes<64>() <= 60 * 1024 &&
-                          ntiles < (int64_t(1) << 31) && B < (int64_t(1) << 31) - 256;
+                          ntiles < (int64_t(1) << 31) && B < (int64_t(1) << 31) - 256 && P <= kMaxTiledP;
     if (!tiled_ok) return 0;
     int path = bsq_internal::tuning("onehot_path");
     if (path == 0) {
@@ -1393,7 +1432,7 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     if (B == 0) return BSQ_OK;
     const size_t sz = bsq_dtype_size(t);
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
-    if (k.C > 250 || B >= (int64_t(1) << 31) - 1024)
+    if (k.C > 250 || B >= (int64_t(1) << 31) - 1024 || (!batch_first && P > kMaxTiledP))
         return bsq_tokenize_device_generic(d, chars, offsets, B, P, batch_first, t, out, hip_stream);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const uintptr_t addr = reinterpret_cast<uintptr_t>(out);
