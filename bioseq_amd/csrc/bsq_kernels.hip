@@ -660,7 +660,16 @@ struct TParams {
     const uint8_t *mask;
     int32_t C;
     uint64_t one_bits;
+    // index arithmetic without divisions: n / P for n < 2^31 is mulhi(n, magic) >> shift (pow2: n >> shift);
+    // step_q / step_r = (1024 / sizeof(T)) / P and % P: row / position advance between two stores of a lane
+    uint32_t magic, shift, pow2, step_q, step_r;
+    uint32_t magic_c, shift_c, pow2_c;  // the same for / C (one-hot mode: row -> sequence, channel)
 };
+
+// floor(n / d) for n < 2^31 with the constants of div_constants() (round-up method: exact below 2^31).
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t shift, uint32_t pow2) {
+    return pow2 ? n >> shift : __umulhi(n, magic) >> shift;
+}
 
 // N characters held as whole words (bytes are extracted only where they are consumed, so the loads
 // stay in flight); alignment 1: gfx950 does unaligned vector loads in hardware.
@@ -710,44 +719,67 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
         reinterpret_cast<uint32_t *>(lut)[lane] = w;
     }
     const int64_t nrows = HOT ? p.B * p.C : p.B;
-    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // scalar: chunk-level arithmetic stays on the SALU
+    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s);
     if (k >= p.nchunks) return;
     const int64_t total_chars = p.offsets[p.B];
     const int64_t lo = k * kChunk;  // chunks are relative to `out` (16-byte aligned on this path)
-    constexpr int32_t EPS = 1024 / SZ;  // elements between two consecutive stores of a lane
-    // The lane's four stores: element e0 + u*EPS.  One wide division, then small 32-bit steps.
-    const int64_t e0 = (lo + lane * 16) / SZ;
+    // The lane's four stores: element e0 + u*EPS with e0 = lo/SZ + lane*EPL.  (row, position) of e0 without a
+    // per-lane division: the chunk's first element is wave-uniform (one division, by a reciprocal when the
+    // matrix has < 2^31 elements), the lane's share adds < 1024 positions, the stores advance by (step_q, step_r).
+    const uint32_t Pu = static_cast<uint32_t>(p.P);
     int64_t b0;
-    int32_t t00;
-    if (nrows * p.P < (int64_t(1) << 32)) {
-        const uint32_t q = static_cast<uint32_t>(e0) / static_cast<uint32_t>(p.P);
-        b0 = q;
-        t00 = static_cast<int32_t>(static_cast<uint32_t>(e0) - q * static_cast<uint32_t>(p.P));
-    } else {
-        b0 = e0 / p.P;
-        t00 = static_cast<int32_t>(e0 - b0 * p.P);
+    uint32_t t00;
+    {
+        const int64_t ec = lo / SZ;  // first element of the chunk (wave-uniform)
+        int64_t bc;
+        uint32_t tc;
+        if (nrows * p.P < (int64_t(1) << 31)) {
+            const uint32_t q = fast_div(static_cast<uint32_t>(ec), p.magic, p.shift, p.pow2);
+            bc = q;
+            tc = static_cast<uint32_t>(ec) - q * Pu;
+        } else {
+            bc = ec / p.P;
+            tc = static_cast<uint32_t>(ec - bc * p.P);
+        }
+        const uint32_t tl = tc + static_cast<uint32_t>(lane) * EPL;  // < P + 1024
+        const uint32_t q = fast_div(tl, p.magic, p.shift, p.pow2);
+        b0 = bc + q;
+        t00 = tl - q * Pu;
     }
     // stage A: row coordinates + offsets of all four stores (unconditional: 8 independent loads in flight)
     bool live[4];
     int32_t t0[4];
     uint32_t chan[4];
     int64_t start[4], stop[4];
+    {
+        int64_t bu = b0;
+        uint32_t tu = t00;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t tt = static_cast<uint32_t>(t00) + static_cast<uint32_t>(u) * EPS;
-        const uint32_t q = tt / static_cast<uint32_t>(p.P);
-        int64_t b = b0 + q;  // row of the flat matrix
-        t0[u] = static_cast<int32_t>(tt - q * static_cast<uint32_t>(p.P));
-        live[u] = b < nrows;
-        b = live[u] ? b : nrows - 1;
-        chan[u] = 0;
-        if constexpr (HOT) {  // row = sequence * C + channel
-            const int64_t seq = b / p.C;
-            chan[u] = static_cast<uint32_t>(b - seq * p.C);
-            b = seq;
+        for (int u = 0; u < 4; ++u) {
+            int64_t b = bu;  // row of the flat matrix
+            t0[u] = static_cast<int32_t>(tu);
+            live[u] = b < nrows;
+            b = live[u] ? b : nrows - 1;
+            chan[u] = 0;
+            if constexpr (HOT) {  // row = sequence * C + channel
+                int64_t seq;
+                if (nrows < (int64_t(1) << 31))  // wave-uniform
+                    seq = fast_div(static_cast<uint32_t>(b), p.magic_c, p.shift_c, p.pow2_c);
+                else
+                    seq = b / p.C;
+                chan[u] = static_cast<uint32_t>(b - seq * p.C);
+                b = seq;
+            }
+            start[u] = p.offsets[b];
+            stop[u] = p.offsets[b + 1];
+            bu += p.step_q;
+            tu += p.step_r;
+            if (tu >= Pu) {
+                tu -= Pu;
+                bu += 1;
+            }
         }
-        start[u] = p.offsets[b];
-        stop[u] = p.offsets[b + 1];
     }
     int32_t L[4];
 #pragma unroll
@@ -809,6 +841,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
         if (!live[u]) continue;
         const int32_t j0 = t0[u] - p.bos;
         alignas(16) T vals[EPL];
+        uint32_t packed[EPL / WB];
 #pragma unroll
         for (int q = 0; q < EPL / WB; ++q) {
             uint32_t w = 0;
@@ -826,16 +859,22 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
                 if (nv >= 0) w = (w & ~(0xFFu << (8 * nv))) | (at_len_v << (8 * nv));  // position bos+L
             }
             if (jf < 0) w = (w & ~0xFFu) | p.bos_id;  // position 0 with BOS
+            packed[q] = w;
+            if constexpr (HOT || SZ != 1) {
 #pragma unroll
-            for (int i = 0; i < WB; ++i) {
-                const uint32_t tk = (w >> (8 * i)) & 0xFFu;
-                if constexpr (HOT)
-                    vals[q * WB + i] = tk == chan[u] ? hot_one : T(0);
-                else
-                    vals[q * WB + i] = static_cast<T>(tk);
+                for (int i = 0; i < WB; ++i) {
+                    const uint32_t tk = (w >> (8 * i)) & 0xFFu;
+                    if constexpr (HOT)
+                        vals[q * WB + i] = tk == chan[u] ? hot_one : T(0);
+                    else
+                        vals[q * WB + i] = static_cast<T>(tk);
+                }
             }
         }
-        store16<NT>(p.out + lo + u * 1024 + lane * 16, *reinterpret_cast<const uint4 *>(vals));
+        if constexpr (!HOT && SZ == 1)  // 8-bit tokens: the packed words ARE the 16 output bytes
+            store16<NT>(p.out + lo + u * 1024 + lane * 16, uint4{packed[0], packed[1], packed[2], packed[3]});
+        else
+            store16<NT>(p.out + lo + u * 1024 + lane * 16, *reinterpret_cast<const uint4 *>(vals));
     }
 }
 
@@ -1314,6 +1353,17 @@ bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
     return check_launch("k_tokenize_tile");
 }
 
+// Constants of fast_div(): floor(n / d) == mulhi(n, magic) >> shift for every n < 2^31 (round-up method:
+// magic = floor(2^(32+shift) / d) + 1 with shift = floor(log2 d); the error term n / 2^(32+shift) stays
+// below 1/d because d < 2^(shift+1)); powers of two are plain shifts.  1 <= d <= 2^30.
+void div_constants(uint32_t d, uint32_t *magic, uint32_t *shift, uint32_t *pow2) {
+    uint32_t sh = 0;
+    while ((uint64_t(2) << sh) <= d) ++sh;
+    *shift = sh;
+    *pow2 = (d & (d - 1)) == 0;
+    *magic = *pow2 ? 0u : uint32_t((uint64_t(1) << (32 + sh)) / d + 1);
+}
+
 template <typename T, bool HOT>
 bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     TParams c;
@@ -1334,6 +1384,10 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     c.at_len_id = k.eos ? uint32_t(k.eos_id) : c.fill_id;
     const int64_t room = k.P - k.bos - k.eos;
     c.room = int32_t(room < 0 ? 0 : room);
+    div_constants(uint32_t(k.P), &c.magic, &c.shift, &c.pow2);
+    div_constants(uint32_t(k.C > 0 ? k.C : 1), &c.magic_c, &c.shift_c, &c.pow2_c);
+    c.step_q = (1024u / uint32_t(sizeof(T))) / uint32_t(k.P);
+    c.step_r = (1024u / uint32_t(sizeof(T))) % uint32_t(k.P);
     const int64_t groups = ((c.nchunks + 7) / 8 + 3) / 4;
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
