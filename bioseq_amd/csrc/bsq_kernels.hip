@@ -430,7 +430,41 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
 // (coalesced bytes), scatter their ones into the wave's private 4-KiB LDS image, stream the image
 // out with 4 x (ds_read_b128 -> global_store_dwordx4), clear the ones.  No barriers.
 // ------------------------------------------------------------------------------------------
+// floor(n / d) for n < 2^31 with the constants of div_constants() (round-up method: exact below 2^31).
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t shift, uint32_t pow2) {
+    return pow2 ? n >> shift : __umulhi(n, magic) >> shift;
+}
+
+// Constants of fast_div(): floor(n / d) == mulhi(n, magic) >> shift for every n < 2^31 (round-up method:
+// magic = floor(2^(32+shift) / d) + 1 with shift = floor(log2 d); the error term n / 2^(32+shift) stays
+// below 1/d because d < 2^(shift+1)); powers of two are plain shifts.  1 <= d <= 2^30.
+void div_constants(uint32_t d, uint32_t *magic, uint32_t *shift, uint32_t *pow2) {
+    uint32_t sh = 0;
+    while ((uint64_t(2) << sh) <= d) ++sh;
+    *shift = sh;
+    *pow2 = (d & (d - 1)) == 0;
+    *magic = *pow2 ? 0u : uint32_t((uint64_t(1) << (32 + sh)) / d + 1);
+}
+
 constexpr int kChunk = 4096;
+
+// floor(n / d) and the remainder for 0 <= n < 2^52, 1 <= d < 2^31 through one double multiply with
+// inv = 1.0 / d (computed on the host): the product is within 1 of n / d, one correction step makes it
+// exact.  Replaces the ~120-instruction 64-bit integer division the chunk kernels would otherwise run
+// twice per wave (byte offset -> row, row -> position).
+__device__ __forceinline__ int64_t div_by(int64_t n, int64_t d, double inv, int64_t *rem) {
+    int64_t q = static_cast<int64_t>(static_cast<double>(n) * inv);
+    int64_t r = n - q * d;
+    if (r < 0) {
+        q -= 1;
+        r += d;
+    } else if (r >= d) {
+        q += 1;
+        r -= d;
+    }
+    *rem = r;
+    return q;
+}
 
 struct EParams {
     const uint8_t *tok;  // raw tokens (kNone = no one), row t at tok + t*Bp (Bp = B rounded up to 256: every
@@ -442,6 +476,8 @@ struct EParams {
     int32_t head;        // out & 4095
     int32_t C;
     uint64_t one_bits;
+    double inv_rowbytes, inv_B;  // reciprocals for div_by()
+    uint32_t rb_magic, rb_shift, rb_pow2;  // fast_div() constants of rowbytes
 };
 
 // WPC = waves per chunk: 1 -> a wave writes a whole 4-KiB chunk (4 stores); 4 -> the workgroup's four waves
@@ -467,11 +503,12 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     if (hi > p.total) hi = p.total;
     if (hi <= lo) return;
     const int32_t len = static_cast<int32_t>(hi - lo);
-    const int64_t r_lo = lo / rowbytes;                               // first row intersecting the piece
-    const int32_t skip = static_cast<int32_t>(lo - r_lo * rowbytes);  // bytes of row r_lo before the piece
-    const int32_t nr = (skip + len + rowbytes - 1) / rowbytes;        // rows intersecting it
-    const int64_t t_lo = r_lo / p.B;  // flat row r = t*B + b
-    const int64_t b_lo = r_lo - t_lo * p.B;
+    int64_t skip64, b_lo;
+    const int64_t r_lo = div_by(lo, rowbytes, p.inv_rowbytes, &skip64);  // first row intersecting the piece
+    const int32_t skip = static_cast<int32_t>(skip64);                   // bytes of row r_lo before the piece
+    const int32_t nr = static_cast<int32_t>(fast_div(static_cast<uint32_t>(skip + len + rowbytes - 1), p.rb_magic,
+                                                     p.rb_shift, p.rb_pow2));  // rows intersecting it
+    const int64_t t_lo = div_by(r_lo, p.B, p.inv_B, &b_lo);              // flat row r = t*B + b
     const uint8_t *tok = p.tok + t_lo * p.Bp + b_lo;
     const int64_t wrap_at = p.B - b_lo;  // rows i >= wrap_at belong to position t_lo + 1 (or later)
     // scatter: row r_lo + i has its one at image byte i*rowbytes - skip + tok*sizeof(ST).
@@ -666,10 +703,6 @@ struct TParams {
     uint32_t magic_c, shift_c, pow2_c;  // the same for / C (one-hot mode: row -> sequence, channel)
 };
 
-// floor(n / d) for n < 2^31 with the constants of div_constants() (round-up method: exact below 2^31).
-__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t shift, uint32_t pow2) {
-    return pow2 ? n >> shift : __umulhi(n, magic) >> shift;
-}
 
 // N characters held as whole words (bytes are extracted only where they are consumed, so the loads
 // stay in flight); alignment 1: gfx950 does unaligned vector loads in hardware.
@@ -1143,6 +1176,8 @@ struct CParams {
     int32_t room;     // P - bos - eos (length clamp)
     int32_t cpw;
     uint64_t one_bits;
+    double inv_rowbytes, inv_B;  // reciprocals for div_by()
+    uint32_t rb_magic, rb_shift, rb_pow2;  // fast_div() constants of rowbytes
 };
 
 // Fewer resident workgroups stream faster (see launch_chunks): the launch caps the occupancy at 4 per CU.
@@ -1178,11 +1213,12 @@ __global__ __launch_bounds__(kThreads) void k_onehot_chunks(const CParams p) {
         if (lo < 0) lo = 0;
         if (hi > p.total) hi = p.total;
         const int32_t len = static_cast<int32_t>(hi - lo);
-        const int64_t r_lo = lo / rowbytes;
-        const int32_t skip = static_cast<int32_t>(lo - r_lo * rowbytes);
-        const int32_t nr = (skip + len + rowbytes - 1) / rowbytes;
-        const int64_t t_lo = r_lo / p.B;
-        const int64_t b_lo = r_lo - t_lo * p.B;
+        int64_t skip64, b_lo;
+        const int64_t r_lo = div_by(lo, rowbytes, p.inv_rowbytes, &skip64);
+        const int32_t skip = static_cast<int32_t>(skip64);
+        const int32_t nr = static_cast<int32_t>(fast_div(static_cast<uint32_t>(skip + len + rowbytes - 1), p.rb_magic,
+                                                         p.rb_shift, p.rb_pow2));
+        const int64_t t_lo = div_by(r_lo, p.B, p.inv_B, &b_lo);
         for (int32_t i0 = 0; i0 < nr; i0 += 64) {
             const int32_t i = i0 + lane;
             if (i < nr) {
@@ -1273,6 +1309,9 @@ bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
     const int cpw = bsq_internal::tuning("expand_cpw");
     c.cpw = cpw > 0 ? cpw : 1;
     c.one_bits = k.one_bits;
+    c.inv_rowbytes = 1.0 / double(k.C * int64_t(sz));
+    c.inv_B = 1.0 / double(k.B);
+    div_constants(uint32_t(k.C * int64_t(sz)), &c.rb_magic, &c.rb_shift, &c.rb_pow2);
     if ((c.nchunks + 7) / 8 / (4 * c.cpw) + 1 >= (int64_t(1) << 28)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     switch (sz) {
     case 1: return launch_chunks<uint8_t>(c, s);
@@ -1336,6 +1375,9 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
     e.nchunks = (e.head + e.total + kChunk - 1) / kChunk;
     e.C = k.C;
     e.one_bits = k.one_bits;
+    e.inv_rowbytes = 1.0 / double(k.C * int64_t(sz));
+    e.inv_B = 1.0 / double(k.B);
+    div_constants(uint32_t(k.C * int64_t(sz)), &e.rb_magic, &e.rb_shift, &e.rb_pow2);
     switch (sz) {
     case 1: return launch_expand<uint8_t>(e, s);
     case 2: return launch_expand<uint16_t>(e, s);
@@ -1351,17 +1393,6 @@ bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
     const size_t smem = tile_fixed_bytes<TB>();
     hipLaunchKernelGGL((k_tokenize_tile<T, TB>), dim3(unsigned(int64_t(k.ntb) * ntt)), dim3(kThreads), smem, s, k);
     return check_launch("k_tokenize_tile");
-}
-
-// Constants of fast_div(): floor(n / d) == mulhi(n, magic) >> shift for every n < 2^31 (round-up method:
-// magic = floor(2^(32+shift) / d) + 1 with shift = floor(log2 d); the error term n / 2^(32+shift) stays
-// below 1/d because d < 2^(shift+1)); powers of two are plain shifts.  1 <= d <= 2^30.
-void div_constants(uint32_t d, uint32_t *magic, uint32_t *shift, uint32_t *pow2) {
-    uint32_t sh = 0;
-    while ((uint64_t(2) << sh) <= d) ++sh;
-    *shift = sh;
-    *pow2 = (d & (d - 1)) == 0;
-    *magic = *pow2 ? 0u : uint32_t((uint64_t(1) << (32 + sh)) / d + 1);
 }
 
 template <typename T, bool HOT>
@@ -1412,16 +1443,18 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P) {
     if (!tiled_ok) return 0;
     int path = bsq_internal::tuning("onehot_path");
     if (path == 0) {
-        // Measured on MI355X over 17 shapes (profiles/r01/sweep_shapes2.txt):
-        //  3 chunk-owner: ~7 TB/s when a row is >= 48 B and its per-position gather set stays L2-resident, i.e.
-        //                 the pitch is a multiple of 32 KiB (each XCD keeps to its own chunk columns) and
-        //                 B <= 128k, or B <= 16k whatever the pitch;
-        //  2 two-pass   : 5.5-6.3 TB/s for any pitch once rows are >= 16 B and the output is large enough to
-        //                 amortise the second launch;
+        // Measured on MI355X over 22 shapes (profiles/r01/sweep_shapes5.txt, sweep_occupancy2.txt):
+        //  2 two-pass   : the fastest streamer once the output is large -- 7.3-7.4 TB/s at 3 workgroups per CU
+        //                 when rows are >= 64 B, 6-7 TB/s for smaller rows, any pitch; needs rows >= 16 B and an
+        //                 output that amortises the token pass and the second launch;
+        //  3 chunk-owner: one launch, no scratch: ahead below ~2 GiB of output when a row is >= 48 B and its
+        //                 per-position gather set stays L2-resident, i.e. the pitch is a multiple of 32 KiB (each
+        //                 XCD keeps to its own chunk columns) and B <= 128k, or B <= 16k whatever the pitch;
         //  1 tiled      : the rest (tiny rows such as int8 DNA, small outputs).
         const int64_t rowbytes = C * int64_t(sz), pitch = B * rowbytes, total = pitch * P;
         const bool pinned_columns = pitch % (8 * kChunk) == 0;
-        if (rowbytes >= 48 && ((pinned_columns && B <= 131072) || B <= 16384))
+        const bool owner_ok = rowbytes >= 48 && ((pinned_columns && B <= 131072) || B <= 16384);
+        if (owner_ok && total < (int64_t(2) << 30))
             path = 3;
         else if (rowbytes >= 16 && total >= (int64_t(256) << 20))
             path = 2;
