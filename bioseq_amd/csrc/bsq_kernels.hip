@@ -31,6 +31,7 @@
 
 #include <cstdint>
 #include <mutex>
+#include <type_traits>
 
 #include "bsq.h"
 #include "bsq_internal.h"
@@ -478,6 +479,7 @@ struct EParams {
     uint64_t one_bits;
     double inv_rowbytes, inv_B;  // reciprocals for div_by()
     uint32_t rb_magic, rb_shift, rb_pow2;  // fast_div() constants of rowbytes
+    int32_t force4;                        // experiment knob "expand_slots" = 4: always four token slots per step
 };
 
 // WPC = waves per chunk: 1 -> a wave writes a whole 4-KiB chunk (4 stores); 4 -> the workgroup's four waves
@@ -512,25 +514,36 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     const uint8_t *tok = p.tok + t_lo * p.Bp + b_lo;
     const int64_t wrap_at = p.B - b_lo;  // rows i >= wrap_at belong to position t_lo + 1 (or later)
     // scatter: row r_lo + i has its one at image byte i*rowbytes - skip + tok*sizeof(ST).
-    // 4 coalesced token loads in flight per step.
-    for (int32_t i0 = 0; i0 < nr; i0 += 256) {
-        uint32_t tk[4];
+    // NS (1..4) coalesced token loads in flight per step, straight-line per NS: the number of 64-row slots a
+    // step needs and the (rare) row-wrap case are wave-uniform, so they are scalar branches.
+    const int32_t nr_s = __builtin_amdgcn_readfirstlane(nr);
+    const bool wraps = wrap_at < nr_s;  // the piece runs over the end of position t_lo's rows
+    auto step = [&](auto ns_tag, int32_t i0) {
+        constexpr int NS = decltype(ns_tag)::value;
+        uint32_t tk[NS];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NS; ++q) {
             const int32_t i = i0 + 64 * q + lane;
             int64_t a = i;
-            if (i >= wrap_at) {  // the piece runs over the end of position t_lo's rows
+            if (wraps && i >= wrap_at) {
                 const int64_t w = (i - wrap_at) / p.B + 1;
                 a = i + w * (p.Bp - p.B);
             }
-            tk[q] = i < nr ? static_cast<uint32_t>(tok[a]) : kNone;
+            tk[q] = i < nr_s ? static_cast<uint32_t>(tok[a]) : kNone;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NS; ++q) {
             const int32_t i = i0 + 64 * q + lane;
             const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk[q]) * static_cast<int32_t>(sizeof(ST));
             if (tk[q] != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
         }
+    };
+    for (int32_t i0 = 0; i0 < nr_s; i0 += 256) {
+        const int32_t left = p.force4 ? 256 : nr_s - i0;
+        if (left > 192) step(std::integral_constant<int, 4>{}, i0);
+        else if (left > 128) step(std::integral_constant<int, 3>{}, i0);
+        else if (left > 64) step(std::integral_constant<int, 2>{}, i0);
+        else step(std::integral_constant<int, 1>{}, i0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1378,6 +1391,7 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
     e.inv_rowbytes = 1.0 / double(k.C * int64_t(sz));
     e.inv_B = 1.0 / double(k.B);
     div_constants(uint32_t(k.C * int64_t(sz)), &e.rb_magic, &e.rb_shift, &e.rb_pow2);
+    e.force4 = bsq_internal::tuning("expand_slots") == 4;
     switch (sz) {
     case 1: return launch_expand<uint8_t>(e, s);
     case 2: return launch_expand<uint16_t>(e, s);

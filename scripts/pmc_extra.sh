@@ -4,8 +4,8 @@ TAG=${1:-pmc_extra}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"; cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 2 --no-cpu-baseline $*"
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/sq" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/sq.err"; echo "sq rc=$?"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/tcc" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/tcc.err"; echo "tcc rc=$?"
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/sq" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/sq.err"; echo "sq rc=$?"
+timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/tcc" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/tcc.err"; echo "tcc rc=$?"
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict

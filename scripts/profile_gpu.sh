@@ -8,11 +8,11 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 echo "trace rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err"
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err"
 echo "pmc write rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
 echo "pmc fetch rc=$?"
 find "$OUT" -name "*.csv" | head -20
 python3 "$REPO/scripts/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
