@@ -181,8 +181,17 @@ bsq_status download(Staging &s, void *out, const void *dev_out, size_t nbytes, h
         }
     };
     std::vector<std::thread> pool;
-    pool.reserve(size_t(nthreads));
-    for (int j = 0; j < nthreads; ++j) pool.emplace_back(worker, j);
+    try {
+        pool.reserve(size_t(nthreads));
+        for (int j = 0; j < nthreads; ++j) pool.emplace_back(worker, j);
+    } catch (...) {  // no threads to be had (never let an exception cross the C ABI): plain copy instead
+        failed.store(1);
+        for (std::thread &t : pool) t.join();
+        e = hipMemcpyAsync(out, dev_out, nbytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("D2H copy of the result", e);
+        return BSQ_OK;
+    }
     for (int64_t c = 0; c < npieces && !failed.load(); ++c) {
         if (c >= kSlots)  // the slot is free once every worker has drained piece c - kSlots
             while (copied[size_t(c - kSlots)].load(std::memory_order_acquire) < nthreads && !failed.load())

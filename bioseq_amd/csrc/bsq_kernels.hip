@@ -29,6 +29,7 @@
 //   k_first_too_long   device-side length validation.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdint>
 #include <mutex>
 #include <type_traits>
@@ -774,11 +775,10 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     // per-lane division: the chunk's first element is wave-uniform (one division, by a reciprocal when the
     // matrix has < 2^31 elements), the lane's share adds < 1024 positions, the stores advance by (step_q, step_r).
     const uint32_t Pu = static_cast<uint32_t>(p.P);
-    int64_t b0;
+    int64_t b0, bc;  // bc: first row of the chunk (wave-uniform)
     uint32_t t00;
     {
         const int64_t ec = lo / SZ;  // first element of the chunk (wave-uniform)
-        int64_t bc;
         uint32_t tc;
         if (nrows * p.P < (int64_t(1) << 31)) {
             const uint32_t q = fast_div(static_cast<uint32_t>(ec), p.magic, p.shift, p.pow2);
@@ -827,35 +827,49 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
             }
         }
     }
+    // Lengths from the low words (a valid length is < 2^31; anything else is clamped to `room` as before).
     int32_t L[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int64_t len = stop[u] - start[u];
-        L[u] = static_cast<int32_t>(len > p.room ? p.room : len);
+        const uint32_t len = static_cast<uint32_t>(stop[u]) - static_cast<uint32_t>(start[u]);
+        L[u] = static_cast<int32_t>(len > static_cast<uint32_t>(p.room) ? static_cast<uint32_t>(p.room) : len);
     }
     // stage B: the characters.  Loads are UNCONDITIONAL (lanes that must not touch their own address read
-    // the first EPL bytes of the buffer instead) so that all four are in flight together.
+    // the first bytes of the window instead) so that all four are in flight together.  Addresses are 32-bit
+    // offsets from a wave-uniform base: the rows of a chunk are consecutive sequences, their characters lie
+    // within 2^31 bytes of the first one's (off0), so "is [a, a + EPL) inside the buffer" is one unsigned
+    // compare of (rel - lo_b) against span, and the load takes the scalar-base + 32-bit-offset form.
     UBytes<EPL> cw[4];
     bool slow[4], fast[4];
-    const bool can_vec = total_chars >= EPL;  // wave-uniform
+    uint32_t uoff[4];
+    int64_t seq0 = bc;
+    if constexpr (HOT) seq0 = (nrows < (int64_t(1) << 31)) ? int64_t(fast_div(static_cast<uint32_t>(bc), p.magic_c, p.shift_c, p.pow2_c)) : bc / p.C;
+    const int64_t off0 = p.offsets[seq0];
+    const int64_t lo_b64 = -off0, hi_b64 = total_chars - off0 - EPL;  // valid range of a vector's first byte, relative to off0
+    const bool can_vec = hi_b64 >= lo_b64;                            // wave-uniform (the buffer holds >= EPL bytes)
+    const int32_t lo_b = lo_b64 < INT32_MIN ? INT32_MIN : static_cast<int32_t>(lo_b64);
+    const int32_t hi_b = hi_b64 > INT32_MAX ? INT32_MAX : (hi_b64 < lo_b ? lo_b : static_cast<int32_t>(hi_b64));
+    const uint32_t span = static_cast<uint32_t>(hi_b) - static_cast<uint32_t>(lo_b);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int32_t j0 = t0[u] - p.bos;
-        const int64_t a = start[u] + j0;
+        const uint32_t rel = static_cast<uint32_t>(start[u]) - static_cast<uint32_t>(off0) + static_cast<uint32_t>(j0);
+        const uint32_t d = rel - static_cast<uint32_t>(lo_b);  // offset from the lowest valid address
         const bool need = live[u] && j0 < L[u] && j0 + EPL > 0;
-        fast[u] = can_vec && need && a >= 0 && a + EPL <= total_chars;
+        fast[u] = can_vec && need && d <= span;
         slow[u] = need && !fast[u];
+        uoff[u] = fast[u] ? d : 0u;
     }
     UBytes<EPL> mw[4];  // mask bytes (one-hot mode with a mask): 0 -> the position is an all-zero row
     const bool has_mask = HOT && p.mask != nullptr;
     if (can_vec) {
+        const uint8_t *cbase = p.chars + (off0 + lo_b);  // wave-uniform, inside the buffer
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            cw[u] = *reinterpret_cast<const UBytes<EPL> *>(p.chars + (fast[u] ? start[u] + t0[u] - p.bos : 0));
+        for (int u = 0; u < 4; ++u) cw[u] = *reinterpret_cast<const UBytes<EPL> *>(cbase + uoff[u]);
         if (has_mask) {
+            const uint8_t *mbase = p.mask + (off0 + lo_b);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                mw[u] = *reinterpret_cast<const UBytes<EPL> *>(p.mask + (fast[u] ? start[u] + t0[u] - p.bos : 0));
+            for (int u = 0; u < 4; ++u) mw[u] = *reinterpret_cast<const UBytes<EPL> *>(mbase + uoff[u]);
         }
     } else {
 #pragma unroll
