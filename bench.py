@@ -101,7 +101,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=20)  # the first ~10 launches after idle run 3-8 % slow (clock ramp)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap the CPU baseline's thread count")
@@ -218,6 +218,8 @@ def main():
     wall = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     kern_avg_ms = float(np.mean(kern_ms))
+    if os.environ.get("BSQ_BENCH_DUMP"):  # per-step device times, for variance hunting
+        print("per-step ms:", " ".join("%.3f" % v for v in kern_ms), file=sys.stderr)
 
     # write-bandwidth yardstick: the fastest plain fill we know (one 1-KiB store per wave, one aligned
     # 4-KiB chunk per workgroup, blocks in address order) over the same output buffer
