@@ -289,7 +289,8 @@ Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
                   {"tile_order", "BSQ_TILE_ORDER", 0, false},
                   {"fill_mode", "BSQ_FILL_MODE", 0, false},
                   {"onehot_path", "BSQ_ONEHOT_PATH", 0, false},
-                  {"expand_cpw", "BSQ_EXPAND_CPW", 0, false},
+                  {"expand_pad", "BSQ_EXPAND_PAD", 0, false},
+                  {"chunks_cpw", "BSQ_CHUNKS_CPW", 0, false},
                   {"tokenize_path", "BSQ_TOKENIZE_PATH", 0, false},
                   {"fill_pad", "BSQ_FILL_PAD", 0, false},
                   {"chunks_pad", "BSQ_CHUNKS_PAD", 0, false},

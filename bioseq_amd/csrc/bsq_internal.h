@@ -10,12 +10,19 @@ namespace bsq_internal {
 bsq_status set_error(bsq_status st, const char *msg);
 bsq_status set_hip_error(const char *what, hipError_t e);
 // Tuning / diagnostic knobs (bsq_tuning_set, or environment BSQ_<NAME> read at first use):
-//   nt_stores   1: `global_store ... nt` for the one-hot stream          (default 1)
-//   onehot_path 0: automatic, 1: tiled kernel, 2: two-pass (tokens + expansion), 3: chunk-owner kernel
-//   expand_cpw  chunks per wave of the chunk kernels (default 1)
-//   onehot_tb   0: automatic, else force 64 / 128 / 256 sequences per tile
-//   tile_order  0: sequence-tile index fastest, 1: position-tile index fastest
-//   fill_mode   access pattern of bsq_fill_device (write-bandwidth experiments)
+// (speed only -- results never depend on them; every variant is covered by the GPU parity tests)
+//   nt_stores     1: `global_store ... nt` for the output streams (default 1)
+//   onehot_path   0: automatic, 1: tiled kernel, 2: two-pass (tokens + expansion), 3: chunk-owner kernel
+//   expand_pad    unused dynamic LDS of k_expand_chunks = occupancy cap: 0 automatic, > 0 bytes, < 0 none
+//   expand_slots  4: k_expand_chunks always issues four token loads per step (0: as many as the chunk needs)
+//   chunks_pad    the same cap for k_onehot_chunks (0: 22528 bytes = 4 workgroups per CU)
+//   chunks_cpw    chunks per wave of k_onehot_chunks (default 1)
+//   tokenize_path 1: never use k_tokenize_chunks / the raw-token kernel for batch_tokenize
+//   tokenize_pad  unused dynamic LDS of k_tokenize_chunks (experiments: no cap helps it)
+//   onehot_tb     0: automatic, else force 64 / 128 / 256 sequences per tile of k_onehot_tile
+//   tile_order    0: sequence-tile index fastest, 1: position-tile index fastest
+//   fill_mode, fill_pad   access pattern / occupancy of bsq_fill_device (write-bandwidth yardsticks)
+//   host_copy_threads     worker threads of the pipelined device -> host result copy (0: 8)
 int tuning(const char *name);
 bool set_tuning(const char *name, int value);
 inline bool nontemporal_stores() { return tuning("nt_stores") != 0; }

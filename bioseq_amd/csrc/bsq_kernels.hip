@@ -483,11 +483,11 @@ struct EParams {
     int32_t force4;                        // experiment knob "expand_slots" = 4: always four token slots per step
 };
 
-// WPC = waves per chunk: 1 -> a wave writes a whole 4-KiB chunk (4 stores); 4 -> the workgroup's four waves
-// write one chunk, 1 KiB (one store) each -- the exact shape of the fastest plain fill.
-template <typename ST, bool NT, int WPC>
+// (A variant with the four waves of a workgroup sharing one chunk -- the shape of the fastest plain fill --
+// measured 1.6x slower: every wave then pays the token-load latency for a single 1-KiB store.)
+template <typename ST, bool NT>
 __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
-    constexpr int PIECE = kChunk / WPC;       // bytes per wave
+    constexpr int PIECE = kChunk;             // bytes per wave
     constexpr int NS = PIECE / 1024;          // 16-byte stores per lane
     __shared__ __align__(16) uint8_t s_img[4][PIECE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -496,12 +496,12 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     for (int u = 0; u < NS; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
 
     // chunk of this wave: class = blockIdx % 8 (pinned to the XCD the block lands on)
-    const int64_t slot = static_cast<int64_t>(blockIdx.x >> 3) * (4 / WPC) + (WPC == 1 ? wave : 0);
+    const int64_t slot = static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave;
     const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot;
     if (k >= p.nchunks) return;
     const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
     const ST one = static_cast<ST>(p.one_bits);
-    int64_t lo = k * kChunk - p.head + (WPC == 1 ? 0 : wave * PIECE), hi = lo + PIECE;  // byte range relative to `out`
+    int64_t lo = k * kChunk - p.head, hi = lo + PIECE;  // byte range relative to `out`
     if (lo < 0) lo = 0;
     if (hi > p.total) hi = p.total;
     if (hi <= lo) return;
@@ -1333,7 +1333,7 @@ bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
     c.at_len_id = k.eos ? uint32_t(k.eos_id) : c.fill_id;
     const int64_t room = k.P - k.bos - k.eos;
     c.room = int32_t(room < 0 ? 0 : room);
-    const int cpw = bsq_internal::tuning("expand_cpw");
+    const int cpw = bsq_internal::tuning("chunks_cpw");  // chunks per wave (1 is fastest: 0.75 / 0.86 / 0.93 ms for 1 / 2 / 4 on cfg3)
     c.cpw = cpw > 0 ? cpw : 1;
     c.one_bits = k.one_bits;
     c.inv_rowbytes = 1.0 / double(k.C * int64_t(sz));
@@ -1350,28 +1350,22 @@ bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
 
 template <typename ST>
 bsq_status launch_expand(const EParams &e, hipStream_t s) {
-    // One wave per chunk by default; "expand_cpw" = 44 selects 4 waves per chunk (measured 1.6x slower:
-    // every wave then pays the token-load latency for a single 1-KiB store).
-    const bool quarter = bsq_internal::tuning("expand_cpw") == 44;
     const int64_t per_class = (e.nchunks + 7) / 8;
-    const int64_t groups = quarter ? per_class : (per_class + 3) / 4;
+    const int64_t groups = (per_class + 3) / 4;
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
-    const bool nt = bsq_internal::nontemporal_stores();
-    // Occupancy cap: with 8 workgroups per CU this kernel streams at 6.3 TB/s, with 4 at 6.7, with 3 at 7.2
-    // (2 is too few: 5.2) -- measured on cfg3, profiles/r01/expand_occupancy.txt -- when rows are >= 64 bytes;
-    // with smaller rows (more token loads and scatters per chunk) it needs the full occupancy instead
-    // (profiles/r01/sweep_shapes4.txt).  Unused dynamic LDS is the cheapest way to hold it at 3 (3 x (16 KiB image + 36 KiB) = 156 KiB <= 160 KiB; 37 KiB already rounds up to 2 per CU).  "expand_cpw" >= 1000 overrides.
-    const int padv = bsq_internal::tuning("expand_cpw");
-    const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;  // <= 65 rows per chunk: one token load per lane
-    const size_t pad = padv >= 1000 ? size_t(padv) : (big_rows ? size_t(36864) : size_t(0));
-    if (quarter) {
-        if (nt) hipLaunchKernelGGL((k_expand_chunks<ST, true, 4>), grid, dim3(kThreads), pad, s, e);
-        else hipLaunchKernelGGL((k_expand_chunks<ST, false, 4>), grid, dim3(kThreads), pad, s, e);
-    } else {
-        if (nt) hipLaunchKernelGGL((k_expand_chunks<ST, true, 1>), grid, dim3(kThreads), pad, s, e);
-        else hipLaunchKernelGGL((k_expand_chunks<ST, false, 1>), grid, dim3(kThreads), pad, s, e);
-    }
+    // Occupancy cap through unused dynamic LDS (3 x (16 KiB image + 36 KiB) = 156 KiB <= 160 KiB; 37 KiB already
+    // rounds up to 2 per CU).  Rows >= 64 B (one token load per lane and chunk): 3 workgroups per CU stream
+    // cfg3 at 7.5-7.8 TB/s, 8 at 6.3, 4 at 6.7, 2 at 5.5.  Smaller rows: no cap -- shapes disagree (1M x 160 x 28 B
+    // wants all 8, 64k x 2048 x 28 B is 6 % faster at 4; profiles/r01/sweep_occupancy2.txt).
+    // Knob "expand_pad": 0 = this rule, > 0 = that many bytes, < 0 = none.
+    const int padv = bsq_internal::tuning("expand_pad");
+    const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;
+    const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : (big_rows ? size_t(36864) : size_t(0)));
+    if (bsq_internal::nontemporal_stores())
+        hipLaunchKernelGGL((k_expand_chunks<ST, true>), grid, dim3(kThreads), pad, s, e);
+    else
+        hipLaunchKernelGGL((k_expand_chunks<ST, false>), grid, dim3(kThreads), pad, s, e);
     return check_launch("k_expand_chunks");
 }
 

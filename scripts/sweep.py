@@ -34,14 +34,14 @@ def run():
         capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), n, P, int(op == "tokenize"), dt, out.data_ptr(), None))
 
 def setk(**kw):
-    for k in ("nt_stores", "onehot_tb", "tile_order", "onehot_path", "expand_cpw"):
+    for k in ("nt_stores", "onehot_tb", "tile_order", "onehot_path", "chunks_cpw"):
         capi.check(lib.bsq_tuning_set(k.encode(), int(kw.get(k, 0))))
 
 variants = [dict()]
 if op == "onehot":
     variants = [dict(onehot_path=1, nt_stores=nt) for nt in (0, 1)] + \
-               [dict(onehot_path=2, expand_cpw=c, nt_stores=nt) for c in (1, 2) for nt in (0, 1)] + \
-               [dict(onehot_path=3, expand_cpw=c, nt_stores=nt) for c in (1, 2, 4) for nt in (0, 1)]
+               [dict(onehot_path=2, nt_stores=nt) for nt in (0, 1)] + \
+               [dict(onehot_path=3, chunks_cpw=c, nt_stores=nt) for c in (1, 2, 4) for nt in (0, 1)]
 setk(); run(); torch.cuda.synchronize(); ref.copy_(out)
 times = {i: [] for i in range(len(variants))}
 for rnd in range(6):

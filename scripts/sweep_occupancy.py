@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Occupancy sweep over shapes: two-pass (expansion kernel, pad via expand_cpw >= 1000) and chunk-owner
+"""Occupancy sweep over shapes: two-pass (expansion kernel, pad via expand_pad) and chunk-owner
 (pad via chunks_pad) with the unused-LDS pads that give 8/7/6/5/4/3 resident workgroups per CU."""
 import ctypes, os, sys
 import numpy as np
@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 PADS = [(8, 1024), (6, 10240), (5, 15360), (4, 22528), (3, 36864)]
 sel = sys.argv[1:] and [int(x) for x in sys.argv[1:]]
 def setk(**kw):
-    for k in ("onehot_path", "expand_cpw", "chunks_pad"):
+    for k in ("onehot_path", "expand_pad", "chunks_pad"):
         capi.check(lib.bsq_tuning_set(k.encode(), int(kw.get(k, 0))))
 for si, (key, flags, B, lo, hi, P, dc) in enumerate(SHAPES):
     if sel and si not in sel: continue
@@ -31,7 +31,7 @@ for si, (key, flags, B, lo, hi, P, dc) in enumerate(SHAPES):
     for path in (2, 3):
         row = []
         for wg, pad in PADS:
-            if path == 2: setk(onehot_path=2, expand_cpw=pad)
+            if path == 2: setk(onehot_path=2, expand_pad=pad)
             else: setk(onehot_path=3, chunks_pad=pad)
             run(); torch.cuda.synchronize()
             ts = []

@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 from sweep_shapes_list import SHAPES
 sel = sys.argv[1:] and [int(x) for x in sys.argv[1:]]
 def setk(**kw):
-    for k in ("nt_stores", "onehot_path", "expand_cpw"):
+    for k in ("nt_stores", "onehot_path"):
         capi.check(lib.bsq_tuning_set(k.encode(), int(kw.get(k, 0))))
 for si, (key, flags, B, lo, hi, P, dc) in enumerate(SHAPES):
     if sel and si not in sel: continue
