@@ -30,10 +30,16 @@ for rnd in range(3):
         capi.check(lib.bsq_tuning_set(knob.encode(), v))
         run(); torch.cuda.synchronize()
         ts = []
-        for _ in range(7):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(3): run()
-            b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) / 3)
+        if os.environ.get("AB_PER_STEP"):  # bench.py's protocol: one event pair per call, all queued before the sync
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(21)]
+            for a, b in ev:
+                a.record(); run(); b.record()
+            torch.cuda.synchronize(); ts = [a.elapsed_time(b) for a, b in ev]
+        else:
+            for _ in range(7):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3): run()
+                b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) / 3)
         row.append("%d: %.3f ms (%.0f GB/s)" % (v, np.median(ts), algo / np.median(ts) / 1e6))
     print("  round %d  " % rnd + " | ".join(row), flush=True)
