@@ -73,6 +73,7 @@ def load():
         "bsq_onehot_device_generic": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
         "bsq_fill_device": (i32, [vp, sz, ctypes.c_uint32, vp]),
         "bsq_fill_pattern_device": (i32, [vp, i64, i64, i32, i32, i32, i32, i32, vp]),
+        "bsq_xcd_of_blocks_device": (i32, [vp, i32, vp]),
         "bsq_blosum62_normrows": (i32, [vp]),
         "bsq_augment_device": (i32, [vp, vp, i64, i32, ctypes.c_double, ctypes.c_uint64, vp]),
         "bsq_tokenize_host": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, c_int, vp, i64p]),

@@ -1075,6 +1075,14 @@ __global__ __launch_bounds__(kThreads) void k_fill_pattern(uint8_t *dst, int64_t
     }
 }
 
+// Diagnostic: the XCD every block of a 1-D grid ran on (HW_REG_XCC_ID, 0..7).  The chunk kernels rely -- for
+// speed only -- on blocks b and b + 8 sharing an XCD; this records what the dispatcher actually did.
+__global__ __launch_bounds__(kThreads) void k_xcd_probe(int32_t *xcd) {
+    uint32_t id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    if (threadIdx.x == 0) xcd[blockIdx.x] = static_cast<int32_t>(id & 0xFu);
+}
+
 __global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offsets, int64_t B, int64_t room,
                                                              unsigned long long *first_bad) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
@@ -1716,6 +1724,12 @@ bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32
         hipLaunchKernelGGL((k_fill_pattern<false>), grid, dim3(kThreads), 0, s, static_cast<uint8_t *>(dst), rows, pitch,
                            seg, rows_per_wave, ncb, nrb, order, interleave);
     return check_launch("k_fill_pattern");
+}
+
+bsq_status bsq_xcd_of_blocks_device(int32_t *xcd_dev, int32_t nblocks, void *hip_stream) {
+    if (!xcd_dev || nblocks <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer or nblocks <= 0");
+    hipLaunchKernelGGL(k_xcd_probe, dim3(unsigned(nblocks)), dim3(kThreads), 0, static_cast<hipStream_t>(hip_stream), xcd_dev);
+    return check_launch("k_xcd_probe");
 }
 
 bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos,

@@ -135,6 +135,10 @@ bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip
 bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32_t seg, int32_t rows_per_wave,
                                    int32_t order, int32_t interleave, int32_t nt, void *hip_stream);
 
+/* Diagnostic: xcd_dev[b] = id (0..7) of the XCD block b of an nblocks-block 1-D launch ran on.  The chunk
+ * kernels assume -- for speed only, never for results -- that blocks b and b + 8 share an XCD. */
+bsq_status bsq_xcd_of_blocks_device(int32_t *xcd_dev, int32_t nblocks, void *hip_stream);
+
 /* ---- BLOSUM62 augmentation (the pre-step of BASELINE config 5): replaces bioseq/blosum.py:36-87.
  * bsq_blosum62_normrows: the 21x20 float64 transition table `normrows` (rows ARNDCQEGHILKMFPSTWYV+X,
  * columns ARNDCQEGHILKMFPSTWYV), bit-identical to the reference's numpy result.
