@@ -1365,7 +1365,9 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     // Occupancy cap through unused dynamic LDS (3 x (16 KiB image + 36 KiB) = 156 KiB <= 160 KiB; 37 KiB already
     // rounds up to 2 per CU).  Rows >= 64 B (one token load per lane and chunk): 3 workgroups per CU stream
     // cfg3 at 7.5-7.8 TB/s, 8 at 6.3, 4 at 6.7, 2 at 5.5.  Smaller rows: no cap -- shapes disagree (1M x 160 x 28 B
-    // wants all 8, 64k x 2048 x 28 B is 6 % faster at 4; profiles/r01/sweep_occupancy2.txt).
+    // wants all 8, 64k x 2048 x 28 B is 6 % faster at 4; profiles/r01/sweep_occupancy2.txt).  12 waves per CU is
+    // the optimum also with 2-wave workgroups (16 / 14 / 12 / 10 waves: 0.83 / 0.81 / 0.76 / 0.93 ms), and 3 x 4 waves
+    // (0.73 ms) beats 6 x 2.
     // Knob "expand_pad": 0 = this rule, > 0 = that many bytes, < 0 = none.
     const int padv = bsq_internal::tuning("expand_pad");
     const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;
@@ -1694,7 +1696,8 @@ bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip
     case 1: hipLaunchKernelGGL((k_fill_blocks<1, false>), dim3(unsigned(blocks)), dim3(kThreads),
                                size_t(bsq_internal::tuning("fill_pad")), s, d4, n16, pattern); break;
     case 2: hipLaunchKernelGGL((k_fill_blocks<4, false>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;
-    case 3: hipLaunchKernelGGL((k_fill_blocks<1, true>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, d4, n16, pattern); break;
+    case 3: hipLaunchKernelGGL((k_fill_blocks<1, true>), dim3(unsigned(blocks)), dim3(kThreads),
+                               size_t(bsq_internal::tuning("fill_pad")), s, d4, n16, pattern); break;
     case 4: hipLaunchKernelGGL((k_fill_blocks<4, true>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;
     default: {
         const unsigned grid = unsigned(blocks > 256 * 16 ? 256 * 16 : blocks);
