@@ -5,10 +5,12 @@
 // right before batch_tokenize / batch_onehot_encode (bioseq/loaders.py:83,102;
 // training/cnnpretrain.py:115-117).  Here it runs in place on the packed batch already in HBM.
 //
-// Algorithm per sequence (same as the reference): with probability `frac` mutate the sequence;
+// Distribution per sequence (the reference's): with probability `frac` mutate the sequence;
 // repeat chain_len times { repeat { idx = uniform position; new = draw from normrows[row(seq[idx])] }
 // until new != seq[idx]; seq[idx] = new }.  Unknown residues (anything outside the 20 letters, incl.
-// lower case) use the 'X' row, as probdict.get(c, default_transitions) does.
+// lower case) use the 'X' row, as probdict.get(c, default_transitions) does.  The kernel samples the same
+// joint distribution in two steps (accept the position with probability 1 - row[old], then draw the new
+// residue from the row without its own entry): see k_augment.
 // The random STREAM is our own (counter-based splitmix64 keyed by seed / sequence / mutation /
 // attempt; the reference uses a module-global numpy PCG64 that also depends on import order), so
 // parity is defined on the table (bit-exact), the invariants and the substitution statistics.
@@ -18,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include "bsq.h"
 #include "bsq_internal.h"
@@ -65,6 +68,7 @@ void make_normrows(double out[kRows * kCols]) {
 
 struct AugTable {
     double cdf[kRows][kCols];  // inclusive prefix sums of normrows (left to right)
+    double self[kRows];        // normrows[r][r]: probability that a draw from row r repeats the residue (row X: 0)
     uint8_t row_of[256];       // byte -> row (20 = 'X' row for everything unknown)
     uint8_t letter[kCols];
 };
@@ -80,8 +84,16 @@ __device__ __forceinline__ uint64_t rnd(uint64_t seed, uint64_t seq, uint64_t i)
 }
 __device__ __forceinline__ double unit(uint64_t x) { return static_cast<double>(x >> 11) * 0x1.0p-53; }
 
-constexpr int kMaxAttempts = 1 << 14;  // rejection loop like the reference's `while inchar == outchar` (an all-W sequence accepts with p = 0.006 per try)
+constexpr int kMaxAttempts = 1 << 14;  // the reference's `while inchar == outchar` is unbounded (an all-W sequence accepts with p = 0.006 per try)
 
+// One mutation = the reference's loop `repeat { idx = choice(L); new = choice(letters, p = row(seq[idx])) } until
+// new != seq[idx]` (bioseq/blosum.py:63-87), sampled in two steps with the same joint distribution: a position is
+// ACCEPTED with probability 1 - row(old)[old] (what the reference's rejection amounts to), and only then is the
+// new residue drawn -- from row(old) without its own entry.  An attempt costs one random word, one character
+// gather and one table lookup instead of two words and a 20-step search; the gathers of kBatch attempts are
+// issued together (attempts are still evaluated strictly in counter order, so results do not depend on kBatch).
+// Random words of thread b: 0 = augment_frac decision; then one per attempt (high bits: position, low 32 bits:
+// acceptance) and one per accepted mutation (the new residue).
 __global__ __launch_bounds__(256) void k_augment(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len,
                                                  double frac, uint64_t seed, const AugTable *tab) {
     __shared__ AugTable s_tab;
@@ -93,24 +105,48 @@ __global__ __launch_bounds__(256) void k_augment(uint8_t *chars, const int64_t *
     const int64_t start = offsets[b];
     const int64_t L = offsets[b + 1] - start;
     if (L <= 0) return;
-    uint64_t ctr = 0;
-    if (frac < 1.0 && !(unit(rnd(seed, b, ctr++)) < frac)) return;  // word 0 decides whether b is augmented
-    ctr = 1;
-    for (int32_t m = 0; m < chain_len; ++m) {
-        for (int a = 0; a < kMaxAttempts; ++a) {
-            const uint64_t r1 = rnd(seed, b, ctr++), r2 = rnd(seed, b, ctr++);
-            const int64_t idx = static_cast<int64_t>(__umul64hi(r1, static_cast<uint64_t>(L)));  // uniform in [0, L)
-            const uint8_t old = chars[start + idx];
-            const double *cdf = s_tab.cdf[s_tab.row_of[old]];
-            const double u = unit(r2) * cdf[kCols - 1];
-            int k = 0;
-            while (k < kCols - 1 && !(u < cdf[k])) ++k;
-            const uint8_t neu = s_tab.letter[k];
-            if (neu != old) {
-                chars[start + idx] = neu;
-                break;
+    if (frac < 1.0 && !(unit(rnd(seed, b, 0)) < frac)) return;  // word 0 decides whether b is augmented
+    uint64_t ctr = 1;
+    // One round of NB attempts: gathers first, then evaluation in counter order.  Returns true once a mutation is made.
+    auto round = [&](auto nb_tag) -> bool {
+        constexpr int NB = decltype(nb_tag)::value;
+        int64_t idx[NB];
+        uint32_t lo[NB];
+        uint8_t old[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const uint64_t r = rnd(seed, b, ctr + j);
+            idx[j] = static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(L)));  // uniform in [0, L)
+            lo[j] = static_cast<uint32_t>(r);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) old[j] = chars[start + idx[j]];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            ctr += 1;
+            const int row = s_tab.row_of[old[j]];
+            const double pself = s_tab.self[row];
+            if (static_cast<double>(lo[j]) * 0x1.0p-32 < 1.0 - pself) {  // position accepted
+                const double *cdf = s_tab.cdf[row];
+                const double u = unit(rnd(seed, b, ctr)) * (cdf[kCols - 1] - pself);
+                ctr += 1;
+                int pick = -1;  // first k != row with u < cdf[k] minus the removed diagonal mass; else the last such k
+                for (int k = 0; k < kCols; ++k) {
+                    if (k == row) continue;
+                    pick = k;
+                    if (u < cdf[k] - (k > row ? pself : 0.0)) break;
+                }
+                chars[start + idx[j]] = s_tab.letter[pick];
+                return true;
             }
         }
+        return false;
+    };
+    // The kernel ends with its unluckiest thread (~30 attempts among 10^5 threads at 30 % acceptance), and every
+    // round is a dependent memory round trip: 4 attempts in the first round, 16 in the later ones.
+    for (int32_t m = 0; m < chain_len; ++m) {
+        bool done = round(std::integral_constant<int, 4>{});
+        for (int a0 = 4; a0 < kMaxAttempts && !done; a0 += 16) done = round(std::integral_constant<int, 16>{});
     }
 }
 
@@ -133,6 +169,7 @@ bsq_status device_table(AugTable **out) {
                 acc += nr[r * kCols + c];
                 h.cdf[r][c] = acc;
             }
+            h.self[r] = r < kCols ? nr[r * kCols + r] : 0.0;
         }
         std::memset(h.row_of, kRows - 1, sizeof(h.row_of));
         for (int c = 0; c < kCols; ++c) {

@@ -59,18 +59,23 @@ def twin(chars, offs, chain_len, frac, seed, normrows):
         ctr = 1
         for _ in range(chain_len):
             for _a in range(1 << 14):
-                r1, r2 = _rnd(seed, b, ctr), _rnd(seed, b, ctr + 1)
-                ctr += 2
-                idx = (r1 * L) >> 64
+                r = _rnd(seed, b, ctr)
+                ctr += 1
+                idx = (r * L) >> 64
                 old = out[start + idx]
-                row = cdf[row_of[old]]
-                u = (r2 >> 11) * 2.0 ** -53 * row[19]
-                k = 0
-                while k < 19 and not (u < row[k]):
-                    k += 1
-                new = ord(LETTERS[k])
-                if new != old:
-                    out[start + idx] = new
+                row = int(row_of[old])
+                pself = float(normrows[row, row]) if row < 20 else 0.0
+                if (r & 0xFFFFFFFF) * 2.0 ** -32 < 1.0 - pself:  # position accepted
+                    u = (_rnd(seed, b, ctr) >> 11) * 2.0 ** -53 * (cdf[row][19] - pself)
+                    ctr += 1
+                    pick = -1
+                    for k in range(20):
+                        if k == row:
+                            continue
+                        pick = k
+                        if u < cdf[row][k] - (pself if k > row else 0.0):
+                            break
+                    out[start + idx] = ord(LETTERS[pick])
                     break
     return out
 
