@@ -19,6 +19,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   chunks_cpw    chunks per wave of k_onehot_chunks (default 1)
 //   tokenize_path 1: never use k_tokenize_chunks / the raw-token kernel for batch_tokenize
 //   tokenize_pad  unused dynamic LDS of k_tokenize_chunks (experiments: no cap helps it)
+//   tokenize_nch  4: software-pipelined four chunks per wave in k_tokenize_chunks (experiments: slower than 1)
 //   onehot_tb     0: automatic, else force 64 / 128 / 256 sequences per tile of k_onehot_tile
 //   tile_order    0: sequence-tile index fastest, 1: position-tile index fastest
 //   fill_mode, fill_pad   access pattern / occupancy of bsq_fill_device (write-bandwidth yardsticks)

@@ -746,11 +746,30 @@ struct __attribute__((packed, aligned(1))) UBytes<2> {
 // consume (the reference gets it with einops.rearrange('length batch emb -> batch emb length') + .float(),
 // bioseq/loaders.py:74): row = b*C + c of the flat (B*C, P) matrix holds (token(b,t) == c) -- the same
 // character-row reader, compared against the row's channel instead of converted to a value.
-template <typename T, bool NT, bool HOT>
+// NCH = chunks per wave, software-pipelined: the offsets of chunk j + 2 and the characters of chunk j + 1 are in
+// flight while chunk j is looked up and stored, so a wave pays the offsets -> characters -> store chain of
+// dependent memory round trips once instead of once per chunk.  Measured: NCH = 4 is slower than 1 (VALU-bound
+// kernel, lower occupancy), so 1 is what runs; 4 stays selectable for experiments.
+template <typename T, bool HOT>
+struct ChunkState {  // one 4-KiB chunk in flight: the lane's four 16-byte stores
+    static constexpr int EPL = 16 / static_cast<int>(sizeof(T));
+    int64_t lo;       // byte offset of the chunk in the output
+    int64_t bc;       // first row of the chunk (wave-uniform)
+    bool valid;       // chunk index < nchunks (wave-uniform)
+    bool live[4];
+    int32_t t0[4], L[4];
+    uint32_t chan[4];
+    int64_t start[4], stop[4];
+    UBytes<EPL> cw[4], mw[4];
+    bool slow[4];
+};
+
+template <typename T, bool NT, bool HOT, int NCH>
 __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     __shared__ __align__(16) uint8_t s_lut4[4][256];
     constexpr int SZ = static_cast<int>(sizeof(T));
     constexpr int EPL = 16 / SZ;  // elements (= characters) per lane per store
+    using State = ChunkState<T, HOT>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint8_t *lut = s_lut4[wave];
     {   // wave-private table: token VALUES (unmapped / >= 0x80 -> 0, the memset value of tokenize.h:427),
@@ -767,58 +786,54 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     }
     const int64_t nrows = HOT ? p.B * p.C : p.B;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // scalar: chunk-level arithmetic stays on the SALU
-    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s);
-    if (k >= p.nchunks) return;
+    // chunks of this wave: class = blockIdx % 8 (pinned to the XCD), NCH consecutive slots of that class
+    const int64_t slot0 = (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s) * NCH;
+    const int64_t k0 = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot0;
+    if (k0 >= p.nchunks) return;
     const int64_t total_chars = p.offsets[p.B];
-    const int64_t lo = k * kChunk;  // chunks are relative to `out` (16-byte aligned on this path)
-    // The lane's four stores: element e0 + u*EPS with e0 = lo/SZ + lane*EPL.  (row, position) of e0 without a
-    // per-lane division: the chunk's first element is wave-uniform (one division, by a reciprocal when the
-    // matrix has < 2^31 elements), the lane's share adds < 1024 positions, the stores advance by (step_q, step_r).
     const uint32_t Pu = static_cast<uint32_t>(p.P);
-    int64_t b0, bc;  // bc: first row of the chunk (wave-uniform)
-    uint32_t t00;
-    {
-        const int64_t ec = lo / SZ;  // first element of the chunk (wave-uniform)
+    const bool has_mask = HOT && p.mask != nullptr;
+    const bool small = nrows * p.P < (int64_t(1) << 31);  // 32-bit element indices: divide by reciprocal
+
+    // stage A: (row, position) of the lane's four stores -- element e0 + u*EPS with e0 = lo/SZ + lane*EPL -- without a
+    // per-lane division (the chunk's first element is wave-uniform, the lane's share adds < 1024 positions, the
+    // stores advance by (step_q, step_r)) -- and the offsets of their sequences (8 independent loads).
+    auto stage_a = [&](State &c, int64_t k) {
+        c.valid = k < p.nchunks;
+        if (!c.valid) return;
+        c.lo = k * kChunk;  // chunks are relative to `out` (16-byte aligned on this path)
+        const int64_t ec = c.lo / SZ;
         uint32_t tc;
-        if (nrows * p.P < (int64_t(1) << 31)) {
+        if (small) {
             const uint32_t q = fast_div(static_cast<uint32_t>(ec), p.magic, p.shift, p.pow2);
-            bc = q;
+            c.bc = q;
             tc = static_cast<uint32_t>(ec) - q * Pu;
         } else {
-            bc = ec / p.P;
-            tc = static_cast<uint32_t>(ec - bc * p.P);
+            c.bc = ec / p.P;
+            tc = static_cast<uint32_t>(ec - c.bc * p.P);
         }
         const uint32_t tl = tc + static_cast<uint32_t>(lane) * EPL;  // < P + 1024
-        const uint32_t q = fast_div(tl, p.magic, p.shift, p.pow2);
-        b0 = bc + q;
-        t00 = tl - q * Pu;
-    }
-    // stage A: row coordinates + offsets of all four stores (unconditional: 8 independent loads in flight)
-    bool live[4];
-    int32_t t0[4];
-    uint32_t chan[4];
-    int64_t start[4], stop[4];
-    {
-        int64_t bu = b0;
-        uint32_t tu = t00;
+        const uint32_t ql = fast_div(tl, p.magic, p.shift, p.pow2);
+        int64_t bu = c.bc + ql;
+        uint32_t tu = tl - ql * Pu;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             int64_t b = bu;  // row of the flat matrix
-            t0[u] = static_cast<int32_t>(tu);
-            live[u] = b < nrows;
-            b = live[u] ? b : nrows - 1;
-            chan[u] = 0;
+            c.t0[u] = static_cast<int32_t>(tu);
+            c.live[u] = b < nrows;
+            b = c.live[u] ? b : nrows - 1;
+            c.chan[u] = 0;
             if constexpr (HOT) {  // row = sequence * C + channel
                 int64_t seq;
                 if (nrows < (int64_t(1) << 31))  // wave-uniform
                     seq = fast_div(static_cast<uint32_t>(b), p.magic_c, p.shift_c, p.pow2_c);
                 else
                     seq = b / p.C;
-                chan[u] = static_cast<uint32_t>(b - seq * p.C);
+                c.chan[u] = static_cast<uint32_t>(b - seq * p.C);
                 b = seq;
             }
-            start[u] = p.offsets[b];
-            stop[u] = p.offsets[b + 1];
+            c.start[u] = p.offsets[b];
+            c.stop[u] = p.offsets[b + 1];
             bu += p.step_q;
             tu += p.step_r;
             if (tu >= Pu) {
@@ -826,115 +841,131 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
                 bu += 1;
             }
         }
-    }
-    // Lengths from the low words (a valid length is < 2^31; anything else is clamped to `room` as before).
-    int32_t L[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t len = static_cast<uint32_t>(stop[u]) - static_cast<uint32_t>(start[u]);
-        L[u] = static_cast<int32_t>(len > static_cast<uint32_t>(p.room) ? static_cast<uint32_t>(p.room) : len);
-    }
-    // stage B: the characters.  Loads are UNCONDITIONAL (lanes that must not touch their own address read
-    // the first bytes of the window instead) so that all four are in flight together.  Addresses are 32-bit
+    };
+
+    // stage B: the characters.  Loads are UNCONDITIONAL (lanes that must not touch their own address read the
+    // first bytes of the window instead) so that all four are in flight together.  Addresses are 32-bit
     // offsets from a wave-uniform base: the rows of a chunk are consecutive sequences, their characters lie
     // within 2^31 bytes of the first one's (off0), so "is [a, a + EPL) inside the buffer" is one unsigned
     // compare of (rel - lo_b) against span, and the load takes the scalar-base + 32-bit-offset form.
-    UBytes<EPL> cw[4];
-    bool slow[4], fast[4];
-    uint32_t uoff[4];
-    int64_t seq0 = bc;
-    if constexpr (HOT) seq0 = (nrows < (int64_t(1) << 31)) ? int64_t(fast_div(static_cast<uint32_t>(bc), p.magic_c, p.shift_c, p.pow2_c)) : bc / p.C;
-    const int64_t off0 = p.offsets[seq0];
-    const int64_t lo_b64 = -off0, hi_b64 = total_chars - off0 - EPL;  // valid range of a vector's first byte, relative to off0
-    const bool can_vec = hi_b64 >= lo_b64;                            // wave-uniform (the buffer holds >= EPL bytes)
-    const int32_t lo_b = lo_b64 < INT32_MIN ? INT32_MIN : static_cast<int32_t>(lo_b64);
-    const int32_t hi_b = hi_b64 > INT32_MAX ? INT32_MAX : (hi_b64 < lo_b ? lo_b : static_cast<int32_t>(hi_b64));
-    const uint32_t span = static_cast<uint32_t>(hi_b) - static_cast<uint32_t>(lo_b);
+    auto stage_b = [&](State &c) {
+        if (!c.valid) return;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int32_t j0 = t0[u] - p.bos;
-        const uint32_t rel = static_cast<uint32_t>(start[u]) - static_cast<uint32_t>(off0) + static_cast<uint32_t>(j0);
-        const uint32_t d = rel - static_cast<uint32_t>(lo_b);  // offset from the lowest valid address
-        const bool need = live[u] && j0 < L[u] && j0 + EPL > 0;
-        fast[u] = can_vec && need && d <= span;
-        slow[u] = need && !fast[u];
-        uoff[u] = fast[u] ? d : 0u;
-    }
-    UBytes<EPL> mw[4];  // mask bytes (one-hot mode with a mask): 0 -> the position is an all-zero row
-    const bool has_mask = HOT && p.mask != nullptr;
-    if (can_vec) {
-        const uint8_t *cbase = p.chars + (off0 + lo_b);  // wave-uniform, inside the buffer
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cw[u] = *reinterpret_cast<const UBytes<EPL> *>(cbase + uoff[u]);
-        if (has_mask) {
-            const uint8_t *mbase = p.mask + (off0 + lo_b);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) mw[u] = *reinterpret_cast<const UBytes<EPL> *>(mbase + uoff[u]);
+        for (int u = 0; u < 4; ++u) {  // lengths from the low words (a valid length is < 2^31; else clamped to `room`)
+            const uint32_t len = static_cast<uint32_t>(c.stop[u]) - static_cast<uint32_t>(c.start[u]);
+            c.L[u] = static_cast<int32_t>(len > static_cast<uint32_t>(p.room) ? static_cast<uint32_t>(p.room) : len);
         }
-    } else {
+        int64_t seq0 = c.bc;
+        if constexpr (HOT)
+            seq0 = (nrows < (int64_t(1) << 31)) ? int64_t(fast_div(static_cast<uint32_t>(c.bc), p.magic_c, p.shift_c, p.pow2_c))
+                                                : c.bc / p.C;
+        const int64_t off0 = p.offsets[seq0];
+        const int64_t lo_b64 = -off0, hi_b64 = total_chars - off0 - EPL;  // valid range of a vector's first byte, relative to off0
+        const bool can_vec = hi_b64 >= lo_b64;                            // wave-uniform (the buffer holds >= EPL bytes)
+        const int32_t lo_b = lo_b64 < INT32_MIN ? INT32_MIN : static_cast<int32_t>(lo_b64);
+        const int32_t hi_b = hi_b64 > INT32_MAX ? INT32_MAX : (hi_b64 < lo_b ? lo_b : static_cast<int32_t>(hi_b64));
+        const uint32_t span = static_cast<uint32_t>(hi_b) - static_cast<uint32_t>(lo_b);
+        uint32_t uoff[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cw[u].clear();
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (slow[u]) {  // first / last bytes of the buffer: never read outside it
-            const int32_t j0 = t0[u] - p.bos;
-            cw[u].clear();
-            if (has_mask) mw[u].clear();
-#pragma unroll
-            for (int i = 0; i < EPL; ++i)
-                if (j0 + i >= 0 && j0 + i < L[u]) {
-                    cw[u].set_byte(i, p.chars[start[u] + j0 + i]);
-                    if (has_mask) mw[u].set_byte(i, p.mask[start[u] + j0 + i]);
-                }
+        for (int u = 0; u < 4; ++u) {
+            const int32_t j0 = c.t0[u] - p.bos;
+            const uint32_t rel = static_cast<uint32_t>(c.start[u]) - static_cast<uint32_t>(off0) + static_cast<uint32_t>(j0);
+            const uint32_t d = rel - static_cast<uint32_t>(lo_b);  // offset from the lowest valid address
+            const bool need = c.live[u] && j0 < c.L[u] && j0 + EPL > 0;
+            const bool fast = can_vec && need && d <= span;
+            c.slow[u] = need && !fast;
+            uoff[u] = fast ? d : 0u;
         }
-    }
-    // stage C: LUT lookups packed 4 (or 2) per word; BOS / EOS / PAD folded in with word masks
+        if (can_vec) {
+            const uint8_t *cbase = p.chars + (off0 + lo_b);  // wave-uniform, inside the buffer
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c.cw[u] = *reinterpret_cast<const UBytes<EPL> *>(cbase + uoff[u]);
+            if (has_mask) {
+                const uint8_t *mbase = p.mask + (off0 + lo_b);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c.mw[u] = *reinterpret_cast<const UBytes<EPL> *>(mbase + uoff[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c.cw[u].clear();
+        }
+    };
+
+    // stage C: the rare byte-wise edge reads, then LUT lookups packed 4 (or 2) per word with BOS / EOS / PAD folded in
+    // as word masks, and the four 16-byte stores.
     constexpr int WB = EPL >= 4 ? 4 : EPL;  // characters per word
     const uint32_t ones = WB == 4 ? 0x01010101u : 0x0101u;
     const uint32_t fill_v = (!HOT && p.fill_id == kNone) ? 0u : p.fill_id;
     const uint32_t at_len_v = (!HOT && p.at_len_id == kNone) ? 0u : p.at_len_id;
     const uint32_t fill_w = fill_v * ones;
     const T hot_one = static_cast<T>(p.one_bits);
+    auto stage_c = [&](State &c) {
+        if (!c.valid) return;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (!live[u]) continue;
-        const int32_t j0 = t0[u] - p.bos;
-        alignas(16) T vals[EPL];
-        uint32_t packed[EPL / WB];
+        for (int u = 0; u < 4; ++u) {
+            if (c.slow[u]) {  // first / last bytes of the buffer: never read outside it
+                const int32_t j0 = c.t0[u] - p.bos;
+                c.cw[u].clear();
+                if (has_mask) c.mw[u].clear();
 #pragma unroll
-        for (int q = 0; q < EPL / WB; ++q) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int i = 0; i < WB; ++i) {
-                uint32_t tk = lut[cw[u].byte(q * WB + i)];
-                if (has_mask && mw[u].byte(q * WB + i) == 0) tk = kNone;
-                w |= tk << (8 * i);
-            }
-            const int32_t jf = j0 + q * WB;  // character index of the word's first byte
-            const int32_t nv = L[u] - jf;    // characters of the sequence left from there
-            if (nv < WB) {
-                const uint32_t m = nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u);
-                w = (w & m) | (fill_w & ~m);
-                if (nv >= 0) w = (w & ~(0xFFu << (8 * nv))) | (at_len_v << (8 * nv));  // position bos+L
-            }
-            if (jf < 0) w = (w & ~0xFFu) | p.bos_id;  // position 0 with BOS
-            packed[q] = w;
-            if constexpr (HOT || SZ != 1) {
-#pragma unroll
-                for (int i = 0; i < WB; ++i) {
-                    const uint32_t tk = (w >> (8 * i)) & 0xFFu;
-                    if constexpr (HOT)
-                        vals[q * WB + i] = tk == chan[u] ? hot_one : T(0);
-                    else
-                        vals[q * WB + i] = static_cast<T>(tk);
-                }
+                for (int i = 0; i < EPL; ++i)
+                    if (j0 + i >= 0 && j0 + i < c.L[u]) {
+                        c.cw[u].set_byte(i, p.chars[c.start[u] + j0 + i]);
+                        if (has_mask) c.mw[u].set_byte(i, p.mask[c.start[u] + j0 + i]);
+                    }
             }
         }
-        if constexpr (!HOT && SZ == 1)  // 8-bit tokens: the packed words ARE the 16 output bytes
-            store16<NT>(p.out + lo + u * 1024 + lane * 16, uint4{packed[0], packed[1], packed[2], packed[3]});
-        else
-            store16<NT>(p.out + lo + u * 1024 + lane * 16, *reinterpret_cast<const uint4 *>(vals));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!c.live[u]) continue;
+            const int32_t j0 = c.t0[u] - p.bos;
+            alignas(16) T vals[EPL];
+            uint32_t packed[EPL / WB];
+#pragma unroll
+            for (int q = 0; q < EPL / WB; ++q) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int i = 0; i < WB; ++i) {
+                    uint32_t tk = lut[c.cw[u].byte(q * WB + i)];
+                    if (has_mask && c.mw[u].byte(q * WB + i) == 0) tk = kNone;
+                    w |= tk << (8 * i);
+                }
+                const int32_t jf = j0 + q * WB;  // character index of the word's first byte
+                const int32_t nv = c.L[u] - jf;  // characters of the sequence left from there
+                if (nv < WB) {
+                    const uint32_t m = nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u);
+                    w = (w & m) | (fill_w & ~m);
+                    if (nv >= 0) w = (w & ~(0xFFu << (8 * nv))) | (at_len_v << (8 * nv));  // position bos+L
+                }
+                if (q == 0 && jf < 0) w = (w & ~0xFFu) | p.bos_id;  // position 0 with BOS (j0 >= -1: only the first word)
+                packed[q] = w;
+                if constexpr (HOT || SZ != 1) {
+#pragma unroll
+                    for (int i = 0; i < WB; ++i) {
+                        const uint32_t tk = (w >> (8 * i)) & 0xFFu;
+                        if constexpr (HOT)
+                            vals[q * WB + i] = tk == c.chan[u] ? hot_one : T(0);
+                        else
+                            vals[q * WB + i] = static_cast<T>(tk);
+                    }
+                }
+            }
+            if constexpr (!HOT && SZ == 1)  // 8-bit tokens: the packed words ARE the 16 output bytes
+                store16<NT>(p.out + c.lo + u * 1024 + lane * 16, uint4{packed[0], packed[1], packed[2], packed[3]});
+            else
+                store16<NT>(p.out + c.lo + u * 1024 + lane * 16, *reinterpret_cast<const uint4 *>(vals));
+        }
+    };
+
+    State st[NCH];
+    stage_a(st[0], k0);
+    if constexpr (NCH > 1) stage_a(st[1], k0 + 8);
+    stage_b(st[0]);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (j + 1 < NCH) stage_b(st[j + 1]);
+        if (j + 2 < NCH) stage_a(st[j + 2], k0 + 8 * (j + 2));
+        stage_c(st[j]);
     }
 }
 
@@ -1451,15 +1482,23 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     div_constants(uint32_t(k.C > 0 ? k.C : 1), &c.magic_c, &c.shift_c, &c.pow2_c);
     c.step_q = (1024u / uint32_t(sizeof(T))) / uint32_t(k.P);
     c.step_r = (1024u / uint32_t(sizeof(T))) % uint32_t(k.P);
-    const int64_t groups = ((c.nchunks + 7) / 8 + 3) / 4;
+    // Chunks per wave: 1.  The software-pipelined 4-chunk form (knob "tokenize_nch" = 4) is 15-20 % SLOWER on cfg2 /
+    // cfg5: the kernel is bound by its ~550 VALU instructions per chunk, not by memory latency, and four chunks
+    // per wave cost occupancy (102 VGPRs).
+    const int nch = bsq_internal::tuning("tokenize_nch") == 4 ? 4 : 1;
+    const int64_t groups = ((c.nchunks + 7) / 8 + int64_t(4) * nch - 1) / (int64_t(4) * nch);
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
     const int padv = bsq_internal::tuning("tokenize_pad");  // unused dynamic LDS = occupancy cap (experiments)
     const size_t pad = padv > 0 ? size_t(padv) : 0;
-    if (bsq_internal::nontemporal_stores())
-        hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT>), grid, dim3(kThreads), pad, s, c);
-    else
-        hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT>), grid, dim3(kThreads), pad, s, c);
+    const bool nt = bsq_internal::nontemporal_stores();
+    if (nch == 4) {
+        if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 4>), grid, dim3(kThreads), pad, s, c);
+        else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 4>), grid, dim3(kThreads), pad, s, c);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 1>), grid, dim3(kThreads), pad, s, c);
+        else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 1>), grid, dim3(kThreads), pad, s, c);
+    }
     return check_launch(HOT ? "k_tokenize_chunks<onehot bcl>" : "k_tokenize_chunks");
 }
 

@@ -68,7 +68,7 @@ int32_t bsq_device_count(void);
 
 /* Tuning / diagnostic knobs (kernel variants for A/B measurements; results never change).
  * Names: "nt_stores", "onehot_tb", "tile_order", "fill_mode", "onehot_path", "expand_pad", "chunks_cpw", "tokenize_path",
- * "chunks_pad", "fill_pad", "tokenize_pad", "expand_slots", "host_copy_threads".  Environment variables
+ * "chunks_pad", "fill_pad", "tokenize_pad", "tokenize_nch", "expand_slots", "host_copy_threads".  Environment variables
  * BSQ_NT_STORES etc. give the initial values. */
 bsq_status bsq_tuning_set(const char *name, int32_t value);
 int32_t bsq_tuning_get(const char *name);
