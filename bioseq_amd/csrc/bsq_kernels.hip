@@ -1518,14 +1518,15 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P) {
         //  2 two-pass   : the fastest streamer once the output is large -- 7.3-7.4 TB/s at 3 workgroups per CU
         //                 when rows are >= 64 B, 6-7 TB/s for smaller rows, any pitch; needs rows >= 16 B and an
         //                 output that amortises the token pass and the second launch;
-        //  3 chunk-owner: one launch, no scratch: ahead below ~2 GiB of output when a row is >= 48 B and its
+        //  3 chunk-owner: one launch, no scratch: ahead below ~4 GiB of output (2.7 GB: 0.383 vs 0.390 ms, 5.4 GB:
+        //                 0.757 vs 0.733) when a row is >= 48 B and its
         //                 per-position gather set stays L2-resident, i.e. the pitch is a multiple of 32 KiB (each
         //                 XCD keeps to its own chunk columns) and B <= 128k, or B <= 16k whatever the pitch;
         //  1 tiled      : the rest (tiny rows such as int8 DNA, small outputs).
         const int64_t rowbytes = C * int64_t(sz), pitch = B * rowbytes, total = pitch * P;
         const bool pinned_columns = pitch % (8 * kChunk) == 0;
         const bool owner_ok = rowbytes >= 48 && ((pinned_columns && B <= 131072) || B <= 16384);
-        if (owner_ok && total < (int64_t(2) << 30))
+        if (owner_ok && total < (int64_t(4) << 30))
             path = 3;
         else if (rowbytes >= 16 && total >= (int64_t(256) << 20))
             path = 2;
