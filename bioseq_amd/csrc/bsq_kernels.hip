@@ -9,14 +9,18 @@
 //
 // What the write side needs on this part (measured): naturally aligned 4-KiB
 // chunks, each XCD writing its own residue class (chunk id % 8 == blockIdx % 8 under round-robin
-// dispatch), one chunk per wave, non-temporal stores.  Speed only -- results never depend on it.
+// dispatch), one chunk per wave, non-temporal stores, about 12 waves resident per CU (occupancy capped with
+// unused LDS) and therefore short instruction streams (reciprocal multiplies instead of integer divisions).
+// Speed only -- results never depend on it.
 //
 // Kernel inventory
-//   k_onehot_chunks    (P,B,C) one-hot, chunk-owner form: a wave gathers the characters of the ~4096/rowbytes
-//                      rows of its chunk (consecutive sequences at one position), LUT from a wave-private
-//                      LDS table, scatters the ones into a 4-KiB LDS image, streams it out.  cfg3: 88 % of HBM peak.
 //   k_tokens_raw +     two-pass (P,B,C) one-hot for any pitch: raw uint8 tokens through tiled, coalesced
 //   k_expand_chunks    character reads into a scratch matrix, then the chunk-wise flat expansion of it.
+//                      Large outputs; cfg3: 92 % of HBM peak (the expansion alone writes at 7.5-7.8 TB/s).
+//   k_onehot_chunks    (P,B,C) one-hot, chunk-owner form, one launch: a wave gathers the characters of the
+//                      ~4096/rowbytes rows of its chunk (consecutive sequences at one position), LUT from a
+//                      wave-private LDS table, scatters the ones into a 4-KiB LDS image, streams it out.
+//                      Outputs below 4 GiB with rows >= 48 B; cfg3 (forced): 89 %.
 //   k_onehot_tile      (P,B,C) one-hot, tiled: workgroup = TB sequences x 64 positions, per-wave LDS row
 //                      images; small rows / small outputs.
 //   k_tokenize_chunks  (B,P) tokens and the channels-first (B,C,P) one-hot: flat chunk stream, a lane owns 16
@@ -26,7 +30,7 @@
 //   k_*_generic        one thread per output element; any shape / alignment / alphabet (BYTES has ids > 255).
 //                      Fallback and in-library cross-check of the fast kernels.
 //   k_fill*, k_fill_pattern   write-bandwidth yardsticks and the store-pattern diagnostics.
-//   k_first_too_long   device-side length validation.
+//   k_first_too_long   device-side length validation.     k_xcd_probe   which XCD each block ran on (diagnostic).
 #include <hip/hip_runtime.h>
 
 #include <climits>
