@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Plain-fill write bandwidth vs resident workgroups per CU (unused dynamic LDS as the occupancy cap), plain and non-temporal stores."""
 import os, sys; sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from bioseq_amd import capi

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Run ON the GPU box (through gpurun): the round-end measurement pass -- GPU suite, rocprofv3 profile of the default bench,
+# bench lines of every workload, shape sweep.  Results land in gpurun_out/; copy what is to be judged into profiles/.
 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
 bash scripts/profile_gpu.sh r01_cfg3_v6 > gpurun_out/prof_v6.log 2>&1
 python bench.py > gpurun_out/bench_final_cfg3.json 2> gpurun_out/bench_final_cfg3.err
