@@ -26,18 +26,24 @@ namespace {
 
 thread_local std::string t_last_error;
 
-// Grow-only staging buffers of one process (per HIP device).  All *_host calls are serialised by
-// g_mu; `busy` marks the point after which the buffers may be reused.
-struct Staging {
-    int device = -1;
+// Grow-only staging buffers of one process (per HIP device).  All *_host calls are serialised by g_mu.
+// The input side is DOUBLE-BUFFERED: two (pinned pack area, device input area, "busy" event) slots used
+// alternately, so the host can gather + pack batch n + 1 while the GPU still copies / encodes batch n
+// (`busy` marks the point after which a slot may be reused).
+struct InSlot {
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     void *d_in = nullptr;  // offsets | chars | mask
     size_t d_in_cap = 0;
-    void *d_out = nullptr;
-    size_t d_out_cap = 0;
     hipEvent_t busy = nullptr;
     bool busy_pending = false;
+};
+struct Staging {
+    int device = -1;
+    InSlot in[2];
+    int next = 0;  // slot the next call packs into
+    void *d_out = nullptr;
+    size_t d_out_cap = 0;
     // device -> pageable host results: ring of pinned bounce slots (see download())
     void *bounce = nullptr;
     hipEvent_t slot_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -50,7 +56,7 @@ std::mutex g_mu;
 
 size_t round_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
 
-bsq_status wait_idle(Staging &s) {
+bsq_status wait_idle(InSlot &s) {
     if (s.busy_pending) {
         const hipError_t e = hipEventSynchronize(s.busy);
         s.busy_pending = false;
@@ -71,8 +77,10 @@ bsq_status current_staging(Staging **out) {
     if (dev < 0 || dev >= kMaxDevices) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "device ordinal out of range");
     Staging &s = g_staging[dev];
     if (s.device < 0) {
-        e = hipEventCreateWithFlags(&s.busy, hipEventDisableTiming);
-        if (e != hipSuccess) return bsq_internal::set_hip_error("hipEventCreate", e);
+        for (InSlot &slot : s.in) {
+            e = hipEventCreateWithFlags(&slot.busy, hipEventDisableTiming);
+            if (e != hipSuccess) return bsq_internal::set_hip_error("hipEventCreate", e);
+        }
         s.device = dev;
     }
     *out = &s;
@@ -97,7 +105,7 @@ bsq_status grow_device(void **buf, size_t *cap, size_t need) {
     return BSQ_OK;
 }
 
-bool in_pinned(const Staging &s, const void *p) {
+bool in_pinned(const InSlot &s, const void *p) {
     const char *c = static_cast<const char *>(p), *b = static_cast<const char *>(s.pinned);
     return b && c >= b && c < b + s.pinned_cap;
 }
@@ -109,7 +117,7 @@ struct DeviceBatch {
 };
 
 // Copy offsets | chars | mask to the device staging buffer on `stream`.
-bsq_status upload(Staging &s, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask, int64_t B,
+bsq_status upload(InSlot &s, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask, int64_t B,
                   hipStream_t stream, DeviceBatch *db) {
     const size_t total = static_cast<size_t>(offsets[B]);
     const size_t off_bytes = round_up(size_t(B + 1) * 8, 256);
@@ -233,14 +241,19 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
     Staging &s = *sp;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (out_bytes == 0 || B == 0) return BSQ_OK;
-    // Wait for the previous call that used the staging buffers -- unless the caller packed this
-    // batch into the pinned scratch itself, in which case bsq_pinned_scratch() already waited.
-    if (!in_pinned(s, offsets)) {
-        st = wait_idle(s);
+    // Input slot: the one the caller packed this batch into (bsq_pinned_scratch() already waited for it), else the
+    // next one in turn -- after waiting for the call that used it two calls ago.
+    InSlot *slot = nullptr;
+    for (InSlot &cand : s.in)
+        if (in_pinned(cand, offsets)) slot = &cand;
+    if (!slot) {
+        slot = &s.in[s.next];
+        s.next ^= 1;
+        st = wait_idle(*slot);
         if (st != BSQ_OK) return st;
     }
     DeviceBatch db;
-    st = upload(s, chars, offsets, mask, B, stream, &db);
+    st = upload(*slot, chars, offsets, mask, B, stream, &db);
     if (st != BSQ_OK) return st;
     void *dev_out = out;
     if (out_space == BSQ_SPACE_HOST) {
@@ -255,9 +268,9 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
         st = download(s, out, dev_out, out_bytes, stream);
         if (st != BSQ_OK) return st;
     } else {
-        e = hipEventRecord(s.busy, stream);
+        e = hipEventRecord(slot->busy, stream);
         if (e != hipSuccess) return bsq_internal::set_hip_error("hipEventRecord", e);
-        s.busy_pending = true;
+        slot->busy_pending = true;
     }
     return BSQ_OK;
 }
@@ -376,7 +389,8 @@ void *bsq_pinned_scratch(size_t nbytes) {
     std::lock_guard<std::mutex> lock(g_mu);
     Staging *sp = nullptr;
     if (current_staging(&sp) != BSQ_OK) return nullptr;
-    Staging &s = *sp;
+    InSlot &s = sp->in[sp->next];  // the slots alternate: the previous batch may still be in flight in the other one
+    sp->next ^= 1;
     if (wait_idle(s) != BSQ_OK) return nullptr;
     if (nbytes > s.pinned_cap) {
         if (s.pinned) (void)hipHostFree(s.pinned);
@@ -400,14 +414,16 @@ void bsq_release_staging(void) {
         int prev = 0;
         (void)hipGetDevice(&prev);
         (void)hipSetDevice(s.device);
-        if (s.busy_pending) (void)hipEventSynchronize(s.busy);
-        if (s.pinned) (void)hipHostFree(s.pinned);
-        if (s.d_in) (void)hipFree(s.d_in);
+        for (InSlot &slot : s.in) {
+            if (slot.busy_pending) (void)hipEventSynchronize(slot.busy);
+            if (slot.pinned) (void)hipHostFree(slot.pinned);
+            if (slot.d_in) (void)hipFree(slot.d_in);
+            if (slot.busy) (void)hipEventDestroy(slot.busy);
+        }
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.bounce) (void)hipHostFree(s.bounce);
         for (hipEvent_t ev : s.slot_done)
             if (ev) (void)hipEventDestroy(ev);
-        if (s.busy) (void)hipEventDestroy(s.busy);
         (void)hipSetDevice(prev);
         s = Staging();
     }

@@ -166,8 +166,10 @@ bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const in
                                const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                                bsq_space out_space, void *hip_stream, int64_t *first_bad);
 
-/* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer):
- * returns a buffer of at least nbytes that stays valid until the next call on this thread. */
+/* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer): returns a buffer of
+ * at least nbytes; pack offsets | chars | mask into it and hand those pointers to the next bsq_*_host call.
+ * Two buffers alternate (the call waits until the batch packed two calls ago has left the GPU), so packing
+ * batch n + 1 overlaps the copy + encode of batch n; a buffer stays valid until the call after next. */
 void *bsq_pinned_scratch(size_t nbytes);
 /* Free every cached staging buffer of the calling process (tests, shutdown). */
 void bsq_release_staging(void);

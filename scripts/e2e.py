@@ -28,6 +28,17 @@ print("onehot packed numpy -> device tensor            : %.2f ms" % t(lambda: to
 dch, dof = torch.from_numpy(chars).cuda(), torch.from_numpy(offs).cuda()
 print("onehot packed device -> device tensor (alloc+kernel): %.2f ms" % t(lambda: tok.onehot_packed(dch, dof, P, "f")))
 print("onehot packed device, validate=False            : %.2f ms" % t(lambda: tok.onehot_packed(dch, dof, P, "f", validate=False)))
+def pipelined(fn, n=20):
+    """n calls back to back, one sync at the end: what a training loop sees (host packing of batch i+1 overlaps the GPU work of batch i)."""
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = fn(); del r  # the caching allocator hands the same block to the next call (stream-ordered reuse)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+for nt in (1, 8):
+    print("onehot list[bytes] -> device tensor, nthreads=%d, 20 calls pipelined: %.2f ms per batch" % (nt, pipelined(lambda: tok.batch_onehot_encode(seqs, padlen=P, destchar="f", nthreads=nt, device="cuda"))))
+print("tokens list[bytes] -> device tensor, nthreads=8, 20 calls pipelined: %.2f ms per batch" % pipelined(lambda: tok.batch_tokenize(seqs, padlen=P, batch_first=True, nthreads=8, device="cuda")))
 from bioseq_amd import capi
 lib = capi.load()
 for nt in (1, 2, 4, 8, 16, 32):
