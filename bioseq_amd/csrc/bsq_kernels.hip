@@ -901,7 +901,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     const uint32_t ones = WB == 4 ? 0x01010101u : 0x0101u;
     const uint32_t fill_v = (!HOT && p.fill_id == kNone) ? 0u : p.fill_id;
     const uint32_t at_len_v = (!HOT && p.at_len_id == kNone) ? 0u : p.at_len_id;
-    const uint32_t fill_w = fill_v * ones;
+    const uint32_t fill_w = fill_v * ones, at_len_w = at_len_v * ones;
     const T hot_one = static_cast<T>(p.one_bits);
     auto stage_c = [&](State &c) {
         if (!c.valid) return;
@@ -936,11 +936,13 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
                 }
                 const int32_t jf = j0 + q * WB;  // character index of the word's first byte
                 const int32_t nv = c.L[u] - jf;  // characters of the sequence left from there
-                if (nv < WB) {
-                    const uint32_t m = nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u);
-                    w = (w & m) | (fill_w & ~m);
-                    if (nv >= 0) w = (w & ~(0xFFu << (8 * nv))) | (at_len_v << (8 * nv));  // position bos+L
-                }
+                // Branch-free (nearly every wave holds a lane that straddles or lies beyond L): the first nvc bytes stay,
+                // the rest is fill, byte nv (if it is one of this word's) is the token at position bos + L.
+                const int32_t nvc = nv < 0 ? 0 : (nv > WB ? WB : nv);
+                const uint32_t keep = static_cast<uint32_t>(uint64_t(1) << (8 * nvc)) - 1u;  // low nvc bytes (nvc = 4: all)
+                w = (w & keep) | (fill_w & ~keep);
+                const uint32_t at = static_cast<uint32_t>(nv) < static_cast<uint32_t>(WB) ? (0xFFu << (8 * nvc)) : 0u;
+                w = (w & ~at) | (at_len_w & at);
                 if (q == 0 && jf < 0) w = (w & ~0xFFu) | p.bos_id;  // position 0 with BOS (j0 >= -1: only the first word)
                 packed[q] = w;
                 if constexpr (HOT || SZ != 1) {
