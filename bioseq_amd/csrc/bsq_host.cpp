@@ -42,6 +42,8 @@ struct Staging {
     int device = -1;
     InSlot in[2];
     int next = 0;  // slot the next call packs into
+    hipStream_t copy_stream = nullptr;  // uploads run here, so that H2D of batch n + 1 overlaps the encode of batch n
+    hipEvent_t uploaded = nullptr;
     void *d_out = nullptr;
     size_t d_out_cap = 0;
     // device -> pageable host results: ring of pinned bounce slots (see download())
@@ -81,6 +83,9 @@ bsq_status current_staging(Staging **out) {
             e = hipEventCreateWithFlags(&slot.busy, hipEventDisableTiming);
             if (e != hipSuccess) return bsq_internal::set_hip_error("hipEventCreate", e);
         }
+        e = hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("copy stream", e);
         s.device = dev;
     }
     *out = &s;
@@ -252,9 +257,14 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
         st = wait_idle(*slot);
         if (st != BSQ_OK) return st;
     }
+    // Upload on the copy stream (the slot is idle: waited for above or in bsq_pinned_scratch), then make the
+    // caller's stream wait for it: the copy overlaps whatever that stream is still running (the previous encode).
     DeviceBatch db;
-    st = upload(*slot, chars, offsets, mask, B, stream, &db);
+    st = upload(*slot, chars, offsets, mask, B, s.copy_stream, &db);
     if (st != BSQ_OK) return st;
+    hipError_t eu = hipEventRecord(s.uploaded, s.copy_stream);
+    if (eu == hipSuccess) eu = hipStreamWaitEvent(stream, s.uploaded, 0);
+    if (eu != hipSuccess) return bsq_internal::set_hip_error("upload -> encode dependency", eu);
     void *dev_out = out;
     if (out_space == BSQ_SPACE_HOST) {
         st = grow_device(&s.d_out, &s.d_out_cap, out_bytes);
@@ -420,6 +430,8 @@ void bsq_release_staging(void) {
             if (slot.d_in) (void)hipFree(slot.d_in);
             if (slot.busy) (void)hipEventDestroy(slot.busy);
         }
+        if (s.copy_stream) (void)hipStreamDestroy(s.copy_stream);
+        if (s.uploaded) (void)hipEventDestroy(s.uploaded);
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.bounce) (void)hipHostFree(s.bounce);
         for (hipEvent_t ev : s.slot_done)

@@ -16,6 +16,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <sstream>
@@ -75,15 +78,35 @@ struct Gathered {
     bool has_mask = false;
 };
 
+// Pointer + length of the three item types whose bytes can be read without calling into the interpreter:
+// bytes, bytearray and compact-ASCII str (UTF-8 == the stored bytes).  Reads object memory only, so worker
+// threads may run it while the calling thread holds the GIL (nothing can mutate or free the items meanwhile).
+inline bool fast_item(PyObject *o, Item *it) {
+    if (PyBytes_CheckExact(o)) {
+        *it = {PyBytes_AS_STRING(o), size_t(PyBytes_GET_SIZE(o))};
+        return true;
+    }
+    if (PyUnicode_CheckExact(o) && PyUnicode_IS_READY(o) && PyUnicode_IS_COMPACT_ASCII(o)) {
+        *it = {reinterpret_cast<const char *>(PyUnicode_1BYTE_DATA(o)), size_t(PyUnicode_GET_LENGTH(o))};
+        return true;
+    }
+    if (PyByteArray_CheckExact(o)) {
+        *it = {PyByteArray_AS_STRING(o), size_t(PyByteArray_GET_SIZE(o))};
+        return true;
+    }
+    return false;
+}
+
 // Item acceptance of tokenize.h:292-322 / :389-419.  (The reference means to accept 8-bit numpy
 // arrays too but falls through to its error label; they are accepted here.)
-void gather(py::sequence batch, const py::object &mask, Gathered &g) {
+// Large batches without a mask list are first scanned by `nthreads` workers (the scan is bound by the cache
+// misses on 64k object headers); whatever is not a plain bytes / bytearray / ASCII str is left to the serial pass.
+void gather(py::sequence batch, const py::object &mask, Gathered &g, int nthreads = 1) {
     py::object fast = py::reinterpret_steal<py::object>(PySequence_Fast(batch.ptr(), "batch must be a sequence"));
     if (!fast) throw py::error_already_set();
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast.ptr());
     PyObject **objs = PySequence_Fast_ITEMS(fast.ptr());
     g.keep.push_back(fast);
-    g.items.reserve(size_t(n));
     const bool mask_is_list = py::isinstance<py::list>(mask);  // anything else is ignored (tokenize.h:294)
     py::list mlist;
     if (mask_is_list) {
@@ -91,7 +114,30 @@ void gather(py::sequence batch, const py::object &mask, Gathered &g) {
         g.masks.reserve(size_t(n));
         g.has_mask = true;
     }
+    std::vector<uint8_t> resolved;
+    if (!mask_is_list && nthreads > 1 && n >= 8192) {
+        g.items.assign(size_t(n), Item{nullptr, 0});
+        resolved.assign(size_t(n), 0);
+        std::vector<size_t> part(size_t(nthreads), 0);
+        auto scan = [&](int t) {
+            size_t sum = 0;
+            for (Py_ssize_t i = n * t / nthreads, e = n * (t + 1) / nthreads; i < e; ++i)
+                if (fast_item(objs[i], &g.items[size_t(i)])) {
+                    resolved[size_t(i)] = 1;
+                    sum += g.items[size_t(i)].len;
+                }
+            part[size_t(t)] = sum;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(scan, t);
+        scan(0);
+        for (auto &x : th) x.join();
+        for (size_t v : part) g.total += v;
+    } else {
+        g.items.reserve(size_t(n));
+    }
     for (Py_ssize_t i = 0; i < n; ++i) {
+        if (!resolved.empty() && resolved[size_t(i)]) continue;
         PyObject *o = objs[i];
         Item it{nullptr, 0};
         if (PyUnicode_Check(o)) {
@@ -130,7 +176,10 @@ void gather(py::sequence batch, const py::object &mask, Gathered &g) {
             g.masks.push_back(mp);
         }
         g.total += it.len;
-        g.items.push_back(it);
+        if (resolved.empty())
+            g.items.push_back(it);
+        else
+            g.items[size_t(i)] = it;
     }
 }
 
@@ -319,7 +368,7 @@ class Tokenizer {
         check_padlen(padlen);
         if (nthreads <= 0) nthreads = 1;
         Gathered g;
-        gather(batch, py::none(), g);
+        gather(batch, py::none(), g, nthreads);
         PackLock lock;
         OutBuf out;  // first: it makes `device=` the current device, so the pinned scratch and the staging
                      // buffers used by pack() and by the encode call belong to the same device
@@ -351,19 +400,30 @@ class Tokenizer {
         const bsq_dtype t = parse_dtype(dt);
         check_padlen(padlen);
         if (nthreads <= 0) nthreads = 1;
+        static const bool prof = std::getenv("BSQ_PROFILE_HOST") != nullptr;  // per-phase host times on stderr
+        const auto t0 = std::chrono::steady_clock::now();
         Gathered g;
-        gather(batch, mask, g);
+        gather(batch, mask, g, nthreads);
+        const auto t1 = std::chrono::steady_clock::now();
         PackLock lock;
         OutBuf out;  // before pack(): see batch_tokenize
         const py::ssize_t C = py::ssize_t(bsq_alphabet_size(&desc)), nb = py::ssize_t(g.items.size());
         make_out(out, bcl ? std::vector<py::ssize_t>{nb, C, padlen} : std::vector<py::ssize_t>{padlen, nb, C}, t, device);
+        const auto t2 = std::chrono::steady_clock::now();
         const Packed p = pack(g, nthreads);
+        const auto t3 = std::chrono::steady_clock::now();
         int64_t bad = -1;
         bsq_status st;
         {
             py::gil_scoped_release nogil;
             st = (bcl ? bsq_onehot_bcl_host : bsq_onehot_host)(&desc, p.chars, p.offsets, p.mask, p.B, padlen, t, out.ptr,
                                                                out.space, out.stream, &bad);
+        }
+        if (prof) {
+            const auto t4 = std::chrono::steady_clock::now();
+            auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+            std::fprintf(stderr, "[bsq host] gather %ld us, output alloc %ld us, pack %ld us, upload+launch %ld us\n", us(t0, t1),
+                         us(t1, t2), us(t2, t3), us(t3, t4));
         }
         if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(p.offsets, bad, padlen);
         if (st != BSQ_OK) throw_status(st);
