@@ -134,3 +134,21 @@ def test_no_gpu_means_loud_failure(bsq):
         tok.batch_onehot_encode(["ACGT"], padlen=8)
     with pytest.raises(RuntimeError, match="no HIP device"):
         tok.onehot_packed(np.frombuffer(b"ACGT", dtype=np.uint8), np.array([0, 4]), 8, "f")
+
+
+def test_parallel_item_scan_runs_before_the_device_is_needed(bsq):
+    """>= 8192 items with nthreads > 1: the worker-thread scan of the items (and the serial pass over the item types it
+    leaves alone) happens before any device call -- a bad item is reported as such, a good batch then fails loudly
+    for want of a GPU (CPU runs of this test also put the scan under the sanitizers, scripts/asan_host.sh)."""
+    tok = bsq.pbeos_tokenizers["DNA"]
+    items = []
+    for i in range(9000):
+        s = "ACGT" * (i % 7)
+        items.append([s, s.encode(), bytearray(s.encode()), np.frombuffer(s.encode(), dtype=np.uint8), s + "é"][i % 5])
+    with pytest.raises(ValueError, match="none of string"):
+        tok.batch_tokenize(items[:8999] + [None], padlen=40, nthreads=4)
+    with pytest.raises(ValueError, match="none of string"):
+        tok.batch_onehot_encode(items[:100] + [1.5] + items[100:], padlen=40, nthreads=8)
+    if bsq.device_count() == 0:
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            tok.batch_tokenize(items, padlen=40, nthreads=4)
