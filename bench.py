@@ -259,6 +259,25 @@ def main():
                        "gb_per_s_into_each_rank": out_bytes * (world - 1) / (float(gt.item()) * 1e-3) / 1e9,
                        "what": "all_gather of every rank's shard into a staging list + concatenation along the batch axis "
                                "(whole batch on every rank); encode time excluded"}
+        if op == "onehot" and backend == "nccl":
+            # the xGMI-friendly form: only the uint8 token matrices travel, every rank expands the whole batch itself
+            import bioseq_amd as _pkg
+            tokz = _pkg.Tokenizer(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
+            raw_tokens, expand = sharding.device_passes(tokz, P, destchar, dev)
+            tms = []
+            for _ in range(args.gather + 1):
+                barrier()
+                g0 = time.perf_counter()
+                full = expand(sharding.gather_tokens(raw_tokens(d_chars, d_offs), n * world, False).contiguous())
+                barrier()
+                tms.append((time.perf_counter() - g0) * 1e3)
+                assert tuple(full.shape) == (P, n * world, C)
+                del full
+            tt = torch.tensor([float(np.mean(tms[1:]))], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            gather_info["via_tokens_ms"] = float(tt.item())
+            gather_info["via_tokens_what"] = ("token pass on the shard + all_gather of the (P, B_g) uint8 token matrices (%d bytes "
+                                              "received per rank) + local expansion of the whole batch" % (P * n * (world - 1)))
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
     tot_t = torch.tensor([float(total), float(out_bytes)], dtype=torch.float64, device=red_dev)

@@ -1420,32 +1420,36 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
 int64_t two_pass_pitch(int64_t B) { return (B + kRawTB - 1) / kRawTB * kRawTB; }
 size_t two_pass_workspace_bytes(int64_t B, int64_t P) { return size_t(two_pass_pitch(B)) * size_t(P); }
 
-bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s) {
-    void *out = k.out;
-    k.out = workspace;
-    k.out_pitch = two_pass_pitch(k.B);  // padded: every scratch row is aligned, full-width vector stores
-    k.aligned = reinterpret_cast<uintptr_t>(workspace) % 16 == 0;
+// Pass 1: raw tokens (kNone = no token) of the batch into a (P, pitch) uint8 matrix.
+bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_t s) {
+    k.out = tokens;
+    k.out_pitch = pitch;
+    k.aligned = reinterpret_cast<uintptr_t>(tokens) % 16 == 0 && pitch % 16 == 0;  // every row starts 16-byte aligned
     k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
     const dim3 grid(unsigned(int64_t(k.ntb) * k.ntt));
     if (k.mask)
         hipLaunchKernelGGL(k_tokens_raw<true>, grid, dim3(kThreads), 0, s, k);
     else
         hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
-    bsq_status st = check_launch("k_tokens_raw");
-    if (st != BSQ_OK) return st;
+    return check_launch("k_tokens_raw");
+}
+
+// Pass 2: the (P, B, C) one-hot as the flat expansion of a (P, pitch) raw token matrix.
+bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int64_t P, int32_t C, size_t sz,
+                            uint64_t one_bits, void *out, hipStream_t s) {
     EParams e;
-    e.tok = static_cast<const uint8_t *>(workspace);
-    e.B = k.B;
-    e.Bp = k.out_pitch;
+    e.tok = tokens;
+    e.B = B;
+    e.Bp = pitch;
     e.out = static_cast<uint8_t *>(out);
-    e.total = k.P * k.B * k.C * int64_t(sz);
+    e.total = P * B * C * int64_t(sz);
     e.head = int32_t(reinterpret_cast<uintptr_t>(out) & (kChunk - 1));
     e.nchunks = (e.head + e.total + kChunk - 1) / kChunk;
-    e.C = k.C;
-    e.one_bits = k.one_bits;
-    e.inv_rowbytes = 1.0 / double(k.C * int64_t(sz));
-    e.inv_B = 1.0 / double(k.B);
-    div_constants(uint32_t(k.C * int64_t(sz)), &e.rb_magic, &e.rb_shift, &e.rb_pow2);
+    e.C = C;
+    e.one_bits = one_bits;
+    e.inv_rowbytes = 1.0 / double(C * int64_t(sz));
+    e.inv_B = 1.0 / double(B);
+    div_constants(uint32_t(C * int64_t(sz)), &e.rb_magic, &e.rb_shift, &e.rb_pow2);
     e.force4 = bsq_internal::tuning("expand_slots") == 4;
     switch (sz) {
     case 1: return launch_expand<uint8_t>(e, s);
@@ -1453,6 +1457,14 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
     case 4: return launch_expand<uint32_t>(e, s);
     default: return launch_expand<uint64_t>(e, s);
     }
+}
+
+bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s) {
+    void *out = k.out;
+    const int64_t pitch = two_pass_pitch(k.B);  // padded: every scratch row is aligned, full-width vector stores
+    const bsq_status st = launch_tokens_raw(k, workspace, pitch, s);
+    if (st != BSQ_OK) return st;
+    return launch_expansion(static_cast<const uint8_t *>(workspace), pitch, k.B, k.P, k.C, sz, k.one_bits, out, s);
 }
 
 template <typename T, int TB>
@@ -1587,6 +1599,30 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     case 4: return dispatch_onehot_tile<uint32_t>(k, s);
     default: return dispatch_onehot_tile<uint64_t>(k, s);
     }
+}
+
+bsq_status bsq_raw_tokens_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                 const uint8_t *mask_or_null, int64_t B, int64_t P, uint8_t *tokens, int64_t pitch,
+                                 void *hip_stream) {
+    KParams k;
+    bsq_status st = fill_common(k, d, chars, offsets, mask_or_null, B, P, tokens);
+    if (st != BSQ_OK) return st;
+    if (pitch < B) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "pitch < B");
+    if (B == 0) return BSQ_OK;
+    if (k.C > 250 || P > kMaxTiledP || B >= (int64_t(1) << 31) - 256 || ((B + kRawTB - 1) / kRawTB) * k.ntt >= (int64_t(1) << 31))
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "raw tokens need ids < 251, padlen <= 2^22 and < 2^31 tiles");
+    return launch_tokens_raw(k, tokens, pitch, static_cast<hipStream_t>(hip_stream));
+}
+
+bsq_status bsq_onehot_from_raw_tokens_device(const uint8_t *tokens, int64_t pitch, int64_t B, int64_t P, int32_t C,
+                                             bsq_dtype t, void *out, void *hip_stream) {
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    if (!tokens || !out || B < 0 || P <= 0 || C <= 0 || C > 250 || pitch < B)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, bad shape or pitch < B");
+    if (B == 0) return BSQ_OK;
+    if (reinterpret_cast<uintptr_t>(out) % sz) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output is not aligned to its element size");
+    return launch_expansion(tokens, pitch, B, P, C, sz, one_bits_of(t), out, static_cast<hipStream_t>(hip_stream));
 }
 
 bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B,

@@ -13,6 +13,12 @@ Whole-batch assembly:
     shards are all-gathered into per-rank staging slabs and concatenated along the batch axis
     (one extra read+write of the tensor on the receiver; SURVEY.md section 8e option 2).
 Ragged shard counts (B % world != 0) are padded to the largest shard for the collective and trimmed.
+
+`onehot_gathered` is the xGMI-friendly form of the whole-batch one-hot: the shards that travel are the raw
+uint8 TOKEN matrices (P, B_g) -- 1/(C*sizeof(T)) of the one-hot's bytes, 1/80 at cfg3 -- and every rank expands
+the assembled (P, B) token matrix into the (P, B, C) tensor locally at HBM speed (the second pass of the
+library's own two-pass kernel, `bsq_onehot_from_raw_tokens_device`).  Gathering the 5.4 GB f32 one-hot of cfg3
+from 8 ranks is link-bound (>= 4.4 ms at 153 GB/s per xGMI link); its tokens are 67 MB.
 """
 from __future__ import annotations
 
@@ -94,6 +100,57 @@ def gather_tokens(local, B: int, batch_first: bool, group=None):
 def gather_onehot(local, B: int, group=None):
     """Whole-batch (P, B, C) one-hot on every rank from per-rank (P, B_g, C) shards."""
     return _gather(local, 1, B, group)
+
+
+def onehot_gathered(raw_tokens: Callable, expand: Callable, chars, offsets, group=None):
+    """Whole-batch (P, B, C) one-hot on every rank, moving only token matrices between ranks.
+
+    raw_tokens(chars_shard, offsets_shard) -> (P, B_g) uint8 torch tensor of raw ids (255 = all-zero row);
+    expand(tokens (P, B)) -> the (P, B, C) one-hot.  `device_passes` builds both from a Tokenizer.
+    """
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = int(offsets.shape[0]) - 1
+    c, o = shard_packed(chars, offsets, world, rank)
+    return expand(gather_tokens(raw_tokens(c, o), B, False, group).contiguous())
+
+
+def device_passes(tokenizer, padlen: int, destchar: str, device):
+    """(raw_tokens, expand) for `onehot_gathered`, running the library's two passes on `device` through the C ABI."""
+    import ctypes
+
+    import torch
+
+    from . import capi
+    lib = capi.load()
+    desc = capi.make_desc(tokenizer.key, tokenizer.includes_eos(), tokenizer.includes_bos(), tokenizer.is_padded())
+    C = int(tokenizer.alphabet_size())
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt)))
+    tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt.value]
+    dev = torch.device(device)
+
+    def raw_tokens(chars, offsets):
+        ch = torch.as_tensor(chars).to(dev)
+        of = torch.as_tensor(offsets).to(dev).to(torch.int64).contiguous()
+        Bg = int(of.shape[0]) - 1
+        out = torch.empty((padlen, Bg), dtype=torch.uint8, device=dev)
+        if Bg == 0:
+            return out
+        with torch.cuda.device(dev):
+            capi.check(lib.bsq_raw_tokens_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), None, Bg, padlen,
+                                                 out.data_ptr(), Bg, torch.cuda.current_stream().cuda_stream))
+        return out
+
+    def expand(tokens):
+        P, B = int(tokens.shape[0]), int(tokens.shape[1])
+        out = torch.empty((P, B, C), dtype=tdt, device=tokens.device)
+        with torch.cuda.device(tokens.device):
+            capi.check(lib.bsq_onehot_from_raw_tokens_device(tokens.data_ptr(), B, B, P, C, dt, out.data_ptr(),
+                                                             torch.cuda.current_stream().cuda_stream))
+        return out
+
+    return raw_tokens, expand
 
 
 def encode_sharded(encode: Callable, chars, offsets, gather: Optional[str] = None, group=None):

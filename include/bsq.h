@@ -135,6 +135,21 @@ bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip
 bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32_t seg, int32_t rows_per_wave,
                                    int32_t order, int32_t interleave, int32_t nt, void *hip_stream);
 
+/* The two passes of the large-output one-hot path on their own (distributed assembly: ship the small token
+ * matrices over xGMI and expand at the destination -- 1/(C*sizeof(T)) of the one-hot's bytes, e.g. 1/80 at cfg3):
+ * bsq_raw_tokens_device       -> tokens[t * pitch + b] = id at position t of sequence b (tokenize.h:342-369
+ *                                semantics incl. BOS/EOS/PAD/mask), BSQ_NO_TOKEN where the one-hot row is all zero;
+ *                                pitch >= B (a multiple of 16 and a 16-byte aligned base make the stores vectorised;
+ *                                columns B..pitch-1 of every row are scratch and may be overwritten);
+ * bsq_onehot_from_raw_tokens_device -> out[(t*B + b)*C + c] = (tokens[t*pitch + b] == c), every element written once.
+ * Together they equal bsq_onehot_device.  Limits: ids < 251 (not BYTES), padlen <= 2^22. */
+#define BSQ_NO_TOKEN 255
+bsq_status bsq_raw_tokens_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                 const uint8_t *mask_or_null, int64_t B, int64_t P, uint8_t *tokens, int64_t pitch,
+                                 void *hip_stream);
+bsq_status bsq_onehot_from_raw_tokens_device(const uint8_t *tokens, int64_t pitch, int64_t B, int64_t P, int32_t C,
+                                             bsq_dtype t, void *out, void *hip_stream);
+
 /* Diagnostic: xcd_dev[b] = id (0..7) of the XCD block b of an nblocks-block 1-D launch ran on.  The chunk
  * kernels assume -- for speed only, never for results -- that blocks b and b + 8 share an XCD. */
 bsq_status bsq_xcd_of_blocks_device(int32_t *xcd_dev, int32_t nblocks, void *hip_stream);

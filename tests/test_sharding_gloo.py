@@ -53,9 +53,23 @@ def _worker(rank, world, port, B, P, q):
         bf = sharding.encode_sharded(lambda c, o: tok.tokenize_packed(c, o, P, "B", True), chars, offs, gather="tokens_bf")
         sf = sharding.encode_sharded(lambda c, o: tok.tokenize_packed(c, o, P, "i", False), chars, offs, gather="tokens_sf")
         keep = sharding.encode_sharded(lambda c, o: tok.onehot_packed(c, o, P, "f"), chars, offs)
+
+        # token-gather assembly (onehot_gathered) with CPU stand-ins for the two device passes
+        def raw_tokens(c, o):
+            oh_ = tok.onehot_packed(c, o, P, "b")
+            ids = oh_.argmax(axis=2).astype(np.uint8)
+            ids[oh_.sum(axis=2) == 0] = 255
+            return torch.from_numpy(ids)
+
+        def expand(tokens):
+            t_ = tokens.numpy()
+            return torch.from_numpy((t_[:, :, None] == np.arange(full_oh.shape[2], dtype=np.uint8)[None, None, :]).astype(np.float32))
+
+        via_tokens = sharding.onehot_gathered(raw_tokens, expand, chars, offs)
         b0, b1 = sharding.shard_bounds(B, world, rank)
         ok = (oh.numpy().tobytes() == full_oh.tobytes() and bf.numpy().tobytes() == full_bf.tobytes()
               and sf.numpy().tobytes() == full_sf.tobytes()
+              and via_tokens.numpy().tobytes() == full_oh.tobytes()
               and keep.tobytes() == np.ascontiguousarray(full_oh[:, b0:b1]).tobytes())
         # bench.py-style timing reduction: MAX over ranks
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
