@@ -58,18 +58,18 @@ def onehot_encode(tokenizer, seqbatch, padlen=-1, destchar='B', batch_first=Fals
     (the reference encodes on the host and copies, ``__init__.py:61-65``).
     """
     on_device = to_pytorch and _is_hip_device(device)
-    if isinstance(seqbatch, (str, bytes)):
-        res = tokenizer.onehot_encode(seqbatch, padlen, destchar)
+    single = isinstance(seqbatch, (str, bytes))
+    if single:
+        encoded = tokenizer.onehot_encode(seqbatch, padlen, destchar)
     else:
-        res = tokenizer.batch_onehot_encode(seqbatch, padlen, destchar, device=device if on_device else None)
-        if batch_first:
-            res = res.permute(1, 0, 2) if on_device else res.transpose(1, 0, 2)  # 'seq batch base -> batch seq base'
-    if to_pytorch and not on_device:
-        from torch import from_numpy
-        res = from_numpy(res)
-        if device is not None:
-            res = res.to(device)
-    return res
+        encoded = tokenizer.batch_onehot_encode(seqbatch, padlen, destchar, device=device if on_device else None)
+        if batch_first:  # 'seq batch base -> batch seq base', a strided view like the reference's einops.rearrange
+            encoded = encoded.permute(1, 0, 2) if on_device else encoded.transpose(1, 0, 2)
+    if on_device or not to_pytorch:
+        return encoded
+    import torch
+    tensor = torch.from_numpy(encoded)
+    return tensor if device is None else tensor.to(device)
 
 
 def f_encode(seqbatch, key="DNA", bos=False, eos=False, padchar=False, padlen=-1, destchar='B', batch_first=False,
@@ -95,18 +95,14 @@ Reduced14Tokenizer = Tokenizer("SEB14")
 DayhoffTokenizer = Tokenizer("DAYHOFF")
 LIATokenizer = Tokenizer("LIA10")
 LIBTokenizer = Tokenizer("LIB10")
-default_tokenizers = {"DNA": DNATokenizer,
-                      "AMINO20": AmineTokenizer,
-                      "AMINE": AmineTokenizer,
-                      "PROTEIN": AmineTokenizer,
-                      "SEB6": Reduced6Tokenizer,
-                      "SEB8": Reduced8Tokenizer,
-                      "SEB10": Reduced10Tokenizer,
-                      "SEB14": Reduced14Tokenizer,
-                      "LIA10": LIATokenizer,
-                      "LIA": LIATokenizer,
-                      "LIB10": LIBTokenizer,
-                      "LIB": LIBTokenizer}
+# name -> shared plain tokenizer (no BOS / EOS / PAD); several names alias one alphabet, as in the reference
+default_tokenizers = {}
+for _names, _tok in ((("DNA",), DNATokenizer), (("AMINO20", "AMINE", "PROTEIN"), AmineTokenizer),
+                     (("SEB6",), Reduced6Tokenizer), (("SEB8",), Reduced8Tokenizer), (("SEB10",), Reduced10Tokenizer),
+                     (("SEB14",), Reduced14Tokenizer), (("LIA10", "LIA"), LIATokenizer), (("LIB10", "LIB"), LIBTokenizer)):
+    for _name in _names:
+        default_tokenizers[_name] = _tok
+del _names, _tok, _name
 
 
 def _family(bos, eos, padchar):
@@ -125,28 +121,28 @@ total_tokenizer_dict = {(b, e, p, k): Tokenizer(k.upper(), bos=b, eos=e, padchar
 
 
 def get_tokenizer_dict(bos, eos, padchar):
-    """Dictionary of tokenizers for a (bos, eos, padchar) combination (bioseq/__init__.py:159-168)."""
-    if bos:
-        if eos:
-            return pbeos_tokenizers if padchar else beos_tokenizers
-        return pbos_tokenizers if padchar else bos_tokenizers
-    if eos:
-        return peos_tokenizers if padchar else eos_tokenizers
-    return pos_tokenizers if padchar else default_tokenizers
+    """Dictionary of tokenizers for a (bos, eos, padchar) combination (bioseq/__init__.py:159-168); all three off
+    selects the short `default_tokenizers`."""
+    table = {(1, 1, 1): pbeos_tokenizers, (1, 1, 0): beos_tokenizers, (1, 0, 1): pbos_tokenizers, (1, 0, 0): bos_tokenizers,
+             (0, 1, 1): peos_tokenizers, (0, 1, 0): eos_tokenizers, (0, 0, 1): pos_tokenizers, (0, 0, 0): default_tokenizers}
+    return table[(int(bool(bos)), int(bool(eos)), int(bool(padchar)))]
 
 
 def make_embedding(tok, embdim, maxnorm=None, norm_type=2.0, scale_grad_by_freq=False, sparse=False, _weight=None):
-    """``nn.Embedding`` sized for a tokenizer (bioseq/__init__.py:171-188)."""
-    assert norm_type >= 1., f"{norm_type} is not >= 1., so it is not a norm."
-    import torch.nn as nn
-    return nn.Embedding(tok.alphabet_size(), embdim, padding_idx=tok.pad() if tok.is_padded() else None,
-                        scale_grad_by_freq=scale_grad_by_freq, sparse=sparse, _weight=_weight)
+    """``torch.nn.Embedding`` with one row per token of `tok` (PAD row as padding_idx when the tokenizer pads) --
+    the helper of bioseq/__init__.py:171-188, same signature."""
+    if norm_type < 1.0:
+        raise AssertionError(f"{norm_type} is not >= 1., so it is not a norm.")
+    from torch import nn
+    pad_row = tok.pad() if tok.is_padded() else None
+    return nn.Embedding(tok.alphabet_size(), embdim, padding_idx=pad_row, scale_grad_by_freq=scale_grad_by_freq,
+                        sparse=sparse, _weight=_weight)
 
 
 def torchify(arr):
-    """``torch.from_numpy`` (bioseq/__init__.py:191-195)."""
-    from torch import from_numpy
-    return from_numpy(arr)
+    """numpy array -> torch tensor sharing its memory (bioseq/__init__.py:191-195)."""
+    import torch
+    return torch.from_numpy(arr)
 
 
 def __getattr__(name):

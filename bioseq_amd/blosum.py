@@ -17,36 +17,43 @@ import numpy as np
 
 from . import capi
 
-true_aas = 'ARNDCQEGHILKMFPSTWYVX'
 _lib = capi.load()
-normrows = np.zeros((21, 20), dtype=np.float64)
+
+# Residue order of the table: the 20 amino acids, then X (the row used for anything unknown).
+true_aas = "ARNDCQEGHILKMFPSTWYV" + "X"
+normrows = np.zeros((len(true_aas), len(true_aas) - 1), dtype=np.float64)
 capi.check(_lib.bsq_blosum62_normrows(normrows.ctypes.data))
 normrows.setflags(write=False)
-ca = np.array(list(true_aas))[:-1]
-aa_array = ca
-probdict = {k: normrows[idx].copy() for idx, k in enumerate(true_aas)}
-default_transitions = probdict['X']
-rng = np.random.default_rng(int(10000. / 137))
+aa_array = np.array([c for c in true_aas[:-1]])
+ca = aa_array                                   # the reference exports both names
+probdict = dict(zip(true_aas, (row.copy() for row in normrows)))
+default_transitions = probdict["X"]
+rng = np.random.default_rng(72)                 # the reference seeds with int(10000. / 137) == 72
+
+
+def _row(residue):
+    return probdict[residue] if residue in probdict else default_transitions
 
 
 def substitute(inchar, size=1):
-    """Sample `size` replacement residues for `inchar` from the BLOSUM62 row (blosum.py:51-60)."""
-    return rng.choice(ca, p=probdict.get(inchar, default_transitions), size=size, replace=True)
+    """`size` replacement residues for `inchar`, drawn from its BLOSUM62 row (reference: blosum.py:51-60)."""
+    return rng.choice(aa_array, size=size, replace=True, p=_row(inchar))
 
 
 def augment_seq(inseq, chain_len=1):
-    """Mutate one sequence `chain_len` times on the host (blosum.py:63-87)."""
-    ls = len(inseq)
-    for _ in range(chain_len):
-        outchar, inchar = (0, 0)
-        while inchar == outchar:
-            idx = rng.choice(ls)
-            outchar = inseq[idx]
-            inchar = substitute(outchar)[0]
-        ba = bytearray(inseq, 'utf-8')
-        ba[idx] = ord(inchar)
-        inseq = ba.decode()
-    return inseq
+    """`chain_len` point substitutions on one str, each at a uniformly drawn position and re-drawn (position included)
+    until the residue really changes -- the host-side helper with the reference's semantics (blosum.py:63-87).
+    Batches belong on the GPU: `augment_packed`."""
+    residues = list(inseq)
+    n = len(residues)
+    for _step in range(chain_len):
+        while True:
+            where = int(rng.choice(n))
+            new = str(substitute(residues[where])[0])
+            if new != residues[where]:
+                residues[where] = new
+                break
+    return "".join(residues)
 
 
 def augment_packed(chars, offsets, chain_len=1, augment_frac=1.0, seed=0):

@@ -18,17 +18,20 @@ from .flatfile import FlatFile
 
 
 def FF2NP(x, tokenizer, destfile, *, batch_size=8192):
-    """FlatFile -> (nseqs, maxseqlen + bos + eos) uint8 token memmap (loaders.py:11-26), one encode per batch."""
-    assert isinstance(x, FlatFile)
-    msl = x.maxseqlen
-    total_msl = msl + tokenizer.includes_bos() + tokenizer.includes_eos()
-    nseqs = x.nseqs()
-    retmat = np.memmap(destfile, mode='w+', dtype=np.uint8, shape=(nseqs, total_msl))
-    for start in range(0, nseqs, batch_size):
-        stop = min(start + batch_size, nseqs)
-        retmat[start:stop] = x.batch_tokenize(tokenizer, start, stop, padlen=total_msl, destchar='B',
-                                              batch_first=True).view(np.uint8)
-    return (retmat, destfile)
+    """Token matrix of a whole FlatFile as a uint8 memmap at `destfile`: (nseqs, maxseqlen + bos + eos), batch-first
+    (the reference's helper of the same name, loaders.py:11-26) -- `batch_size` sequences per device encode."""
+    if not isinstance(x, FlatFile):
+        raise TypeError("FF2NP expects a FlatFile")
+    n = x.nseqs()
+    width = x.maxseqlen + int(tokenizer.includes_bos()) + int(tokenizer.includes_eos())
+    tokens = np.memmap(destfile, dtype=np.uint8, mode="w+", shape=(n, width))
+    first = 0
+    while first < n:
+        last = min(n, first + batch_size)
+        rows = x.batch_tokenize(tokenizer, first, last, padlen=width, destchar="B", batch_first=True)
+        tokens[first:last] = rows.view(np.uint8)
+        first = last
+    return tokens, destfile
 
 
 class FlatFileDataset(torch.utils.data.Dataset):
@@ -42,18 +45,14 @@ class FlatFileDataset(torch.utils.data.Dataset):
 
     def __init__(self, ff, tokenizer, *, augment=0, augment_frac=0.5, cnn=False, device=None, maskfrac=0.15, seed=13):
         super().__init__()
-        assert isinstance(ff, FlatFile)
-        if device is None:
-            device = torch.device("cuda")
-        self.device = torch.device(device)
-        self.ff = ff
-        self.tokenizer = tokenizer
-        self.max_seq_len = ff.maxseqlen + tokenizer.includes_bos() + tokenizer.includes_eos()
-        self.maxseqlen = self.max_seq_len
-        self.augment = augment
-        self.augment_frac = augment_frac
-        self.cnn = cnn
-        self.maskfrac = maskfrac
+        if not isinstance(ff, FlatFile):
+            raise TypeError("FlatFileDataset expects a FlatFile")
+        self.device = torch.device("cuda" if device is None else device)
+        self.ff, self.tokenizer = ff, tokenizer
+        # attribute names as in the reference's class (loaders.py:36-47)
+        self.max_seq_len = self.maxseqlen = ff.maxseqlen + int(tokenizer.includes_bos()) + int(tokenizer.includes_eos())
+        self.augment, self.augment_frac = augment, augment_frac
+        self.cnn, self.maskfrac = cnn, maskfrac
         self._seed = int(seed)
         self._calls = 0
 
@@ -102,12 +101,13 @@ class FlatFileDataset(torch.utils.data.Dataset):
         return self.get_batch(index, index + 1)[0]
 
     def access(self, slc, stop=None, step=None):
-        if isinstance(slc, int):
-            slc = slice(slc, stop, step)
-        return self[slc]
+        """Range accessor with the reference's convention (loaders.py:105-111): an int `slc` is the START of
+        slice(slc, stop, step) -- so access(i) alone runs from i to the end --, a slice is used as it is."""
+        rng_ = slc if isinstance(slc, slice) else slice(slc, stop, step)
+        return self[rng_]
 
     def cleanup(self):
-        pass
+        """Nothing to release (the reference's loader closes its memmap here)."""
 
 
 class AugmentedSeqDataset(FlatFileDataset):
