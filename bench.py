@@ -205,6 +205,21 @@ def main():
         if not os.environ.get("BSQ_BENCH_SKIP_SANITY"):
             assert ones == expect, ("one-hot sanity failed", ones, expect)
 
+    # write-bandwidth yardstick: a plain fill (one 1-KiB store per wave, one aligned 4-KiB chunk per workgroup,
+    # blocks in address order) over the same output buffer.  Measured BEFORE the warm-up steps: its launches
+    # also lift the clocks out of idle, so that a small --warmup does not time the clock ramp.
+    capi.check(lib.bsq_tuning_set(b"fill_mode", 1))
+    fill_bytes = (out_bytes // 16) * 16
+    for _ in range(10):
+        capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh))
+    fa, fb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fa.record(stream)
+    for _ in range(5):
+        capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh))
+    fb.record(stream)
+    torch.cuda.synchronize()
+    fill_gbps = fill_bytes * 5 / (fa.elapsed_time(fb) * 1e-3) / 1e9
+
     for _ in range(args.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -220,20 +235,6 @@ def main():
     kern_avg_ms = float(np.mean(kern_ms))
     if os.environ.get("BSQ_BENCH_DUMP"):  # per-step device times, for variance hunting
         print("per-step ms:", " ".join("%.3f" % v for v in kern_ms), file=sys.stderr)
-
-    # write-bandwidth yardstick: the fastest plain fill we know (one 1-KiB store per wave, one aligned
-    # 4-KiB chunk per workgroup, blocks in address order) over the same output buffer
-    capi.check(lib.bsq_tuning_set(b"fill_mode", 1))
-    fill_bytes = (out_bytes // 16) * 16
-    for _ in range(2):
-        capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh))
-    fa, fb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fa.record(stream)
-    for _ in range(5):
-        capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh))
-    fb.record(stream)
-    torch.cuda.synchronize()
-    fill_gbps = fill_bytes * 5 / (fa.elapsed_time(fb) * 1e-3) / 1e9
 
     gather_info = None
     if world > 1 and args.gather > 0:
