@@ -74,6 +74,7 @@ def load():
         "bsq_fill_device": (i32, [vp, sz, ctypes.c_uint32, vp]),
         "bsq_fill_pattern_device": (i32, [vp, i64, i64, i32, i32, i32, i32, i32, vp]),
         "bsq_xcd_of_blocks_device": (i32, [vp, i32, vp]),
+        "bsq_selftest_index_math": (i64, []),
         "bsq_raw_tokens_device": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, vp]),
         "bsq_onehot_from_raw_tokens_device": (i32, [vp, i64, i64, i64, i32, i32, vp, vp]),
         "bsq_blosum62_normrows": (i32, [vp]),

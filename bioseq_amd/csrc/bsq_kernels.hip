@@ -437,8 +437,9 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
 // out with 4 x (ds_read_b128 -> global_store_dwordx4), clear the ones.  No barriers.
 // ------------------------------------------------------------------------------------------
 // floor(n / d) for n < 2^31 with the constants of div_constants() (round-up method: exact below 2^31).
-__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t shift, uint32_t pow2) {
-    return pow2 ? n >> shift : __umulhi(n, magic) >> shift;
+// (host + device: bsq_selftest_index_math() runs the very same code on the CPU)
+__host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t shift, uint32_t pow2) {
+    return pow2 ? n >> shift : static_cast<uint32_t>((static_cast<uint64_t>(n) * magic) >> 32) >> shift;  // v_mul_hi_u32
 }
 
 // Constants of fast_div(): floor(n / d) == mulhi(n, magic) >> shift for every n < 2^31 (round-up method:
@@ -458,7 +459,7 @@ constexpr int kChunk = 4096;
 // inv = 1.0 / d (computed on the host): the product is within 1 of n / d, one correction step makes it
 // exact.  Replaces the ~120-instruction 64-bit integer division the chunk kernels would otherwise run
 // twice per wave (byte offset -> row, row -> position).
-__device__ __forceinline__ int64_t div_by(int64_t n, int64_t d, double inv, int64_t *rem) {
+__host__ __device__ __forceinline__ int64_t div_by(int64_t n, int64_t d, double inv, int64_t *rem) {
     int64_t q = static_cast<int64_t>(static_cast<double>(n) * inv);
     int64_t r = n - q * d;
     if (r < 0) {
@@ -1809,6 +1810,52 @@ bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32
         hipLaunchKernelGGL((k_fill_pattern<false>), grid, dim3(kThreads), 0, s, static_cast<uint8_t *>(dst), rows, pitch,
                            seg, rows_per_wave, ncb, nrb, order, interleave);
     return check_launch("k_fill_pattern");
+}
+
+// Host-side self-test of the kernels' division-free index arithmetic (the same inline functions the device runs):
+// fast_div against n / d for dividends below 2^31, div_by against the integer quotient / remainder below 2^52.
+// Returns 0, or a non-zero code that identifies the first failing case.
+int64_t bsq_selftest_index_math(void) {
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    auto next = [&x]() {  // splitmix64
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    for (int it = 0; it < 20000; ++it) {
+        uint32_t d;
+        switch (it % 5) {
+        case 0: d = uint32_t(it / 5 + 1); break;                                    // 1, 2, 3, ...
+        case 1: d = uint32_t(1) << (it / 5 % 31); break;                            // powers of two
+        case 2: d = (uint32_t(1) << (it / 5 % 30 + 1)) - 1; break;                  // 2^k - 1
+        case 3: d = (uint32_t(1) << (it / 5 % 29 + 1)) + 1; break;                  // 2^k + 1
+        default: d = uint32_t(next() % (uint64_t(1) << 30)) + 1; break;             // random <= 2^30
+        }
+        if (d > (uint32_t(1) << 30)) d = uint32_t(1) << 30;
+        uint32_t magic, shift, pow2;
+        div_constants(d, &magic, &shift, &pow2);
+        const double inv = 1.0 / double(d);
+        for (int j = 0; j < 64; ++j) {
+            uint32_t n;
+            const uint64_t qmax = ((uint64_t(1) << 31) - 1) / d;
+            switch (j % 4) {
+            case 0: n = uint32_t(next() & 0x7FFFFFFFu); break;
+            case 1: n = uint32_t((next() % (qmax + 1)) * d); break;                 // exact multiples
+            case 2: { const uint64_t m = (next() % (qmax + 1)) * d; n = uint32_t(m ? m - 1 : 0); break; }  // one below
+            default: n = uint32_t(0x7FFFFFFFu - uint32_t(j)); break;                // the top of the range
+            }
+            if (fast_div(n, magic, shift, pow2) != n / d) return 1000000 + it;
+            int64_t big = int64_t(next() >> 12);                                    // < 2^52
+            if (j % 8 == 3) big = (big / d) * int64_t(d);
+            if (j % 8 == 5) big = (int64_t(1) << 52) - 1 - j;
+            int64_t rem = -1;
+            const int64_t q = div_by(big, int64_t(d), inv, &rem);
+            if (q != big / int64_t(d) || rem != big % int64_t(d)) return 2000000 + it;
+        }
+    }
+    return 0;
 }
 
 bsq_status bsq_xcd_of_blocks_device(int32_t *xcd_dev, int32_t nblocks, void *hip_stream) {

@@ -150,6 +150,10 @@ bsq_status bsq_raw_tokens_device(const bsq_desc *d, const uint8_t *chars, const 
 bsq_status bsq_onehot_from_raw_tokens_device(const uint8_t *tokens, int64_t pitch, int64_t B, int64_t P, int32_t C,
                                              bsq_dtype t, void *out, void *hip_stream);
 
+/* Host-only self-test of the kernels' division-free index arithmetic (reciprocal multiplies instead of integer
+ * divisions; the same inline functions run on the device): 0 = every case exact. */
+int64_t bsq_selftest_index_math(void);
+
 /* Diagnostic: xcd_dev[b] = id (0..7) of the XCD block b of an nblocks-block 1-D launch ran on.  The chunk
  * kernels assume -- for speed only, never for results -- that blocks b and b + 8 share an XCD. */
 bsq_status bsq_xcd_of_blocks_device(int32_t *xcd_dev, int32_t nblocks, void *hip_stream);

@@ -118,3 +118,11 @@ def test_repo_layout():
     assert "oracle/_ref/" in gi
     gri = open(os.path.join(ROOT, ".gpurunignore")).read()
     assert "_ref" not in gri and ".so" not in gri  # built artefacts must travel to the GPU box
+
+
+def test_index_math_selftest():
+    """The kernels divide by reciprocal multiplies (fast_div: n < 2^31, div_by: n < 2^52); the library runs the same
+    inline functions on the host against integer division -- 1.3 million cases incl. powers of two, 2^k +- 1,
+    exact multiples and the top of both ranges."""
+    from bioseq_amd import capi
+    assert capi.load().bsq_selftest_index_math() == 0
