@@ -273,13 +273,15 @@ __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, i
     __syncthreads();
 }
 
+// One 16-byte store, non-temporal if NT (global_store_dwordx4 ... nt).  The value goes through ONE vector-typed
+// nontemporal store: four scalar ones only stay `nt` if the compiler happens to merge them unchanged (it dropped
+// the flag for the 8-byte element types, which cost the f64 token matrix 40 % of its bandwidth).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ void store16(void *dst, const uint4 &v) {
     if constexpr (NT) {
-        __builtin_nontemporal_store(v.x, reinterpret_cast<uint32_t *>(dst) + 0);
-        __builtin_nontemporal_store(v.y, reinterpret_cast<uint32_t *>(dst) + 1);
-        __builtin_nontemporal_store(v.z, reinterpret_cast<uint32_t *>(dst) + 2);
-        __builtin_nontemporal_store(v.w, reinterpret_cast<uint32_t *>(dst) + 3);
+        const u32x4 x = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(x, reinterpret_cast<u32x4 *>(dst));
     } else {
         *reinterpret_cast<uint4 *>(dst) = v;
     }
@@ -379,9 +381,20 @@ __global__ __launch_bounds__(kThreads) void k_onehot_tile(const KParams p) {
 // ------------------------------------------------------------------------------------------
 // Tokens, (P,B) layout, tiled: phase 1 as above, then a transposed read of the token tile.
 // ------------------------------------------------------------------------------------------
+// Token id (< 256) as a value of type T.  double goes through the 2^52 trick -- bits(2^52 + k) = 0x4330000000000000 | k,
+// minus 2^52 is exact -- because v_cvt_f64_u32 is slow on this part (f64 token matrices ran 1.7x slower than int64
+// ones with the plain cast; the f32 cast is full rate).
+template <typename T>
+__device__ __forceinline__ T id_as(uint32_t tk) {
+    if constexpr (std::is_same<T, double>::value)
+        return __hiloint2double(0x43300000, static_cast<int>(tk)) - 4503599627370496.0;
+    else
+        return static_cast<T>(tk);
+}
+
 template <typename T>
 __device__ __forceinline__ T token_value(uint32_t tk) {
-    return tk == kNone ? T(0) : static_cast<T>(tk);  // unmapped / unpadded positions keep the memset 0
+    return tk == kNone ? T(0) : id_as<T>(tk);  // unmapped / unpadded positions keep the memset 0
 }
 
 template <typename T, int TB>
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
         }
         T *dst = out + t * p.B + b0 + sb0;
         if (p.aligned && b0 + sb0 + EPC <= p.B) {
-            *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(vals);
+            store16<true>(dst, *reinterpret_cast<const uint4 *>(vals));  // streamed once, never re-read: non-temporal
         } else {
 #pragma unroll
             for (int i = 0; i < EPC; ++i)
@@ -645,7 +658,10 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
             v.y = *reinterpret_cast<const uint32_t *>(src + 4);
             v.z = *reinterpret_cast<const uint32_t *>(src + 8);
             v.w = *reinterpret_cast<const uint32_t *>(src + 12);
-            *reinterpret_cast<uint4 *>(dst) = v;
+            if constexpr (RAW)
+                *reinterpret_cast<uint4 *>(dst) = v;  // scratch: re-read by the expansion pass right away
+            else
+                store16<true>(dst, v);               // final token matrix: streamed once
         } else {
             for (int i = 0; i < 16; ++i)
                 if (b0 + q * 16 + i < p.B) dst[i] = src[i];
@@ -953,7 +969,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
                         if constexpr (HOT)
                             vals[q * WB + i] = tk == c.chan[u] ? hot_one : T(0);
                         else
-                            vals[q * WB + i] = static_cast<T>(tk);
+                            vals[q * WB + i] = id_as<T>(tk);
                     }
                 }
             }
