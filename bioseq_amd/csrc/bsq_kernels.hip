@@ -696,10 +696,10 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_rows(const KParams p) {
             } else if constexpr (sizeof(T) == 2) {
                 *reinterpret_cast<uint2 *>(orow + tpos) = *reinterpret_cast<const uint2 *>(vals);
             } else if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<uint4 *>(orow + tpos) = *reinterpret_cast<const uint4 *>(vals);
+                store16<true>(orow + tpos, *reinterpret_cast<const uint4 *>(vals));
             } else {
-                reinterpret_cast<uint4 *>(orow + tpos)[0] = reinterpret_cast<const uint4 *>(vals)[0];
-                reinterpret_cast<uint4 *>(orow + tpos)[1] = reinterpret_cast<const uint4 *>(vals)[1];
+                store16<true>(orow + tpos, reinterpret_cast<const uint4 *>(vals)[0]);
+                store16<true>(orow + tpos + 2, reinterpret_cast<const uint4 *>(vals)[1]);
             }
         } else {
 #pragma unroll
