@@ -1,0 +1,64 @@
+// Device-side helpers shared by the kernel translation units of libbsq_hip.so (gfx950 only; not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace bsq_dev {
+
+constexpr int kThreads = 256;      // 4 waves of 64
+constexpr uint32_t kNone = 0xFFu;  // "no token": all-zero one-hot row / token value 0
+constexpr int kChunk = 4096;       // the unit of the streaming kernels: one naturally aligned 4-KiB piece of the output
+
+// One 16-byte store, non-temporal if NT (global_store_dwordx4 ... nt).  The value goes through ONE vector-typed
+// nontemporal store: four scalar ones only stay `nt` if the compiler happens to merge them unchanged (it dropped
+// the flag for the 8-byte element types, which cost the f64 token matrix 40 % of its bandwidth).
+// (Write-through `sc1` stores were tried in round 2: a pure 64-128 MiB store stream runs 15-20 % faster with them,
+// every kernel that also reads runs the same or slower, multi-GB outputs much slower: profiles/r02/store_kinds.txt.)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void store16(void *dst, const uint4 &v) {
+    if constexpr (NT) {
+        const u32x4 x = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(x, reinterpret_cast<u32x4 *>(dst));
+    } else {
+        *reinterpret_cast<uint4 *>(dst) = v;
+    }
+}
+
+// floor(n / d) for n < 2^31 with the constants of div_constants() (round-up method: exact below 2^31).
+// (host + device: bsq_selftest_index_math() runs the very same code on the CPU)
+__host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t shift, uint32_t pow2) {
+    return pow2 ? n >> shift : static_cast<uint32_t>((static_cast<uint64_t>(n) * magic) >> 32) >> shift;  // v_mul_hi_u32
+}
+
+// Constants of fast_div(): floor(n / d) == mulhi(n, magic) >> shift for every n < 2^31 (round-up method:
+// magic = floor(2^(32+shift) / d) + 1 with shift = floor(log2 d); the error term n / 2^(32+shift) stays
+// below 1/d because d < 2^(shift+1)); powers of two are plain shifts.  1 <= d <= 2^30.
+inline void div_constants(uint32_t d, uint32_t *magic, uint32_t *shift, uint32_t *pow2) {
+    uint32_t sh = 0;
+    while ((uint64_t(2) << sh) <= d) ++sh;
+    *shift = sh;
+    *pow2 = (d & (d - 1)) == 0;
+    *magic = *pow2 ? 0u : uint32_t((uint64_t(1) << (32 + sh)) / d + 1);
+}
+
+// floor(n / d) and the remainder for 0 <= n < 2^52, 1 <= d < 2^31 through one double multiply with
+// inv = 1.0 / d (computed on the host): the product is within 1 of n / d, one correction step makes it
+// exact.  Replaces the ~120-instruction 64-bit integer division the chunk kernels would otherwise run
+// twice per wave (byte offset -> row, row -> position).
+__host__ __device__ __forceinline__ int64_t div_by(int64_t n, int64_t d, double inv, int64_t *rem) {
+    int64_t q = static_cast<int64_t>(static_cast<double>(n) * inv);
+    int64_t r = n - q * d;
+    if (r < 0) {
+        q -= 1;
+        r += d;
+    } else if (r >= d) {
+        q += 1;
+        r -= d;
+    }
+    *rem = r;
+    return q;
+}
+
+}  // namespace bsq_dev

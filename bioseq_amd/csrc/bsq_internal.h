@@ -20,6 +20,9 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokenize_path 1: never use k_tokenize_chunks / the raw-token kernel for batch_tokenize
 //   tokenize_pad  unused dynamic LDS of k_tokenize_chunks (experiments: no cap helps it)
 //   tokenize_nch  4: software-pipelined four chunks per wave in k_tokenize_chunks (experiments: slower than 1)
+//   tokens8       1: never use k_tokens_bp8 for the (B,P) int8 token matrix (falls back to k_tokenize_chunks)
+//   tokens8_lookup  0 automatic, 1 LDS byte table, 2 register table (v_perm_b32)
+//   tokens8_pad   unused dynamic LDS of k_tokens_bp8;  tokens8_abl  ablation experiments (diagnostic)
 //   onehot_tb     0: automatic, else force 64 / 128 / 256 sequences per tile of k_onehot_tile
 //   tile_order    0: sequence-tile index fastest, 1: position-tile index fastest
 //   fill_mode, fill_pad   access pattern / occupancy of bsq_fill_device (write-bandwidth yardsticks)
@@ -31,5 +34,10 @@ inline bool nontemporal_stores() { return tuning("nt_stores") != 0; }
 // Stream-ordered scratch (hipMallocAsync from a pool that keeps its memory between calls).
 bsq_status workspace_acquire(size_t nbytes, hipStream_t stream, void **ptr);
 void workspace_release(void *ptr, hipStream_t stream);
+
+// bsq_tokens8.hip: the (B,P) int8 token matrix (register-table lookups, LDS rule tables).
+bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out);
+bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
+                             void *out, hipStream_t stream);
 
 }  // namespace bsq_internal

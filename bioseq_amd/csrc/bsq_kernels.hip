@@ -39,15 +39,16 @@
 #include <type_traits>
 
 #include "bsq.h"
+#include "bsq_device.h"
 #include "bsq_internal.h"
 
 namespace {
 
-constexpr int kThreads = 256;         // 4 waves of 64
+using namespace bsq_dev;  // kThreads, kNone, kChunk, store16, fast_div, div_constants, div_by
+
 constexpr int kTT = 64;               // positions per tile
 constexpr int kTokStride = kTT + 4;   // bytes per sequence row of the LDS token tile (17 dwords:
                                       // odd dword stride -> column reads hit 32 distinct banks)
-constexpr uint32_t kNone = 0xFFu;     // "no token": all-zero one-hot row / token value 0
 constexpr int64_t kMaxTiledP = int64_t(1) << 22;  // tiled kernels: 256 sequences x padlen must fit 32-bit offsets
 
 struct KParams {
@@ -273,20 +274,6 @@ __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, i
     __syncthreads();
 }
 
-// One 16-byte store, non-temporal if NT (global_store_dwordx4 ... nt).  The value goes through ONE vector-typed
-// nontemporal store: four scalar ones only stay `nt` if the compiler happens to merge them unchanged (it dropped
-// the flag for the 8-byte element types, which cost the f64 token matrix 40 % of its bandwidth).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ void store16(void *dst, const uint4 &v) {
-    if constexpr (NT) {
-        const u32x4 x = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(x, reinterpret_cast<u32x4 *>(dst));
-    } else {
-        *reinterpret_cast<uint4 *>(dst) = v;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // One-hot, tiled.  Dynamic LDS layout:
 //   [0, off_bytes)              int64 offsets of the tile's sequences (+1)
@@ -449,43 +436,6 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
 // (coalesced bytes), scatter their ones into the wave's private 4-KiB LDS image, stream the image
 // out with 4 x (ds_read_b128 -> global_store_dwordx4), clear the ones.  No barriers.
 // ------------------------------------------------------------------------------------------
-// floor(n / d) for n < 2^31 with the constants of div_constants() (round-up method: exact below 2^31).
-// (host + device: bsq_selftest_index_math() runs the very same code on the CPU)
-__host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t shift, uint32_t pow2) {
-    return pow2 ? n >> shift : static_cast<uint32_t>((static_cast<uint64_t>(n) * magic) >> 32) >> shift;  // v_mul_hi_u32
-}
-
-// Constants of fast_div(): floor(n / d) == mulhi(n, magic) >> shift for every n < 2^31 (round-up method:
-// magic = floor(2^(32+shift) / d) + 1 with shift = floor(log2 d); the error term n / 2^(32+shift) stays
-// below 1/d because d < 2^(shift+1)); powers of two are plain shifts.  1 <= d <= 2^30.
-void div_constants(uint32_t d, uint32_t *magic, uint32_t *shift, uint32_t *pow2) {
-    uint32_t sh = 0;
-    while ((uint64_t(2) << sh) <= d) ++sh;
-    *shift = sh;
-    *pow2 = (d & (d - 1)) == 0;
-    *magic = *pow2 ? 0u : uint32_t((uint64_t(1) << (32 + sh)) / d + 1);
-}
-
-constexpr int kChunk = 4096;
-
-// floor(n / d) and the remainder for 0 <= n < 2^52, 1 <= d < 2^31 through one double multiply with
-// inv = 1.0 / d (computed on the host): the product is within 1 of n / d, one correction step makes it
-// exact.  Replaces the ~120-instruction 64-bit integer division the chunk kernels would otherwise run
-// twice per wave (byte offset -> row, row -> position).
-__host__ __device__ __forceinline__ int64_t div_by(int64_t n, int64_t d, double inv, int64_t *rem) {
-    int64_t q = static_cast<int64_t>(static_cast<double>(n) * inv);
-    int64_t r = n - q * d;
-    if (r < 0) {
-        q -= 1;
-        r += d;
-    } else if (r >= d) {
-        q += 1;
-        r -= d;
-    }
-    *rem = r;
-    return q;
-}
-
 struct EParams {
     const uint8_t *tok;  // raw tokens (kNone = no one), row t at tok + t*Bp (Bp = B rounded up to 256: every
                          // row of the scratch is 256-byte aligned whatever B is)
@@ -1656,6 +1606,8 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     const uintptr_t addr = reinterpret_cast<uintptr_t>(out);
     if (batch_first && bsq_internal::tuning("tokenize_path") != 1 && addr % 16 == 0 &&
         P % int64_t(16 / sz) == 0) {  // chunk kernel: every lane's 16 output bytes lie inside one row
+        if (t == BSQ_I8 && bsq_internal::tuning("tokens8") != 1 && bsq_internal::tokens_bp8_applicable(d, B, P, out))
+            return bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, out, s);
         switch (t) {
         case BSQ_I8: return launch_tokenize_chunks<int8_t, false>(k, s);
         case BSQ_I16: return launch_tokenize_chunks<int16_t, false>(k, s);

@@ -1,0 +1,377 @@
+// k_tokens_bp8: the (B,P) int8 token matrix of batch_tokenize(batch_first=True, destchar='b') -- BASELINE
+// configs 2 and 5 -- for gfx950 (MI355X / CDNA4) only.  Semantics: /root/reference/src/tokenize.h:454-479.
+//
+// Same streaming shape as the other chunk kernels (one wave = one naturally aligned 4-KiB chunk of the flat
+// output, chunk classes pinned to XCDs, one unaligned 16-byte character load and one 16-byte nt store per lane
+// and KiB), but with the per-character work cut to what an 8-bit stream can afford (the generic
+// k_tokenize_chunks spends ~30 VALU + 4 LDS instructions per 4 characters and runs at 0.60-0.69 of the HBM
+// roof on these shapes, bound by instruction issue and by the serial ds_read_u8 -> pack chains):
+//   * alphabet lookup out of REGISTERS: every alphabet but BYTES maps letters only and both cases alike, so
+//     the table is 32 bytes indexed by (c & 31) -- eight dwords in VGPRs, looked up four characters at a time
+//     with v_perm_b32 (4 + 2 + 1 perms over bits 2:0, 3, 4 of each byte).  Non-letters (rare) are detected on
+//     the packed words and fixed on a wave-uniform slow path.  LK = 0 keeps the LDS byte table instead.
+//   * BOS / EOS / PAD rules from a per-wave LDS table: the 16 bytes of a lane start `d` = L - j0 characters
+//     before the end of its sequence; entry clamp(d, -1, 16) holds the 16-byte keep mask and the 16 constant
+//     bytes (EOS at byte d, PAD behind it), so the rules cost two ds_read_b128 per store and ONE v_and_or per
+//     word instead of ~10 VALU per word.
+//   * the offsets of the <= 63 sequences a chunk touches are loaded ONCE per wave (lane i: sequence bc + i) and
+//     handed to the lanes with ds_bpermute, instead of eight 8-byte loads per lane.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+
+#include "bsq.h"
+#include "bsq_device.h"
+#include "bsq_internal.h"
+
+namespace {
+
+using namespace bsq_dev;
+
+struct T8Params {
+    int8_t lut[256];   // LK == 0 only
+    uint32_t tab[8];   // LK == 1: token value of letter (c & 31), unmapped = 0 (the memset value of tokenize.h:427)
+    const uint8_t *chars;
+    const int64_t *offsets;
+    uint8_t *out;
+    int64_t total;     // output bytes = B * P
+    int64_t nchunks;
+    int64_t B;
+    double inv_P;      // div_by() constant (outputs of 2^31 bytes and more)
+    uint32_t P, magic, shift, pow2;  // fast_div() constants of P
+    int32_t bos, room;
+    uint32_t bos_id, at_len_v, fill_v;  // token VALUES at position 0, bos + L and beyond (0 where the reference leaves the memset)
+    int32_t abl;       // ablation experiments (diagnostic builds of the kernel only)
+};
+
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+
+__device__ __forceinline__ uint32_t lookup4_perm(uint32_t cw, const uint32_t (&T)[8]) {
+    const uint32_t sel = cw & 0x07070707u;
+    const uint32_t r0 = __builtin_amdgcn_perm(T[1], T[0], sel);
+    const uint32_t r1 = __builtin_amdgcn_perm(T[3], T[2], sel);
+    const uint32_t r2 = __builtin_amdgcn_perm(T[5], T[4], sel);
+    const uint32_t r3 = __builtin_amdgcn_perm(T[7], T[6], sel);
+    const uint32_t s3 = ((cw >> 1) & 0x04040404u) | 0x03020100u;  // byte i: i + 4 * bit 3 of character i
+    const uint32_t lo = __builtin_amdgcn_perm(r1, r0, s3);
+    const uint32_t hi = __builtin_amdgcn_perm(r3, r2, s3);
+    const uint32_t s4 = ((cw >> 2) & 0x04040404u) | 0x03020100u;  // ... bit 4
+    return __builtin_amdgcn_perm(hi, lo, s4);
+}
+
+// 0xFF in every byte of cw that is NOT a letter position (0x40..0x7F): those bytes are unmapped.
+__device__ __forceinline__ uint32_t nonletter_mask(uint32_t cw) {
+    const uint32_t x = (cw ^ 0x40404040u) & 0xC0C0C0C0u;
+    const uint32_t f = ((x >> 6) | (x >> 7)) & 0x01010101u;
+    return (f << 8) - f;  // f * 0xFF
+}
+
+// ABL (diagnostic instantiations only): 0 the kernel; 1 no alphabet lookup (characters stored as they are);
+// 2 no character loads; 3 no offsets loads either (synthetic sequence spans); 4 stores only; 5 character loads at
+// synthetic addresses that do not depend on the offsets.
+struct OffStage {   // stage A of one chunk: where it lies, the offsets of its rows in flight
+    bool valid;     // wave-uniform
+    int64_t lo, bc; // byte offset of the chunk in the output, its first row
+    uint32_t tc;    // position inside row bc of the chunk's first element
+    int64_t o0, o1; // lane i: offsets[bc + i], offsets[bc + i + 1]
+};
+struct CharStage {  // stage B: the lane's four 16-byte character vectors in flight + what stage C needs
+    bool valid;
+    int64_t lo, bc;
+    uint32_t tc;
+    u32x4u cw[4];
+    int32_t j0[4], L[4];
+    bool live[4], slow[4];
+};
+
+template <bool NT, int LK, int ABL>
+__global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
+    __shared__ __align__(16) uint4 s_rule[4][2][18];
+    __shared__ __align__(16) uint8_t s_lut4[LK == 0 ? 4 : 1][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+
+    // chunk of this wave: class = blockIdx % 8 (pinned to the XCD the block lands on)
+    const int64_t k0 = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s);
+    if (k0 >= p.nchunks) return;
+
+    if constexpr (ABL == 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 * kChunk + u * 1024 + lane * 16 < p.total)
+                store16<NT>(p.out + k0 * kChunk + u * 1024 + lane * 16, uint4{p.fill_v, 0, 0, 0});
+        return;
+    }
+
+    // ---- per-wave tables ----
+    const uint32_t fill_w = p.fill_v * 0x01010101u, at_w = p.at_len_v * 0x01010101u;
+    if (lane < 18) {  // rule entry `lane`: n = lane - 1 bytes kept, byte n (if any) = token at bos + L, the rest fill
+        const int n = lane - 1;
+        uint32_t keep[4], cst[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nv = n - 4 * q;
+            const int nvc = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+            const uint32_t kq = nvc == 4 ? 0xFFFFFFFFu : ((1u << (8 * nvc)) - 1u);
+            const uint32_t at = (nv >= 0 && nv < 4) ? (0xFFu << (8 * nv)) : 0u;
+            keep[q] = kq;
+            cst[q] = (fill_w & ~kq & ~at) | (at_w & at);
+        }
+        s_rule[wave][0][lane] = uint4{keep[0], keep[1], keep[2], keep[3]};
+        s_rule[wave][1][lane] = uint4{cst[0], cst[1], cst[2], cst[3]};
+    }
+    uint32_t T[8];
+    if constexpr (LK == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) T[i] = p.tab[i];
+    } else {  // wave-private byte table of token VALUES (unmapped / >= 0x80 -> 0)
+        uint32_t w = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane * 4 + q;
+            const int8_t v = p.lut[idx];
+            w |= ((idx < 128 && v >= 0) ? static_cast<uint32_t>(v) : 0u) << (8 * q);
+        }
+        reinterpret_cast<uint32_t *>(s_lut4[wave])[lane] = w;
+    }
+    const uint8_t *lut = s_lut4[LK == 0 ? wave : 0];
+
+    const bool small = p.total < (int64_t(1) << 31);
+    const uint32_t P = p.P;
+    auto div_p = [&](uint32_t n) { return fast_div(n, p.magic, p.shift, p.pow2); };
+    constexpr bool kLoadOffsets = ABL != 3 && ABL != 5;
+    constexpr bool kLoadChars = ABL < 2 || ABL >= 5;
+    const int64_t total_chars = kLoadOffsets ? p.offsets[p.B] : int64_t(1) << 24;
+
+    // ---- stage A: rows of the chunk, their offsets (ONE coalesced pair of loads per wave) ----
+    auto stage_a = [&](int64_t k) {
+        OffStage a;
+        a.valid = k < p.nchunks;  // wave-uniform
+        a.o0 = a.o1 = 0;
+        a.lo = a.bc = 0;
+        a.tc = 0;
+        if (!a.valid) return a;
+        a.lo = k * kChunk;
+        if (small) {
+            const uint32_t q = div_p(static_cast<uint32_t>(a.lo));
+            a.bc = q;
+            a.tc = static_cast<uint32_t>(a.lo) - q * P;
+        } else {
+            int64_t rem;
+            a.bc = div_by(a.lo, P, p.inv_P, &rem);
+            a.tc = static_cast<uint32_t>(rem);
+        }
+        const uint32_t nr = div_p(a.tc + (kChunk - 1));  // rows bc .. bc + nr intersect the chunk (nr <= 62: P >= 128)
+        if (kLoadOffsets && static_cast<uint32_t>(lane) <= nr) {
+            const int64_t i0 = a.bc + lane, i1 = i0 + 1;
+            a.o0 = p.offsets[i0 < p.B ? i0 : p.B];
+            a.o1 = p.offsets[i1 < p.B ? i1 : p.B];
+        }
+        return a;
+    };
+
+    // ---- stage B: the characters (4 unconditional unaligned 16-byte loads, all in flight together).  Lanes that
+    // must not touch their own address read the first bytes of the window instead.  Addresses are 32-bit offsets
+    // from a wave-uniform base: the rows of a chunk are consecutive sequences, their characters lie within 2^31
+    // bytes of the first one's (off0), so "is [a, a + 16) inside the buffer" is one unsigned compare. ----
+    auto stage_b = [&](const OffStage &a) {
+        CharStage b;
+        b.valid = a.valid;
+        b.lo = a.lo;
+        b.bc = a.bc;
+        b.tc = a.tc;
+        if (!a.valid) return b;
+        int64_t off0;
+        uint32_t rel;
+        int32_t Lr;
+        if constexpr (kLoadOffsets) {
+            off0 = (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(static_cast<int32_t>(a.o0 >> 32))) << 32) |
+                   static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int32_t>(a.o0)));
+            rel = static_cast<uint32_t>(a.o0) - static_cast<uint32_t>(off0);
+            const uint32_t len = static_cast<uint32_t>(a.o1) - static_cast<uint32_t>(a.o0);
+            Lr = static_cast<int32_t>(len > static_cast<uint32_t>(p.room) ? static_cast<uint32_t>(p.room) : len);
+        } else {
+            off0 = (a.lo >> 1) & ((int64_t(1) << 23) - 1);  // synthetic spans: ~half of the positions hold characters
+            rel = lane * (P / 2) + 3;
+            Lr = static_cast<int32_t>(P / 2) < p.room ? static_cast<int32_t>(P / 2) : p.room;
+        }
+        const int64_t lo_b64 = -off0, hi_b64 = total_chars - off0 - 16;  // valid range of a vector's first byte, relative to off0
+        const bool can_vec = hi_b64 >= lo_b64;                           // wave-uniform (the buffer holds >= 16 bytes)
+        const int32_t lo_b = lo_b64 < INT32_MIN ? INT32_MIN : static_cast<int32_t>(lo_b64);
+        const int32_t hi_b = hi_b64 > INT32_MAX ? INT32_MAX : (hi_b64 < lo_b ? lo_b : static_cast<int32_t>(hi_b64));
+        const uint32_t span = static_cast<uint32_t>(hi_b) - static_cast<uint32_t>(lo_b);
+        const int64_t rows_left64 = p.B - a.bc;
+        const uint32_t rows_left = rows_left64 > 64 ? 64u : static_cast<uint32_t>(rows_left64);
+        uint32_t uoff[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t tl = a.tc + static_cast<uint32_t>(u * 1024 + lane * 16);
+            const uint32_t q = div_p(tl);
+            const int32_t t0 = static_cast<int32_t>(tl - q * P);
+            b.live[u] = q < rows_left;
+            const uint32_t rs = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(q << 2), static_cast<int>(rel)));
+            b.L[u] = __builtin_amdgcn_ds_bpermute(static_cast<int>(q << 2), Lr);
+            const int32_t j0 = t0 - p.bos;  // >= -1
+            b.j0[u] = j0;
+            const bool need = b.live[u] && j0 < b.L[u];
+            const uint32_t d = rs + static_cast<uint32_t>(j0) - static_cast<uint32_t>(lo_b);  // offset from the lowest valid address
+            const bool fast = can_vec && need && d <= span;
+            b.slow[u] = need && !fast;
+            uoff[u] = fast ? d : 0u;
+        }
+        if (kLoadChars && can_vec) {
+            const uint8_t *cbase = p.chars + (off0 + lo_b);  // wave-uniform, inside the buffer
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b.cw[u] = *reinterpret_cast<const u32x4u *>(cbase + uoff[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b.cw[u] = u32x4u{0x41434447u, 0x61636474u, 0x4B4C4D4Eu, 0x50515253u};
+        }
+        return b;
+    };
+
+    // ---- stage C: lookups, rules, stores ----
+    auto stage_c = [&](CharStage &b) {
+        if (!b.valid) return;
+
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (kLoadChars && ABL != 5 && b.slow[u]) {  // first / last bytes of the buffer: never read outside it
+                const uint32_t tl = b.tc + static_cast<uint32_t>(u * 1024 + lane * 16);
+                const int64_t row = b.bc + div_p(tl);
+                const int64_t start = p.offsets[row];
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+                for (int i = 0; i < 16; ++i)
+                    if (b.j0[u] + i >= 0 && b.j0[u] + i < b.L[u])
+                        w[i >> 2] |= static_cast<uint32_t>(p.chars[start + b.j0[u] + i]) << (8 * (i & 3));
+                b.cw[u] = u32x4u{w[0], w[1], w[2], w[3]};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t dd = b.L[u] - b.j0[u];
+            const int32_t idx = (dd < -1 ? -1 : (dd > 16 ? 16 : dd)) + 1;
+            const uint4 keep = s_rule[wave][0][idx];
+            const uint4 cst = s_rule[wave][1][idx];
+            uint32_t w[4];
+            const uint32_t in[4] = {b.cw[u].x, b.cw[u].y, b.cw[u].z, b.cw[u].w};
+            if constexpr (ABL == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = in[q];
+            } else if constexpr (LK == 1) {
+                uint32_t bad = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w[q] = lookup4_perm(in[q], T);
+                    bad |= (in[q] ^ 0x40404040u) & 0xC0C0C0C0u;
+                }
+                if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {  // some lane holds a non-letter: exact masks (rare)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] &= ~nonletter_mask(in[q]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t x = in[q];
+                    w[q] = static_cast<uint32_t>(lut[x & 0xFFu]) | (static_cast<uint32_t>(lut[(x >> 8) & 0xFFu]) << 8) |
+                           (static_cast<uint32_t>(lut[(x >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(lut[x >> 24]) << 24);
+                }
+            }
+            uint4 o;
+            o.x = (w[0] & keep.x) | cst.x;
+            o.y = (w[1] & keep.y) | cst.y;
+            o.z = (w[2] & keep.z) | cst.z;
+            o.w = (w[3] & keep.w) | cst.w;
+            if (b.j0[u] < 0) o.x = (o.x & ~0xFFu) | p.bos_id;  // position 0 with BOS
+            if (b.live[u]) store16<NT>(p.out + b.lo + u * 1024 + lane * 16, o);
+        }
+    };
+
+    const OffStage a = stage_a(k0);
+    CharStage b = stage_b(a);
+    stage_c(b);
+}
+
+template <bool NT, int LK>
+void launch_variant(const T8Params &c, dim3 grid, size_t pad, hipStream_t s) {
+    switch (c.abl) {
+    case 1: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 1>), grid, dim3(kThreads), pad, s, c); break;
+    case 2: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 2>), grid, dim3(kThreads), pad, s, c); break;
+    case 3: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 3>), grid, dim3(kThreads), pad, s, c); break;
+    case 4: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 4>), grid, dim3(kThreads), pad, s, c); break;
+    case 5: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 5>), grid, dim3(kThreads), pad, s, c); break;
+    default: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0>), grid, dim3(kThreads), pad, s, c); break;
+    }
+}
+
+}  // namespace
+
+namespace bsq_internal {
+
+// True when every mapped byte of `lut` is a letter position (0x40..0x7F) and both cases map alike: the
+// 32-entry folded table represents it exactly (all reference alphabets but BYTES, alphabet.h:39,44).
+static bool fold_table(const int8_t lut[256], uint32_t tab[8]) {
+    for (int i = 0; i < 8; ++i) tab[i] = 0;
+    for (int c = 0; c < 256; ++c) {
+        const bool mapped = c < 128 && lut[c] >= 0;
+        if (!mapped) continue;
+        if (c < 0x40) return false;
+        const int other = c ^ 0x20;
+        if (lut[other] != lut[c]) return false;
+        tab[(c & 31) >> 2] |= static_cast<uint32_t>(static_cast<uint8_t>(lut[c])) << (8 * (c & 3));
+    }
+    // a letter position that is unmapped in one case must be unmapped in the other (checked above for mapped ones)
+    for (int c = 0x40; c < 0x80; ++c)
+        if ((lut[c] >= 0) != (lut[c ^ 0x20] >= 0)) return false;
+    return true;
+}
+
+bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out) {
+    (void)d;
+    return B > 0 && P >= 128 && P % 16 == 0 && P <= (int64_t(1) << 30) && reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
+           bsq_alphabet_size(d) <= 250 && B * P < (int64_t(1) << 51);
+}
+
+bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
+                             void *out, hipStream_t s) {
+    T8Params c;
+    for (int i = 0; i < 256; ++i) c.lut[i] = d->lut[i];
+    const bool foldable = fold_table(d->lut, c.tab);
+    c.chars = chars;
+    c.offsets = offsets;
+    c.out = static_cast<uint8_t *>(out);
+    c.B = B;
+    c.P = uint32_t(P);
+    c.total = B * P;
+    c.nchunks = (c.total + kChunk - 1) / kChunk;
+    c.inv_P = 1.0 / double(P);
+    div_constants(uint32_t(P), &c.magic, &c.shift, &c.pow2);
+    c.bos = d->bos;
+    const int64_t room = P - d->bos - d->eos;
+    c.room = int32_t(room < 0 ? 0 : room);
+    c.bos_id = uint32_t(bsq_bos_id(d)) & 0xFFu;
+    const uint32_t fill = d->padchar ? uint32_t(bsq_pad_id(d)) : 0u;  // no padchar: the memset 0 of tokenize.h:427 stays
+    c.fill_v = fill;
+    c.at_len_v = d->eos ? uint32_t(bsq_eos_id(d)) : fill;
+    c.abl = tuning("tokens8_abl");
+    int lk = tuning("tokens8_lookup");  // 0 automatic (registers when the table folds), 1 LDS byte table, 2 registers
+    if (lk == 0) lk = foldable ? 2 : 1;
+    if (lk == 2 && !foldable) lk = 1;
+    const int64_t groups = ((c.nchunks + 7) / 8 + 3) / 4;
+    if (groups * 8 >= (int64_t(1) << 31)) return set_error(BSQ_ERR_INVALID_ARG, "output too large");
+    const dim3 grid(unsigned(groups * 8));
+    const int padv = tuning("tokens8_pad");  // unused dynamic LDS = occupancy cap (experiments)
+    const size_t pad = padv > 0 ? size_t(padv) : 0;
+    const bool nt = nontemporal_stores();
+#define BSQ_T8(NTV, LKV) launch_variant<NTV, LKV>(c, grid, pad, s)
+    if (lk == 2) { if (nt) BSQ_T8(true, 1); else BSQ_T8(false, 1); }
+    else { if (nt) BSQ_T8(true, 0); else BSQ_T8(false, 0); }
+#undef BSQ_T8
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_hip_error("k_tokens_bp8", e);
+    return BSQ_OK;
+}
+
+}  // namespace bsq_internal

@@ -1,0 +1,132 @@
+"""k_tokens_bp8 -- the (B,P) int8 token matrix kernel of BASELINE cfg2 / cfg5 (bioseq_amd/csrc/bsq_tokens8.hip) --
+against the oracle (/root/reference/src/tokenize.h:454-479 restated in oracle/bsq_oracle.c), for both of its
+alphabet-lookup forms (register table through v_perm_b32, LDS byte table), and against the round-1 kernel it
+replaced.  Bit-exact."""
+import ctypes
+import itertools
+
+import numpy as np
+import pytest
+
+from bioseq_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ALL_KEYS = ["AMINO", "AMINO20", "C", "DAYHOFF", "DNA", "DNA4", "DNA5", "DNAMETH", "KETO", "LIA10",
+            "LIB10", "MURPHY", "PROTEIN", "PURPYR", "SEB10", "SEB14", "SEB6", "SEB8", "SEV10"]
+COMBOS = list(itertools.product([0, 1], repeat=3))  # (eos, bos, padchar)
+
+
+def nasty_batch(seed, n, lo, hi):
+    """Ragged batch in which every byte value appears: non-letters, digits, bytes >= 0x80, both cases."""
+    lens = synth.synth_lengths(seed, n, lo, hi)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    rng = np.random.default_rng(seed)
+    chars = rng.integers(0, 256, size=int(offs[-1]), dtype=np.uint8)
+    letters = np.frombuffer((synth.AA + synth.AA.lower()).encode(), dtype=np.uint8)
+    pick = rng.random(chars.size) < 0.7   # mostly residues, so that whole waves also take the fast path
+    chars[pick] = letters[rng.integers(0, letters.size, size=int(pick.sum()))]
+    return chars, offs
+
+
+@pytest.fixture(params=[(0, 0), (0, 1), (0, 2), (1, 0)], ids=["auto", "lds-table", "register-table", "round1-kernel"])
+def variant(request):
+    from bioseq_amd import capi
+    lib = capi.load()
+    off, lookup = request.param
+    capi.check(lib.bsq_tuning_set(b"tokens8", off))
+    capi.check(lib.bsq_tuning_set(b"tokens8_lookup", lookup))
+    yield request.param
+    capi.check(lib.bsq_tuning_set(b"tokens8", 0))
+    capi.check(lib.bsq_tuning_set(b"tokens8_lookup", 0))
+
+
+def dev_tokens(lib, capi, desc, chars, offs, P, gpu):
+    import torch
+    B = len(offs) - 1
+    # one spare byte keeps the buffer non-empty; the kernel must never read it
+    dch = torch.from_numpy(np.concatenate([chars, np.full(1, 0x41, np.uint8)])).to(gpu)[:len(chars)]
+    dof = torch.from_numpy(offs).to(gpu)
+    out = torch.full((B, P), 99, dtype=torch.int8, device=gpu)
+    capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 1, capi.I8,
+                                       out.data_ptr(), None))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_all_keys_and_flags_vs_oracle(gpu, oracle, variant):
+    """19 letter alphabets x 8 flag combos, ragged batches of every byte value, P = 128 (the smallest the kernel
+    takes) and 272 (rows straddle the 1-KiB stores)."""
+    from bioseq_amd import capi
+    lib = capi.load()
+    for P in (128, 272):
+        chars, offs = nasty_batch(4242 + P, 301, 0, P - 2)
+        for key in ALL_KEYS:
+            for (eos, bos, pad) in COMBOS:
+                ora = oracle.OracleTokenizer(key, eos, bos, pad)
+                want = ora.tokenize_packed(chars, offs, P, "b", True)
+                got = dev_tokens(lib, capi, capi.make_desc(key, eos, bos, pad), chars, offs, P, gpu)
+                assert got.tobytes() == want.tobytes(), (key, eos, bos, pad, P)
+
+
+@pytest.mark.parametrize("B,lo,hi,P", [(1, 0, 0, 128), (1, 126, 126, 128), (3, 5, 9, 144), (65, 0, 4100, 4112),
+                                       (40000, 0, 126, 128), (777, 510, 510, 512), (5000, 1, 254, 256),
+                                       (33, 1000, 2046, 2048), (4097, 0, 14, 16 * 9)])
+def test_shapes_vs_oracle(gpu, oracle, variant, B, lo, hi, P):
+    """Single sequences, empty sequences, full rows, rows longer than a chunk, many short rows per chunk, a last
+    chunk that is cut by the end of the matrix."""
+    from bioseq_amd import capi
+    lib = capi.load()
+    chars, offs = synth.synth_packed(B * 7 + P, B, lo, hi, synth.DIRTY)
+    for key, flags in (("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1)), ("SEB8", (1, 0, 1)), ("DNA5", (0, 1, 0))):
+        if hi + flags[0] + flags[1] > P:
+            continue
+        ora = oracle.OracleTokenizer(key, *flags)
+        want = ora.tokenize_packed(chars, offs, P, "b", True)
+        got = dev_tokens(lib, capi, capi.make_desc(key, *flags), chars, offs, P, gpu)
+        assert got.tobytes() == want.tobytes(), (key, flags)
+
+
+def test_tables_that_do_not_fold_use_the_lds_lookup(gpu, variant):
+    """A caller-made bsq_desc whose table maps digits, or the two cases differently, cannot use the 32-entry folded
+    register table: the kernel must fall back to the byte table and still equal the generic element kernel."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    chars, offs = nasty_batch(31337, 2000, 0, 254)
+    B, P = len(offs) - 1, 256
+    dch, dof = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+    for trial in range(3):
+        d = capi.make_desc("AMINO20", 1, 1, 1)
+        if trial == 0:
+            d.lut[ord("7")] = 3           # a mapped non-letter
+        elif trial == 1:
+            d.lut[ord("a")] = 5           # 'a' and 'A' disagree
+        else:
+            d.lut[ord("q")] = -1          # one case unmapped
+        a = torch.full((B, P), 99, dtype=torch.int8, device=gpu)
+        b = torch.full((B, P), 98, dtype=torch.int8, device=gpu)
+        capi.check(lib.bsq_tokenize_device(ctypes.byref(d), dch.data_ptr(), dof.data_ptr(), B, P, 1, capi.I8, a.data_ptr(), None))
+        capi.check(lib.bsq_tokenize_device_generic(ctypes.byref(d), dch.data_ptr(), dof.data_ptr(), B, P, 1, capi.I8, b.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), trial
+
+
+def test_unvalidated_overlong_sequences_are_clamped(gpu, variant):
+    """The device entry point does not validate: a sequence longer than the row must be clamped to it (memory safety),
+    exactly as the generic kernel does."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    chars, offs = synth.synth_packed(5, 300, 100, 400, synth.AA)
+    B, P = len(offs) - 1, 128
+    dch, dof = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+    for flags in ((0, 0, 0), (1, 1, 1)):
+        d = capi.make_desc("AMINO20", *flags)
+        a = torch.full((B, P), 99, dtype=torch.int8, device=gpu)
+        b = torch.full((B, P), 98, dtype=torch.int8, device=gpu)
+        capi.check(lib.bsq_tokenize_device(ctypes.byref(d), dch.data_ptr(), dof.data_ptr(), B, P, 1, capi.I8, a.data_ptr(), None))
+        capi.check(lib.bsq_tokenize_device_generic(ctypes.byref(d), dch.data_ptr(), dof.data_ptr(), B, P, 1, capi.I8, b.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), flags
