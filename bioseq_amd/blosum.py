@@ -28,7 +28,10 @@ aa_array = np.array([c for c in true_aas[:-1]])
 ca = aa_array                                   # the reference exports both names
 probdict = dict(zip(true_aas, (row.copy() for row in normrows)))
 default_transitions = probdict["X"]
-rng = np.random.default_rng(72)                 # the reference seeds with int(10000. / 137) == 72
+# Host helpers only.  Same seed as the reference (int(10000. / 137) == 72, blosum.py:6), but NOT the same stream: the
+# reference draws 30 000 variates at import time (blosum.py:90-92) before any caller sees `rng`, and its accept loop
+# consumes draws differently, so substitute() / augment_seq() agree with it in distribution, not draw for draw.
+rng = np.random.default_rng(72)
 
 
 def _row(residue):

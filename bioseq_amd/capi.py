@@ -12,6 +12,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsq_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bsq.h")
+DIAG_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bsq_diag.h")
 
 I8, I16, I32, U64, F32, F64 = range(6)
 SPACE_HOST, SPACE_DEVICE = 0, 1
@@ -27,9 +28,9 @@ class Desc(ctypes.Structure):
 _lib = None
 
 
-def declared_symbols(header: str = HEADER_PATH):
-    """Every function name declared in include/bsq.h."""
-    text = open(header).read()
+def declared_symbols(header: str = None):
+    """Every function name declared in include/bsq.h and include/bsq_diag.h (or in `header`)."""
+    text = open(header).read() if header else open(HEADER_PATH).read() + open(DIAG_HEADER_PATH).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bsq_[a-z0-9_]+)\s*\(", text)))
 
@@ -65,6 +66,8 @@ def load():
         "bsq_dtype_size": (sz, [c_int]),
         "bsq_validate_lengths": (i32, [vp, i64, i64, i32, i32, i64p]),
         "bsq_validate_lengths_device": (i32, [vp, i64, i64, i32, i32, i64p, vp]),
+        "bsq_validate_packed_device": (i32, [vp, i64, i64, i32, i32, i64, i64p, vp]),
+        "bsq_xcd_round_robin": (i32, []),
         "bsq_tokenize_device": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, vp]),
         "bsq_onehot_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
         "bsq_onehot_bcl_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),

@@ -7,8 +7,8 @@
 // Design note: the reference declares alias strings ("OU:KC", "U:T") but its alias pass stores
 // lut[lut[target]] (alphabet.h:52-56), i.e. the lookup of a control character, so the aliases
 // are inert in the compiled tables (O/U stay unmapped).  The tables here
-// are therefore built from the comma groups alone; tests/test_alphabets.py pins all 20 keys
-// against LUTs dumped from the compiled reference.
+// are therefore built from the comma groups alone; tests/test_oracle_golden.py and tests/test_host_surface.py pin
+// all 20 keys against tests/golden/alphabets.json (LUTs dumped from the compiled reference).
 #include "bsq.h"
 
 #include <cctype>

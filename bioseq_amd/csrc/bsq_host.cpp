@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "bsq.h"
+#include "bsq_diag.h"
 #include "bsq_internal.h"
 
 namespace {
@@ -186,7 +187,9 @@ bsq_status download(Staging &s, void *out, const void *dev_out, size_t nbytes, h
             }
             const size_t base = size_t(c) * kSlotBytes;
             const size_t len = nbytes - base < kSlotBytes ? nbytes - base : kSlotBytes;
-            const size_t per = (len / size_t(nthreads) + 4095) & ~size_t(4095);  // page-granular shares
+            // page-granular shares; ceil(len / nthreads) first, so that per * nthreads >= len (with the floor, a piece
+            // whose floor share was already a multiple of 4096 lost its last len % nthreads bytes)
+            const size_t per = ((len + size_t(nthreads) - 1) / size_t(nthreads) + 4095) & ~size_t(4095);
             const size_t lo = per * size_t(j) < len ? per * size_t(j) : len;
             const size_t hi = lo + per < len ? lo + per : len;
             if (hi > lo) std::memcpy(dst + base + lo, ring + size_t(c % kSlots) * kSlotBytes + lo, hi - lo);

@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include "bsq.h"
+#include "bsq_diag.h"
 #include "bsq_device.h"
 #include "bsq_internal.h"
 
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
 // of naturally aligned 4-KiB CHUNKS of the output, and every workgroup only writes chunks of ONE
 // residue class mod 8: blocks are dealt round-robin over the 8 XCDs, so block b (class b % 8) keeps
 // "XCD x writes the chunks with (chunk id % 8) == x" -- measured on MI355X: 7.1 TB/s for that
-// assignment vs 5.8 TB/s when the classes are mixed across XCDs (profiles/r01/write_patterns.txt).
+// assignment vs 5.8 TB/s when the classes are mixed across XCDs (profiles/r01/sweep_pattern.txt, sweep_perm.txt).
 // The mapping only affects speed, never results.
 //
 // One wave = one chunk at a time: load the ~4096/(C*sizeof(T)) tokens whose rows intersect the chunk
@@ -1087,11 +1088,19 @@ __global__ __launch_bounds__(kThreads) void k_xcd_probe(int32_t *xcd) {
     if (threadIdx.x == 0) xcd[blockIdx.x] = static_cast<int32_t>(id & 0xFu);
 }
 
-__global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offsets, int64_t B, int64_t room,
+// first_bad[0]: first sequence longer than `room`; first_bad[1]: first entry i with offsets[i] > offsets[i + 1],
+// offsets[0] < 0 (reported as 0) or offsets[B] > nchars (reported as B) -- only checked when nchars >= 0.
+__global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offsets, int64_t B, int64_t room, int64_t nchars,
                                                              unsigned long long *first_bad) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < B; i += stride)
-        if (offsets[i + 1] - offsets[i] > room) atomicMin(first_bad, static_cast<unsigned long long>(i));
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < B; i += stride) {
+        const int64_t lo = offsets[i], hi = offsets[i + 1];
+        if (hi - lo > room) atomicMin(first_bad, static_cast<unsigned long long>(i));
+        if (nchars >= 0) {
+            if (hi < lo || (i == 0 && lo < 0)) atomicMin(first_bad + 1, static_cast<unsigned long long>(i));
+            if (i == B - 1 && hi > nchars) atomicMin(first_bad + 1, static_cast<unsigned long long>(B));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1832,13 +1841,51 @@ bsq_status bsq_xcd_of_blocks_device(int32_t *xcd_dev, int32_t nblocks, void *hip
     return check_launch("k_xcd_probe");
 }
 
+int32_t bsq_xcd_round_robin(void) {
+    static int cached[16] = {};  // 0 unknown, 1 no, 2 yes
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    if (cached[dev]) return cached[dev] - 1;
+    constexpr int n = 256;
+    int32_t *d = nullptr;
+    int32_t h[n];
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(int32_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_xcd_probe, dim3(n), dim3(kThreads), 0, nullptr, d);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    bool ok = true;
+    for (int b = 0; b + 8 < n; ++b) ok = ok && h[b] == h[b + 8];
+    uint32_t seen = 0;
+    for (int b = 0; b < 8; ++b) seen |= 1u << (h[b] & 15);
+    ok = ok && __builtin_popcount(seen) == 8;
+    cached[dev] = ok ? 2 : 1;
+    return ok ? 1 : 0;
+}
+
 bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos,
                                        int32_t eos, int64_t *first_bad, void *hip_stream) {
+    return bsq_validate_packed_device(offsets_dev, B, P, bos, eos, -1, first_bad, hip_stream);
+}
+
+bsq_status bsq_validate_packed_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos, int32_t eos,
+                                      int64_t nchars, int64_t *first_bad, void *hip_stream) {
     if (!offsets_dev || B < 0 || P <= 0 || !first_bad) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
     *first_bad = -1;
     if (B == 0) return BSQ_OK;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    // one 8-byte flag per device, allocated once (a hipMalloc/hipFree pair per call costs ~25 us)
+    // two 8-byte flags per device, allocated once (a hipMalloc/hipFree pair per call costs ~25 us)
     static unsigned long long *flags[16] = {};
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);  // the flag is shared: one validation at a time per process
@@ -1847,22 +1894,26 @@ bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, in
     if (e != hipSuccess) return bsq_internal::set_hip_error("hipGetDevice", e);
     if (dev < 0 || dev >= 16) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "device ordinal out of range");
     if (!flags[dev]) {
-        e = hipMalloc(reinterpret_cast<void **>(&flags[dev]), sizeof(unsigned long long));
+        e = hipMalloc(reinterpret_cast<void **>(&flags[dev]), 2 * sizeof(unsigned long long));
         if (e != hipSuccess) return bsq_internal::set_hip_error("hipMalloc", e);
     }
     unsigned long long *flag = flags[dev];
-    e = hipMemsetAsync(flag, 0xFF, sizeof(*flag), s);
+    e = hipMemsetAsync(flag, 0xFF, 2 * sizeof(*flag), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_first_too_long, dim3(generic_grid(B)), dim3(kThreads), 0, s, offsets_dev, B,
-                           P - (bos != 0) - (eos != 0), flag);
+                           P - (bos != 0) - (eos != 0), nchars, flag);
         e = hipGetLastError();
     }
-    unsigned long long host = ~0ull;
-    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(host), hipMemcpyDeviceToHost, s);
+    unsigned long long host[2] = {~0ull, ~0ull};
+    if (e == hipSuccess) e = hipMemcpyAsync(host, flag, sizeof(host), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return bsq_internal::set_hip_error("bsq_validate_lengths_device", e);
-    if (host != ~0ull) {
-        *first_bad = static_cast<int64_t>(host);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("bsq_validate_packed_device", e);
+    if (host[1] != ~0ull) {
+        *first_bad = static_cast<int64_t>(host[1]);
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "offsets are negative, decreasing or run past the end of chars");
+    }
+    if (host[0] != ~0ull) {
+        *first_bad = static_cast<int64_t>(host[0]);
         return BSQ_ERR_SEQ_TOO_LONG;
     }
     return BSQ_OK;

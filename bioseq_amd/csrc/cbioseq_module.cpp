@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "bsq.h"
+#include "bsq_diag.h"
 
 namespace py = pybind11;
 
@@ -282,7 +283,9 @@ void make_out(OutBuf &o, const std::vector<py::ssize_t> &shape, bsq_dtype t, con
         throw std::invalid_argument("device= must be a HIP ('cuda') device; omit it for a numpy result");
     o.guard = torch.attr("cuda").attr("device")(dev);
     o.guard.attr("__enter__")();
-    py::object ten = torch.attr("empty")(py::cast(shape), py::arg("dtype") = torch.attr(numpy_dtype_name(t)),
+    // 'l' / 'q' results are uint64 in numpy (the reference's type); as device tensors they are torch.int64 -- same
+    // bits for token ids and 0/1, and torch.uint64 does not exist before torch 2.3 and supports almost no ops after
+    py::object ten = torch.attr("empty")(py::cast(shape), py::arg("dtype") = torch.attr(t == BSQ_U64 ? "int64" : numpy_dtype_name(t)),
                                          py::arg("device") = dev);
     o.ptr = reinterpret_cast<void *>(ten.attr("data_ptr")().cast<uintptr_t>());
     o.stream = reinterpret_cast<void *>(torch.attr("cuda").attr("current_stream")().attr("cuda_stream").cast<uintptr_t>());
@@ -303,8 +306,8 @@ ArrayArg as_array(const py::object &o, const char *np_dtype, size_t itemsize, co
     if (py::hasattr(o, "data_ptr") && py::hasattr(o, "is_cuda")) {  // torch tensor
         py::object t = o;
         if (!t.attr("is_contiguous")().cast<bool>()) t = t.attr("contiguous")();
-        if (size_t(t.attr("element_size")().cast<int64_t>()) != itemsize)
-            throw std::invalid_argument(std::string(what) + ": wrong element size");
+        if (py::str(t.attr("dtype")).cast<std::string>() != std::string("torch.") + np_dtype)
+            throw std::invalid_argument(std::string(what) + ": expected a torch." + np_dtype + " tensor");
         a.on_device = t.attr("is_cuda").cast<bool>();
         a.ptr = reinterpret_cast<const void *>(t.attr("data_ptr")().cast<uintptr_t>());
         a.n = t.attr("numel")().cast<int64_t>();
@@ -355,10 +358,14 @@ class Tokenizer {
         if (padlen <= 0) throw std::invalid_argument("batch tokenize requires padlen is provded.");
     }
 
-    [[noreturn]] void throw_too_long(const int64_t *offsets, int64_t bad, py::ssize_t padlen) const {
+    // The reference throws std::runtime_error from batch_tokenize (tokenize.h:456-459) and std::invalid_argument from
+    // batch_onehot_encode (:359-362) -- inside an OpenMP region, so its process aborts; here they reach Python as
+    // RuntimeError / ValueError with the reference's text.
+    [[noreturn]] void throw_too_long(const int64_t *offsets, int64_t bad, py::ssize_t padlen, bool onehot) const {
         const int64_t tl = offsets[bad + 1] - offsets[bad] + desc.bos + desc.eos;
-        throw std::invalid_argument("seq len + bos + eos > padlen: " + std::to_string(tl) + ", vs padlen " +
-                                    std::to_string(padlen));
+        const std::string msg = "seq len + bos + eos > padlen: " + std::to_string(tl) + ", vs padlen " + std::to_string(padlen);
+        if (onehot) throw std::invalid_argument(msg);
+        throw std::runtime_error(msg);
     }
 
     // batch_tokenize (tokenize.cpp:82-98 -> tokenize.h:381-485)
@@ -382,7 +389,7 @@ class Tokenizer {
             st = bsq_tokenize_host(&desc, p.chars, p.offsets, p.B, padlen, batch_first, t, out.ptr, out.space,
                                    out.stream, &bad);
         }
-        if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(p.offsets, bad, padlen);
+        if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(p.offsets, bad, padlen, false);
         if (st != BSQ_OK) throw_status(st);
         return out.obj;
     }
@@ -425,7 +432,7 @@ class Tokenizer {
             std::fprintf(stderr, "[bsq host] gather %ld us, output alloc %ld us, pack %ld us, upload+launch %ld us\n", us(t0, t1),
                          us(t1, t2), us(t2, t3), us(t3, t4));
         }
-        if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(p.offsets, bad, padlen);
+        if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(p.offsets, bad, padlen, true);
         if (st != BSQ_OK) throw_status(st);
         return out.obj;
     }
@@ -470,7 +477,10 @@ class Tokenizer {
             {
                 py::gil_scoped_release nogil;
                 st = BSQ_OK;
-                if (validate) st = bsq_validate_lengths_device(offs, B, padlen, desc.bos, desc.eos, &bad, out.stream);
+                // validate=True also checks the offsets themselves (non-negative, non-decreasing, inside chars): the
+                // kernels bound their reads by offsets[B], not by the real size of the buffer.  validate=False is an
+                // unchecked contract: the caller vouches for well-formed offsets and lengths <= padlen - bos - eos.
+                if (validate) st = bsq_validate_packed_device(offs, B, padlen, desc.bos, desc.eos, chars.n, &bad, out.stream);
                 if (st == BSQ_OK)
                     st = onehot ? (bcl ? bsq_onehot_bcl_device : bsq_onehot_device)(
                                       &desc, static_cast<const uint8_t *>(chars.ptr), offs,
@@ -479,10 +489,13 @@ class Tokenizer {
                                 : bsq_tokenize_device(&desc, static_cast<const uint8_t *>(chars.ptr), offs, B, padlen,
                                                       batch_first, t, out.ptr, out.stream);
             }
+            if (st == BSQ_ERR_INVALID_ARG && bad >= 0)
+                throw std::invalid_argument("offsets must be non-negative, non-decreasing and end inside chars (first bad entry: " +
+                                            std::to_string(bad) + ")");
             if (st == BSQ_ERR_SEQ_TOO_LONG) {
                 py::object pair = offsets.keep.attr("__getitem__")(py::slice(bad, bad + 2, 1)).attr("tolist")();
                 bad_pair = pair.cast<std::vector<int64_t>>();
-                throw_too_long(bad_pair.data(), 0, padlen);
+                throw_too_long(bad_pair.data(), 0, padlen, onehot);
             }
         } else {
             const int64_t *offs = static_cast<const int64_t *>(offsets.ptr);
@@ -498,7 +511,7 @@ class Tokenizer {
                             : bsq_tokenize_host(&desc, static_cast<const uint8_t *>(chars.ptr), offs, B, padlen,
                                                 batch_first, t, out.ptr, out.space, out.stream, &bad);
             }
-            if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(offs, bad, padlen);
+            if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(offs, bad, padlen, onehot);
         }
         if (st != BSQ_OK) throw_status(st);
         return out.obj;

@@ -87,8 +87,20 @@ class FlatFileDataset(torch.utils.data.Dataset):
         """Sequences [start, stop) as one encoded batch on the device."""
         return self._encode(*self._packed_device(start, stop))
 
+    def _index(self, i):
+        """Python indexing: -len <= i < len, else IndexError (the reference's ff.access raises out_of_range; a silent
+        wrap would also make `for x in ds` -- the legacy iteration protocol -- run forever)."""
+        n = len(self)
+        i = int(i)
+        if not -n <= i < n:
+            raise IndexError("index %d is out of range for %d sequences" % (i, n))
+        return i + n if i < 0 else i
+
     def __getitems__(self, indices):
-        idx = [int(i) % len(self) for i in indices]
+        """One encoded batch ON THE DEVICE for the whole index list -- a single stacked tensor, not a list of samples:
+        use `DataLoader(ds, batch_size=..., collate_fn=lambda batch: batch, num_workers=0)` (the default collate would
+        re-stack it with a copy, and device tensors cannot cross worker processes)."""
+        idx = [self._index(i) for i in indices]
         if idx and idx == list(range(idx[0], idx[0] + len(idx))):
             return self.get_batch(idx[0], idx[-1] + 1)
         return self._encode(*self._packed_device(0, 0, idx))
@@ -97,7 +109,7 @@ class FlatFileDataset(torch.utils.data.Dataset):
         if isinstance(index, slice):
             s, e, st = index.indices(len(self))
             return self.__getitems__(list(range(s, e, st)))
-        index = int(index) % len(self)
+        index = self._index(index)
         return self.get_batch(index, index + 1)[0]
 
     def access(self, slc, stop=None, step=None):

@@ -13,6 +13,9 @@
  *     offsets : int64[B + 1]   sequence i is chars[offsets[i] .. offsets[i+1])
  *     mask    : uint8[total] or NULL, one byte per input character, same offsets
  *
+ * Measurement / diagnostic exports (tuning knobs, write-bandwidth yardsticks, self-tests) are declared in
+ * bsq_diag.h, not here: they are not part of the drop-in surface.
+ *
  * Output layouts (C-contiguous, bit-exact with the reference's numpy results):
  *     bsq_tokenize_* : (B, P) when batch_first else (P, B)       -- tokenize.h:420-425
  *     bsq_onehot_*   : (P, B, C), C = bsq_alphabet_size(desc)    -- tokenize.h:326-330
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSQ_ABI_VERSION 1
+#define BSQ_ABI_VERSION 2
 
 typedef int32_t bsq_status;
 enum {
@@ -66,13 +69,6 @@ const char *bsq_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int32_t bsq_device_count(void);
 
-/* Tuning / diagnostic knobs (kernel variants for A/B measurements; results never change).
- * Names: "nt_stores", "onehot_tb", "tile_order", "fill_mode", "onehot_path", "expand_pad", "chunks_cpw", "tokenize_path",
- * "chunks_pad", "fill_pad", "tokenize_pad", "tokenize_nch", "expand_slots", "host_copy_threads".  Environment variables
- * BSQ_NT_STORES etc. give the initial values. */
-bsq_status bsq_tuning_set(const char *name, int32_t value);
-int32_t bsq_tuning_get(const char *name);
-
 /* ---- alphabets: replaces alph::CAMAP + TAlphabet::make_lut (alphabet.h:32-61,198-222) ---- */
 int32_t bsq_num_keys(void);
 const char *bsq_key_name(int32_t i);
@@ -96,6 +92,12 @@ bsq_status bsq_validate_lengths(const int64_t *offsets, int64_t B, int64_t P, in
 /* offsets in device memory; runs a reduction kernel on `hip_stream` and synchronises it. */
 bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos,
                                        int32_t eos, int64_t *first_bad, void *hip_stream);
+
+/* The same plus the well-formedness of the offsets themselves: offsets[0] >= 0, non-decreasing, offsets[B] <= nchars
+ * (the kernels bound their reads by offsets[B]).  BSQ_ERR_INVALID_ARG with *first_bad = the first offending entry, or
+ * BSQ_ERR_SEQ_TOO_LONG with *first_bad = the first over-long sequence; malformed offsets are reported first. */
+bsq_status bsq_validate_packed_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos, int32_t eos,
+                                      int64_t nchars, int64_t *first_bad, void *hip_stream);
 
 /* ---- device entry points: every pointer is device memory; stream-ordered; never synchronise.
  * Over-long sequences are clamped inside the kernels (memory-safe); call a validate function
@@ -126,15 +128,6 @@ bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, 
 bsq_status bsq_onehot_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                      const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                                      void *hip_stream);
-/* Streaming fill of nbytes (multiple of 16, 16-byte aligned) with a 32-bit pattern: the
- * write-bandwidth yardstick bench.py reports next to the encode kernels. */
-bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip_stream);
-/* Diagnostic: writes a (rows x pitch bytes) matrix with the tiled one-hot kernel's store pattern and none
- * of its work -- block (cb, rb) owns `seg` contiguous bytes of 4*rows_per_wave rows, one wave per
- * rows_per_wave rows.  Used by scripts/sweep_pattern.py to separate pattern cost from kernel cost. */
-bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32_t seg, int32_t rows_per_wave,
-                                   int32_t order, int32_t interleave, int32_t nt, void *hip_stream);
-
 /* The two passes of the large-output one-hot path on their own (distributed assembly: ship the small token
  * matrices over xGMI and expand at the destination -- 1/(C*sizeof(T)) of the one-hot's bytes, e.g. 1/80 at cfg3):
  * bsq_raw_tokens_device       -> tokens[t * pitch + b] = id at position t of sequence b (tokenize.h:342-369
@@ -149,14 +142,6 @@ bsq_status bsq_raw_tokens_device(const bsq_desc *d, const uint8_t *chars, const 
                                  void *hip_stream);
 bsq_status bsq_onehot_from_raw_tokens_device(const uint8_t *tokens, int64_t pitch, int64_t B, int64_t P, int32_t C,
                                              bsq_dtype t, void *out, void *hip_stream);
-
-/* Host-only self-test of the kernels' division-free index arithmetic (reciprocal multiplies instead of integer
- * divisions; the same inline functions run on the device): 0 = every case exact. */
-int64_t bsq_selftest_index_math(void);
-
-/* Diagnostic: xcd_dev[b] = id (0..7) of the XCD block b of an nblocks-block 1-D launch ran on.  The chunk
- * kernels assume -- for speed only, never for results -- that blocks b and b + 8 share an XCD. */
-bsq_status bsq_xcd_of_blocks_device(int32_t *xcd_dev, int32_t nblocks, void *hip_stream);
 
 /* ---- BLOSUM62 augmentation (the pre-step of BASELINE config 5): replaces bioseq/blosum.py:36-87.
  * bsq_blosum62_normrows: the 21x20 float64 transition table `normrows` (rows ARNDCQEGHILKMFPSTWYV+X,

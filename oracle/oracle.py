@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- ctypes front-end of the CPU oracle (oracle/bsq_oracle.c).
 
 Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
-bioseq_amd/ never imports this module (tests/test_layout.py greps for that).
+bioseq_amd/ never imports this module (tests/test_abi_and_layout.py greps for that).
 
 ``OracleTokenizer`` mirrors the Python surface of the reference's ``cbioseq.Tokenizer``
 (/root/reference/src/tokenize.cpp:22-112) for the batch entry points so parity tests can call

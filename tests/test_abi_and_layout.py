@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads and exports every symbol include/bsq.h declares; host-only ABI calls
+"""CPU: the C-ABI library loads and exports every symbol include/bsq.h and include/bsq_diag.h declare; host-only ABI calls
 behave; repository layout rules (the product never touches the oracle; no reference sources)."""
 import ctypes
 import os
@@ -17,7 +17,9 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25 and "bsq_onehot_device" in names and "bsq_tokenize_host" in names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.bsq_abi_version() == 1
+    assert lib.bsq_abi_version() == 2
+    product = capi.declared_symbols(capi.HEADER_PATH)  # the drop-in surface holds no knobs / yardsticks / probes
+    assert not [n for n in product if 'tuning' in n or 'fill' in n or 'selftest' in n or 'xcd' in n]
 
 
 def test_host_only_abi_calls(alphabets_golden):

@@ -48,6 +48,13 @@ def test_dataset_batches_match_per_item_reference_semantics(gpu, bsq, oracle, tm
     assert (ds[7].cpu().numpy() == exp_tok[7]).all() and tuple(ds[7].shape) == (P,)           # reference item shape
     assert (ds.__getitems__([5, 499, 17]).cpu().numpy() == exp_tok[[5, 499, 17]]).all()       # scattered indices
     assert (ds[10:20].cpu().numpy() == exp_tok[10:20]).all()
+    assert (ds[-1].cpu().numpy() == exp_tok[499]).all()                                        # Python indexing ...
+    for bad in (500, -501, 10 ** 6):                                                           # ... never a silent wrap
+        with pytest.raises(IndexError):
+            ds[bad]
+    with pytest.raises(IndexError):
+        ds.__getitems__([1, 500])
+    assert sum(1 for _ in ds) == 500                                                           # legacy iteration ends
     dl = torch.utils.data.DataLoader(ds, batch_size=64, shuffle=False, collate_fn=lambda x: x)
     got = torch.cat([x for x in dl]).cpu().numpy()
     assert (got == exp_tok).all()
