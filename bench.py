@@ -2,6 +2,7 @@
 """bench.py -- headline benchmark of the hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4f|cfg4b|cfg5]
+                    [--scaling weak|strong] [--gather K]
 
 A "step" is ONE pass of the hot path over one batch of synthetic input that is already resident
 in HBM (packed chars + offsets on the device, output preallocated): for the default workload
@@ -9,7 +10,10 @@ in HBM (packed chars + offsets on the device, output preallocated): for the defa
 len ~ U(50,1024), padlen 1024 -> float32 (1024, 65536, 20) = 5.37 GB, through the C ABI entry
 point bsq_onehot_device.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every
 rank encodes its own 65 536-sequence shard of an N x 65 536 batch -- sequences are independent, so
-there is no data-path collective (weak scaling) -- and `value` is the whole-job rate.
+there is no data-path collective (weak scaling) -- and `value` is the whole-job rate.  `--scaling strong`
+splits ONE batch of the workload's size over the ranks instead (sharding.shard_bounds: BASELINE config 4 is
+"1M reads, 1 vs 8 GPU shard + RCCL gather" -> --workload cfg4f --scaling strong --gather 3); `--gather K`
+additionally times the whole-batch assembly over xGMI in each of its forms, never as part of `value`.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      algorithmic bytes per launch / average kernel duration (HIP events on the launch
@@ -54,36 +58,44 @@ def baseline_metric():
 
 
 def cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, cap_threads=None):
-    """Time the reference CPU path once on the full batch (bounded: one call)."""
+    """Time the reference CPU path on this box's host cores (bounded: two calls): all cores on the full batch --
+    the headline `value` -- and nthreads=1 (BASELINE.md section 4 asks for both) on the first eighth of it."""
     from bioseq_amd import synth
     from oracle import oracle as O  # checker / baseline only -- never on the product path
     cores = os.cpu_count() or 1
     nthreads = min(cores, cap_threads) if cap_threads else cores
     P = cfg["padlen"]
     ref = O.load_reference()
-    total = int(offsets[-1])
     if ref is not None:
         kind = "reference"
         tok = ref.Tokenizer(cfg["key"], bool(cfg["eos"]), bool(cfg["bos"]), bool(cfg["padchar"]))
-        seqs = synth.unpack(chars, offsets)
-        t0 = time.perf_counter()
-        if op == "onehot":
-            out = tok.batch_onehot_encode(seqs, padlen=P, destchar=destchar, nthreads=nthreads)
-        else:
-            out = tok.batch_tokenize(seqs, padlen=P, destchar=destchar, batch_first=batch_first, nthreads=nthreads)
-        dt = time.perf_counter() - t0
     else:
         kind = "port"
         O.build()
         tok = O.OracleTokenizer(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
+
+    def run(c, o, nt):
+        seqs = synth.unpack(c, o) if ref is not None else None  # the reference's API takes Python objects: untimed
         t0 = time.perf_counter()
-        if op == "onehot":
-            out = tok.onehot_packed(chars, offsets, P, destchar, nthreads)
+        if ref is not None:
+            if op == "onehot":
+                out = tok.batch_onehot_encode(seqs, padlen=P, destchar=destchar, nthreads=nt)
+            else:
+                out = tok.batch_tokenize(seqs, padlen=P, destchar=destchar, batch_first=batch_first, nthreads=nt)
         else:
-            out = tok.tokenize_packed(chars, offsets, P, destchar, batch_first, nthreads)
+            if op == "onehot":
+                out = tok.onehot_packed(c, o, P, destchar, nt)
+            else:
+                out = tok.tokenize_packed(c, o, P, destchar, batch_first, nt)
         dt = time.perf_counter() - t0
-    nbytes = out.nbytes
-    del out
+        return dt, out.nbytes
+
+    B = len(offsets) - 1
+    total = int(offsets[-1])
+    dt, nbytes = run(chars, offsets, nthreads)
+    B1 = max(1, B // 8)
+    c1, o1 = chars[:int(offsets[B1])], offsets[:B1 + 1]
+    dt1, nbytes1 = run(c1, o1, 1)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -92,9 +104,14 @@ def cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, cap_threads=Non
         pass
     return {"cpu_model": model, "value": total / dt / 1e9, "unit": "Gseq-chars/s", "cores": nthreads, "kind": kind,
             "gb_per_s_written": nbytes / dt / 1e9, "seconds": dt, "host_cpus": cores,
+            "opt": "-O3 without -march=native (oracle/Makefile); the reference itself ships -O0 -march=native (setup.py:50-55)",
             "sample": "the full batch of this workload (%d sequences, %d chars, %.2f GB output), one call incl. "
                       "result allocation as the reference does per call, nthreads=%d"
-                      % (len(offsets) - 1, total, nbytes / 1e9, nthreads)}
+                      % (B, total, nbytes / 1e9, nthreads),
+            "single_thread": {"value": int(o1[-1]) / dt1 / 1e9, "unit": "Gseq-chars/s", "cores": 1,
+                              "gb_per_s_written": nbytes1 / dt1 / 1e9, "seconds": dt1,
+                              "sample": "the first %d sequences of the batch (%d chars, %.2f GB output), nthreads=1"
+                                        % (B1, int(o1[-1]), nbytes1 / 1e9)}}
 
 
 def main():
@@ -105,9 +122,13 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap the CPU baseline's thread count")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: every rank encodes a batch of the workload's size (default); strong: ONE batch of that "
+                         "size is split over the ranks by sequence (sharding.shard_bounds)")
     ap.add_argument("--gather", type=int, default=0, metavar="K",
-                    help="N > 1 only: additionally time K whole-batch assemblies (RCCL all-gather of the shards over "
-                         "xGMI); reported separately as `gather`, never part of `value`")
+                    help="N > 1 only: additionally time K whole-batch assemblies over xGMI in every form (all_gather + "
+                         "concatenate, grouped point-to-point straight into the destination, to a root and to every "
+                         "rank, token matrices + local expansion); reported separately as `gather`, never part of `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,9 +163,19 @@ def main():
 
     cfg_name, op, destchar, batch_first = WORKLOADS[args.workload]
     cfg = synth.CONFIGS[cfg_name]
-    n, P = cfg["n"], cfg["padlen"]
-    # rank r owns sequences [r*n, (r+1)*n) of the N*n-sequence stream (weak scaling)
-    chars, offsets = synth.synth_packed(cfg["seed"], n, cfg["lo"], cfg["hi"], cfg["letters"], first=rank * n)
+    P = cfg["padlen"]
+    if args.scaling == "strong":
+        # ONE batch of cfg["n"] sequences, rank r owns the contiguous range shard_bounds gives it
+        from bioseq_amd.sharding import shard_bounds
+        n_job = cfg["n"]
+        first, stop = shard_bounds(n_job, world, rank)
+        n = stop - first
+    else:
+        # rank r owns sequences [r*n, (r+1)*n) of the N*n-sequence stream (weak scaling)
+        n = cfg["n"]
+        n_job = n * world
+        first = rank * n
+    chars, offsets = synth.synth_packed(cfg["seed"], n, cfg["lo"], cfg["hi"], cfg["letters"], first=first)
     total = int(offsets[-1])
 
     lib = capi.load()
@@ -239,46 +270,51 @@ def main():
     gather_info = None
     if world > 1 and args.gather > 0:
         from bioseq_amd import sharding
-        gms = []
-        for _ in range(args.gather + 1):
-            barrier()
-            g0 = time.perf_counter()
-            if op in ("onehot",):
-                full = sharding.gather_onehot(out, n * world)
-            elif op == "onehot_bcl":
-                full = sharding.gather_tokens(out, n * world, True)   # (B,C,P): shards are contiguous slabs
-            else:
-                full = sharding.gather_tokens(out, n * world, batch_first)
-            barrier()
-            gms.append((time.perf_counter() - g0) * 1e3)
-            assert full.shape[1 if (op == "onehot" or (op == "tokenize" and not batch_first)) else 0] == n * world
-            del full
-        gms = gms[1:]  # first one warms RCCL up
-        gt = torch.tensor([float(np.mean(gms))], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-        gather_info = {"ms": float(gt.item()), "bytes_received_per_rank": out_bytes * (world - 1),
-                       "gb_per_s_into_each_rank": out_bytes * (world - 1) / (float(gt.item()) * 1e-3) / 1e9,
-                       "what": "all_gather of every rank's shard into a staging list + concatenation along the batch axis "
-                               "(whole batch on every rank); encode time excluded"}
+        seq_first = op == "onehot" or (op == "tokenize" and not batch_first)
+        axis = 1 if seq_first else 0
+        out_c = out.contiguous() if backend == "nccl" else out.cpu().contiguous()  # gloo smoke runs move host tensors
+
+        def timed(fn, check_axis=None):
+            ms = []
+            for _ in range(args.gather + 1):
+                barrier()
+                g0 = time.perf_counter()
+                full = fn()
+                barrier()
+                ms.append((time.perf_counter() - g0) * 1e3)
+                if full is not None and check_axis is not None:
+                    assert full.shape[check_axis] == n_job, (tuple(full.shape), n_job)
+                del full
+            t = torch.tensor([float(np.mean(ms[1:]))], dtype=torch.float64, device=red_dev)  # first one warms RCCL up
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        shard_bytes = torch.tensor([float(out_bytes)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(shard_bytes, op=dist.ReduceOp.SUM)
+        recv_bytes = float(shard_bytes.item()) - out_bytes
+        forms = {}
+        forms["all_gather"] = {"ms": timed(lambda: sharding._gather(out_c, axis, n_job), axis),
+                               "what": "all_gather of every rank's shard (RCCL picks the algorithm) + concatenation along the "
+                                       "batch axis for seq-first layouts; whole batch on every rank"}
+        forms["direct_all"] = {"ms": timed(lambda: sharding.gather_direct(out_c, axis, n_job, None), axis),
+                               "what": "grouped isend/irecv, one peer per xGMI link, received straight into the destination "
+                                       "(one message per peer, or per peer and position row for seq-first layouts); whole "
+                                       "batch on every rank"}
+        forms["direct_root"] = {"ms": timed(lambda: sharding.gather_direct(out_c, axis, n_job, 0), None),
+                                "what": "the same to rank 0 only (the gather north_star names)"}
         if op == "onehot" and backend == "nccl":
             # the xGMI-friendly form: only the uint8 token matrices travel, every rank expands the whole batch itself
             import bioseq_amd as _pkg
             tokz = _pkg.Tokenizer(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
             raw_tokens, expand = sharding.device_passes(tokz, P, destchar, dev)
-            tms = []
-            for _ in range(args.gather + 1):
-                barrier()
-                g0 = time.perf_counter()
-                full = expand(sharding.gather_tokens(raw_tokens(d_chars, d_offs), n * world, False).contiguous())
-                barrier()
-                tms.append((time.perf_counter() - g0) * 1e3)
-                assert tuple(full.shape) == (P, n * world, C)
-                del full
-            tt = torch.tensor([float(np.mean(tms[1:]))], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            gather_info["via_tokens_ms"] = float(tt.item())
-            gather_info["via_tokens_what"] = ("token pass on the shard + all_gather of the (P, B_g) uint8 token matrices (%d bytes "
-                                              "received per rank) + local expansion of the whole batch" % (P * n * (world - 1)))
+            forms["via_tokens"] = {
+                "ms": timed(lambda: expand(sharding.gather_direct(raw_tokens(d_chars, d_offs), 1, n_job, None).contiguous()), 1),
+                "what": "token pass on the shard + point-to-point gather of the (P, B_g) uint8 token matrices (%d bytes "
+                        "received per rank) + local expansion of the whole batch" % int(recv_bytes / max(1, C * sz))}
+        for f in forms.values():
+            f["gb_per_s_into_each_rank"] = recv_bytes / (f["ms"] * 1e-3) / 1e9
+        gather_info = {"bytes_received_per_rank": recv_bytes, "forms": forms, "note": "encode time excluded; mean of %d "
+                       "assemblies after one warm-up, MAX over ranks" % args.gather}
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
     tot_t = torch.tensor([float(total), float(out_bytes)], dtype=torch.float64, device=red_dev)
@@ -298,7 +334,8 @@ def main():
             except Exception:
                 traffic = None
         kernel_name = (lib.bsq_onehot_kernel_name(ctypes.byref(desc), n, P, dt_code).decode() if op == "onehot"
-                       else ("k_tokenize_chunks" if batch_first else "k_tokenize_tile"))
+                       else (("k_tokens_bp8" if sz == 1 and P >= 128 and P % 16 == 0 else "k_tokenize_chunks")
+                             if batch_first else "k_tokenize_tile"))
         if op == "augment+tokenize":
             kernel_name = "k_augment+" + kernel_name
         if op == "onehot_bcl":
@@ -311,16 +348,25 @@ def main():
             "gb_per_s_written": job_out_bytes * args.steps / wall_max / 1e9,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"f": "f32", "B": "u8"}.get(destchar, destchar), "data": "synthetic",
             "config": {"workload": "%s: %s %s, %d seqs/GPU len~U(%d,%d), padlen %d, C=%d, %s output %s" % (
                 args.workload, cfg["key"], {"onehot": "batch_onehot_encode", "tokenize": "batch_tokenize", "onehot_bcl": "batch_onehot_encode(layout=bcl)"}.get(op, "BLOSUM62 augment + batch_tokenize"), n,
                 cfg["lo"], cfg["hi"], P, C, str(tdt).replace("torch.", ""),
                 "(P,B,C)" if op == "onehot" else "(B,C,P)" if op == "onehot_bcl" else ("(B,P)" if batch_first else "(P,B)")),
                 "sequences_per_gpu": n, "padlen": P, "channels": C, "input_chars_per_gpu": total,
-                "output_bytes_per_gpu": out_bytes, "sharding": "by sequence, no collective"},
+                "output_bytes_per_gpu": out_bytes,
+                "sharding": ("by sequence, no collective; weak scaling: every rank encodes its own %d-sequence batch" % n)
+                            if args.scaling == "weak" else
+                            ("by sequence, no collective; strong scaling: ONE %d-sequence batch split over %d ranks "
+                             "(sharding.shard_bounds; rank 0 holds %d)" % (n_job, world, n)),
+                "job_sequences": n_job,
+                "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+                "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel_name,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "frac_wall": algo_bytes / (wall_max / args.steps) / 1e9 / HBM_PEAK_GBPS,  # from ms_per_step (host clock)
+                         "traffic": traffic, "kernel": kernel_name,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_avg_ms": kern_avg_ms,
                          "kernel_min_ms": float(np.min(kern_ms)), "kernel_median_ms": float(np.median(kern_ms)),
                          "fill_yardstick_gbps": fill_gbps,

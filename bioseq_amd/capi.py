@@ -80,6 +80,9 @@ def load():
         "bsq_selftest_index_math": (i64, []),
         "bsq_raw_tokens_device": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, vp]),
         "bsq_onehot_from_raw_tokens_device": (i32, [vp, i64, i64, i64, i32, i32, vp, vp]),
+        "bsq_decode_sizes_device": (i32, [dp, vp, i32, i64, i64, i64, i64, vp, i64p, i64p, vp]),
+        "bsq_decode_write_device": (i32, [dp, vp, i32, i64, i64, i64, i64, vp, vp, vp]),
+        "bsq_argmax_tokens_device": (i32, [vp, i32, i64, i32, i64, vp, i32, vp]),
         "bsq_blosum62_normrows": (i32, [vp]),
         "bsq_augment_device": (i32, [vp, vp, i64, i32, ctypes.c_double, ctypes.c_uint64, vp]),
         "bsq_tokenize_host": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, c_int, vp, i64p]),

@@ -542,7 +542,52 @@ class Tokenizer {
             for (; r < padlen; ++r) ptr[r * C + bsq_pad_id(&desc)] = T(1);
         return ret;
     }
-    py::object onehot_single(const char *s, py::ssize_t L, py::ssize_t padlen, const std::string &dt) const {
+    // Single-sequence one-hot ON THE DEVICE (device=...): the batch kernel with B = 1 and P = rows writes BOS, the
+    // residues, EOS and PAD rows; the reference pads only the rows below `padlen` (tokenize.h:208-212), so the rows
+    // from max(padlen, L + bos + eos) on are zeroed again.  Returns a torch tensor (rows, C) of uint8 / int16 / int32 /
+    // float32 / float64 (the 16- and 32-bit unsigned types of the host path have no usable torch dtype: same bits).
+    py::object onehot_single_device(const char *s, py::ssize_t L, py::ssize_t padlen, const std::string &dt,
+                                    const py::object &device) const {
+        if (padlen > 0 && L > padlen) throw std::runtime_error("padlen is too short to accommodate sequence\n");
+        bsq_dtype t;
+        const char *tname;
+        switch (dt.empty() ? 0 : (dt[0] & 223)) {
+        case 'B': t = BSQ_I8, tname = "uint8"; break;
+        case 'H': t = BSQ_I16, tname = "int16"; break;
+        case 'I': t = BSQ_I32, tname = "int32"; break;
+        case 'F': t = BSQ_F32, tname = "float32"; break;
+        case 'D': t = BSQ_F64, tname = "float64"; break;
+        default: throw std::invalid_argument(std::string("Unsupported dtype: ") + dt);
+        }
+        py::module_ torch = py::module_::import("torch");
+        py::object dev = torch.attr("device")(device);
+        if (dev.attr("type").cast<std::string>() != "cuda")
+            throw std::invalid_argument("device= must be a HIP ('cuda') device; omit it for a numpy result");
+        const py::ssize_t C = bsq_alphabet_size(&desc);
+        const py::ssize_t rows = std::max(L, padlen) + desc.bos + desc.eos;
+        py::object out = torch.attr("empty")(py::make_tuple(rows, C), py::arg("dtype") = torch.attr(tname), py::arg("device") = dev);
+        if (rows == 0) return out;
+        // packed batch of one sequence: offsets | chars in one small host tensor -> device
+        py::array_t<uint8_t> host(py::ssize_t(16 + L));
+        int64_t offs[2] = {0, int64_t(L)};
+        std::memcpy(host.mutable_data(), offs, 16);
+        if (L) std::memcpy(host.mutable_data() + 16, s, size_t(L));
+        py::object packed = torch.attr("from_numpy")(host).attr("to")(dev);
+        const uintptr_t base = packed.attr("data_ptr")().cast<uintptr_t>();
+        py::object guard = torch.attr("cuda").attr("device")(dev);
+        guard.attr("__enter__")();
+        void *stream = reinterpret_cast<void *>(torch.attr("cuda").attr("current_stream")().attr("cuda_stream").cast<uintptr_t>());
+        const bsq_status st = bsq_onehot_device(&desc, reinterpret_cast<const uint8_t *>(base + 16), reinterpret_cast<const int64_t *>(base),
+                                                nullptr, 1, rows, t, reinterpret_cast<void *>(out.attr("data_ptr")().cast<uintptr_t>()), stream);
+        guard.attr("__exit__")(py::none(), py::none(), py::none());
+        if (st != BSQ_OK) throw_status(st);
+        const py::ssize_t first_zero = std::max(padlen, L + desc.bos + desc.eos);
+        if (desc.padchar && first_zero < rows) out.attr("__getitem__")(py::slice(first_zero, rows, 1)).attr("zero_")();
+        return out;
+    }
+    py::object onehot_single(const char *s, py::ssize_t L, py::ssize_t padlen, const std::string &dt,
+                             const py::object &device = py::none()) const {
+        if (!device.is_none()) return onehot_single_device(s, L, padlen, dt, device);
         switch (dt.empty() ? 0 : (dt[0] & 223)) {
         case 'B': return onehot_single_t<uint8_t>(s, L, padlen);
         case 'H': return onehot_single_t<uint16_t>(s, L, padlen);
@@ -554,8 +599,120 @@ class Tokenizer {
     }
 
     // decode_tokens (tokenize.h:131-183): 1-D -> str, 2-D -> list of str.
+    // Token matrices that live on a HIP device are decoded THERE (bsq_decode.hip: per-row wave prefix sums of the
+    // piece widths; only the decoded text is copied back), host arrays here.
+    py::object decode_device(py::object t) const {
+        py::module_ torch = py::module_::import("torch");
+        t = t.attr("detach")();
+        const int64_t ndim = t.attr("dim")().cast<int64_t>();
+        if (ndim > 2 || ndim == 0)
+            throw std::invalid_argument("Currently supported: 1 or 2 dimensions for decoding tokens.");
+        if (t.attr("dtype").equal(torch.attr("bool"))) t = t.attr("to")(torch.attr("uint8"));
+        const int32_t itemsize = t.attr("element_size")().cast<int32_t>();
+        if (itemsize != 1 && itemsize != 2 && itemsize != 4 && itemsize != 8)
+            throw std::runtime_error("Unexpected itemsize: expected 1, 2, 4, or 8. Found " + std::to_string(itemsize));
+        const std::vector<int64_t> shape = t.attr("shape").cast<std::vector<int64_t>>();
+        const std::vector<int64_t> stride = t.attr("stride")().cast<std::vector<int64_t>>();
+        const int64_t nrows = ndim == 2 ? shape[0] : 1, ncols = ndim == 2 ? shape[1] : shape[0];
+        const int64_t rs = ndim == 2 ? stride[0] * itemsize : 0, cs = (ndim == 2 ? stride[1] : stride[0]) * itemsize;
+        if (nrows == 0 || ncols == 0) {  // nothing to decode (an empty tensor has no storage to point at)
+            if (ndim == 1) return py::str("");
+            py::list empty;
+            for (int64_t r = 0; r < nrows; ++r) empty.append(py::str(""));
+            return empty;
+        }
+        py::object dev = t.attr("device");
+        py::object guard = torch.attr("cuda").attr("device")(dev);
+        guard.attr("__enter__")();
+        struct Exit {
+            py::object g;
+            ~Exit() {
+                try {
+                    g.attr("__exit__")(py::none(), py::none(), py::none());
+                } catch (...) {
+                }
+            }
+        } exit_guard{guard};
+        void *stream = reinterpret_cast<void *>(torch.attr("cuda").attr("current_stream")().attr("cuda_stream").cast<uintptr_t>());
+        const void *tok = reinterpret_cast<const void *>(t.attr("data_ptr")().cast<uintptr_t>());
+        py::object offs = torch.attr("empty")(py::make_tuple(nrows + 1), py::arg("dtype") = torch.attr("int64"), py::arg("device") = dev);
+        int64_t *offs_p = reinterpret_cast<int64_t *>(offs.attr("data_ptr")().cast<uintptr_t>());
+        int64_t total = 0, bad = -1;
+        bsq_status st;
+        {
+            py::gil_scoped_release nogil;
+            st = bsq_decode_sizes_device(&desc, tok, itemsize, nrows, ncols, rs, cs, offs_p, &total, &bad, stream);
+        }
+        if (st == BSQ_ERR_INVALID_ARG && bad >= 0) {  // the reference's message carries the offending value (as uint32)
+            const int64_t r = ncols ? bad / ncols : 0, c = ncols ? bad % ncols : 0;
+            py::object item = (ndim == 2 ? t.attr("__getitem__")(py::make_tuple(r, c)) : t.attr("__getitem__")(c)).attr("item")();
+            const uint64_t v = uint64_t(item.cast<int64_t>()) & (itemsize == 1 ? 0xFFull : itemsize == 2 ? 0xFFFFull : 0xFFFFFFFFull);
+            throw std::runtime_error("Unexpected/invalid token " + std::to_string(v));
+        }
+        if (st != BSQ_OK) throw_status(st);
+        py::object out = torch.attr("empty")(py::make_tuple(total), py::arg("dtype") = torch.attr("uint8"), py::arg("device") = dev);
+        {
+            uint8_t *out_p = reinterpret_cast<uint8_t *>(out.attr("data_ptr")().cast<uintptr_t>());
+            py::gil_scoped_release nogil;
+            st = bsq_decode_write_device(&desc, tok, itemsize, nrows, ncols, rs, cs, offs_p, out_p, stream);
+        }
+        if (st != BSQ_OK) throw_status(st);
+        py::array_t<uint8_t> text = out.attr("cpu")().attr("numpy")().cast<py::array_t<uint8_t>>();
+        py::array_t<int64_t> ho = offs.attr("cpu")().attr("numpy")().cast<py::array_t<int64_t>>();
+        const char *tp = reinterpret_cast<const char *>(text.data());
+        const int64_t *op = ho.data();
+        if (ndim == 1) return py::str(tp + op[0], size_t(op[1] - op[0]));
+        py::list ret;
+        for (int64_t r = 0; r < nrows; ++r) ret.append(py::str(tp + op[r], size_t(op[r + 1] - op[r])));
+        return ret;
+    }
+
+    // decode_logits (addition; README.md:48): argmax over the last (channel) axis on the device, then decode_device.
+    // logits: float tensor on a HIP device, (L, C) -> str, (B, L, C) -> list of B str (batch_first) or (L, B, C).
+    py::object decode_logits(py::object logits, bool batch_first) const {
+        py::module_ torch = py::module_::import("torch");
+        if (!py::hasattr(logits, "is_cuda") || !logits.attr("is_cuda").cast<bool>())
+            throw std::invalid_argument("decode_logits expects a float tensor on a HIP ('cuda') device");
+        logits = logits.attr("detach")();
+        const int64_t ndim = logits.attr("dim")().cast<int64_t>();
+        if (ndim != 2 && ndim != 3) throw std::invalid_argument("logits must be (L, C) or (B, L, C) / (L, B, C)");
+        if (logits.attr("stride")(-1).cast<int64_t>() != 1 || !logits.attr("is_contiguous")().cast<bool>())
+            logits = logits.attr("contiguous")();
+        const std::string dt = py::str(logits.attr("dtype")).cast<std::string>();
+        int32_t kind;
+        if (dt == "torch.float32") kind = BSQ_LOGITS_F32;
+        else if (dt == "torch.float64") kind = BSQ_LOGITS_F64;
+        else if (dt == "torch.float16") kind = BSQ_LOGITS_F16;
+        else if (dt == "torch.bfloat16") kind = BSQ_LOGITS_BF16;
+        else throw std::invalid_argument("logits must be float32, float64, float16 or bfloat16, not " + dt);
+        const std::vector<int64_t> shape = logits.attr("shape").cast<std::vector<int64_t>>();
+        const int64_t C = shape.back();
+        if (C <= 0 || C > (int64_t(1) << 30)) throw std::invalid_argument("bad channel count");
+        int64_t n = 1;
+        std::vector<int64_t> tshape(shape.begin(), shape.end() - 1);
+        for (int64_t v : tshape) n *= v;
+        py::object dev = logits.attr("device");
+        py::object tokens = torch.attr("empty")(py::cast(tshape), py::arg("dtype") = torch.attr(C <= 256 ? "uint8" : "int32"),
+                                                py::arg("device") = dev);
+        {
+            py::object guard = torch.attr("cuda").attr("device")(dev);
+            guard.attr("__enter__")();
+            void *stream = reinterpret_cast<void *>(torch.attr("cuda").attr("current_stream")().attr("cuda_stream").cast<uintptr_t>());
+            const bsq_status st = bsq_argmax_tokens_device(reinterpret_cast<const void *>(logits.attr("data_ptr")().cast<uintptr_t>()),
+                                                           kind, n, int32_t(C), C,
+                                                           reinterpret_cast<void *>(tokens.attr("data_ptr")().cast<uintptr_t>()),
+                                                           C <= 256 ? 1 : 4, stream);
+            guard.attr("__exit__")(py::none(), py::none(), py::none());
+            if (st != BSQ_OK) throw_status(st);
+        }
+        if (ndim == 3 && !batch_first) tokens = tokens.attr("t")();  // a strided view: the decoder takes any strides
+        return decode_device(tokens);
+    }
+
     py::object decode_tokens(py::object obj) const {
-        if (py::hasattr(obj, "detach") && py::hasattr(obj, "cpu"))  // torch tensor (possibly on the device)
+        if (py::hasattr(obj, "is_cuda") && py::hasattr(obj, "data_ptr") && obj.attr("is_cuda").cast<bool>())
+            return decode_device(obj);
+        if (py::hasattr(obj, "detach") && py::hasattr(obj, "cpu"))  // torch tensor in host memory
             obj = obj.attr("detach")().attr("cpu")().attr("numpy")();
         py::array array = py::array::ensure(obj);
         if (!array) throw std::invalid_argument("decode_tokens expects a numpy array or torch tensor");
@@ -660,27 +817,29 @@ PYBIND11_MODULE(cbioseq, m) {
              py::arg("mask") = py::none(), py::arg("device") = py::none(), py::arg("validate") = true,
              py::arg("layout") = "tbc")
         .def("onehot_encode",
-             [](const Tokenizer &t, py::str s, py::ssize_t padlen, const std::string &dt) {
+             [](const Tokenizer &t, py::str s, py::ssize_t padlen, const std::string &dt, const py::object &device) {
                  Py_ssize_t n = 0;
                  const char *p = PyUnicode_AsUTF8AndSize(s.ptr(), &n);
                  if (!p) throw py::error_already_set();
-                 return t.onehot_single(p, n, padlen, dt);
+                 return t.onehot_single(p, n, padlen, dt, device);
              },
-             py::arg("str"), py::arg("padlen") = 0, py::arg("destchar") = "f")
+             py::arg("str"), py::arg("padlen") = 0, py::arg("destchar") = "f", py::kw_only(), py::arg("device") = py::none())
         .def("onehot_encode",
-             [](const Tokenizer &t, py::bytearray s, py::ssize_t padlen, const std::string &dt) {
-                 return t.onehot_single(PyByteArray_AS_STRING(s.ptr()), PyByteArray_GET_SIZE(s.ptr()), padlen, dt);
+             [](const Tokenizer &t, py::bytearray s, py::ssize_t padlen, const std::string &dt, const py::object &device) {
+                 return t.onehot_single(PyByteArray_AS_STRING(s.ptr()), PyByteArray_GET_SIZE(s.ptr()), padlen, dt, device);
              },
-             py::arg("bytearray"), py::arg("padlen") = 0, py::arg("destchar") = "f")
+             py::arg("bytearray"), py::arg("padlen") = 0, py::arg("destchar") = "f", py::kw_only(), py::arg("device") = py::none())
         .def("onehot_encode",
-             [](const Tokenizer &t, py::bytes s, py::ssize_t padlen, const std::string &dt) {
+             [](const Tokenizer &t, py::bytes s, py::ssize_t padlen, const std::string &dt, const py::object &device) {
                  char *p = nullptr;
                  Py_ssize_t n = 0;
                  if (PyBytes_AsStringAndSize(s.ptr(), &p, &n)) throw py::error_already_set();
-                 return t.onehot_single(p, n, padlen, dt);
+                 return t.onehot_single(p, n, padlen, dt, device);
              },
-             py::arg("str"), py::arg("padlen") = 0, py::arg("destchar") = "B")
+             py::arg("str"), py::arg("padlen") = 0, py::arg("destchar") = "B", py::kw_only(), py::arg("device") = py::none())
         .def("decode_tokens", &Tokenizer::decode_tokens, py::arg("tokenizer"))
+        .def("decode_logits", &Tokenizer::decode_logits, py::arg("logits"), py::arg("batch_first") = true,
+             "argmax over the last axis on the device, then decode (README: 'if you have logits, use an argmax ...')")
         .def("lut", [](const Tokenizer &t) { return t.lookup; })
         .def("token_map", [](const Tokenizer &t) { return t.token_map_str; })
         .def("token_decoder", &Tokenizer::token_decoder)

@@ -14,6 +14,15 @@ Whole-batch assembly:
     (one extra read+write of the tensor on the receiver; SURVEY.md section 8e option 2).
 Ragged shard counts (B % world != 0) are padded to the largest shard for the collective and trimmed.
 
+`gather_direct` is the point-to-point form (SURVEY.md section 8e option 1): no ring, no staging, no concatenate.
+xGMI is a full mesh of point-to-point links (7 links x ~153 GB/s per GPU), so every rank posts ONE grouped
+batch of isend / irecv -- peer k of the group is rank +- k, i.e. every link of the mesh carries exactly one shard
+in each direction at the same time -- and the receives land straight in the destination tensor: batch-first slabs
+as one message per peer, seq-first / one-hot column blocks as one message per (peer, position row) (a row's block
+of B_g * C elements is contiguous in the destination even though the block as a whole is not).  `root=r` is the
+gather `north_star` names (only rank r ends up with the whole batch, the others only send); `root=None` leaves the
+whole batch on every rank like all_gather does.
+
 `onehot_gathered` is the xGMI-friendly form of the whole-batch one-hot: the shards that travel are the raw
 uint8 TOKEN matrices (P, B_g) -- 1/(C*sizeof(T)) of the one-hot's bytes, 1/80 at cfg3 -- and every rank expands
 the assembled (P, B) token matrix into the (P, B, C) tensor locally at HBM speed (the second pass of the
@@ -91,6 +100,60 @@ def _gather(local, batch_axis: int, B: int, group=None):
     return torch.cat(_all_gather_padded(local, batch_axis, B, group), dim=batch_axis)
 
 
+def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, group=None, rows_per_call: int = 128):
+    """Whole batch from per-rank shards by grouped point-to-point transfers written straight into the result.
+
+    local: this rank's shard, contiguous; batch_axis 0 = (B_g, ...) slabs, 1 = (P, B_g, ...) column blocks.
+    root: None -> every rank returns the whole batch; r -> only (group) rank r does, the others return None.
+    rows_per_call: position rows per batch_isend_irecv call (bounds the number of operations in one RCCL group).
+    """
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if batch_axis not in (0, 1) or (batch_axis == 1 and local.dim() < 2):
+        raise ValueError("batch_axis must be 0, or 1 for (P, B_g, ...) shards")
+    if root is not None and not 0 <= root < world:
+        raise ValueError("bad root")
+    bounds = [shard_bounds(B, world, r) for r in range(world)]
+    b0, b1 = bounds[rank]
+    if local.shape[batch_axis] != b1 - b0:
+        raise ValueError("local shard has %d sequences, expected %d" % (local.shape[batch_axis], b1 - b0))
+    local = local.contiguous()
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    receives = root is None or rank == root
+    full = None
+    if receives:
+        shape = list(local.shape)
+        shape[batch_axis] = B
+        full = local.new_empty(shape)
+        full.narrow(batch_axis, b0, b1 - b0).copy_(local)
+    # k-th exchange: send to rank + k, receive from rank - k -- all world - 1 exchanges are in flight together,
+    # each on its own link of the mesh
+    sends = [(rank + k) % world for k in range(1, world)] if root is None else ([root] if rank != root else [])
+    recvs = [(rank - k) % world for k in range(1, world)] if receives else []
+    recvs = [r for r in recvs if bounds[r][1] > bounds[r][0]]
+    reqs = []
+    if b1 == b0:
+        sends = []
+    if batch_axis == 0:
+        ops = [dist.P2POp(dist.irecv, full.narrow(0, bounds[r][0], bounds[r][1] - bounds[r][0]), peer(r), group) for r in recvs]
+        ops += [dist.P2POp(dist.isend, local, peer(r), group) for r in sends]
+        if ops:
+            reqs += dist.batch_isend_irecv(ops)
+    else:
+        P = int(local.shape[0])
+        for t0 in range(0, P, max(1, rows_per_call)):
+            ops = []
+            for t in range(t0, min(P, t0 + max(1, rows_per_call))):
+                ops += [dist.P2POp(dist.irecv, full[t].narrow(0, bounds[r][0], bounds[r][1] - bounds[r][0]), peer(r), group)
+                        for r in recvs]
+                ops += [dist.P2POp(dist.isend, local[t], peer(r), group) for r in sends]
+            if ops:
+                reqs += dist.batch_isend_irecv(ops)
+    for q in reqs:
+        q.wait()
+    return full
+
+
 def gather_tokens(local, B: int, batch_first: bool, group=None):
     """Whole-batch token matrix on every rank from per-rank shards ((B_g,P) or (P,B_g));
     also used for channels-first one-hot (B_g, C, P) with batch_first=True."""
@@ -157,7 +220,8 @@ def encode_sharded(encode: Callable, chars, offsets, gather: Optional[str] = Non
     """Run `encode(chars_shard, offsets_shard)` on this rank's sequences.
 
     encode: e.g. ``lambda c, o: tok.onehot_packed(c, o, padlen, 'f', device=dev)``.
-    gather: None (data-parallel consumer: keep the shard), 'onehot', 'tokens_bf' or 'tokens_sf'.
+    gather: None (data-parallel consumer: keep the shard), 'onehot', 'tokens_bf' or 'tokens_sf' (all_gather forms),
+            'direct_onehot', 'direct_tokens_bf', 'direct_tokens_sf' (point-to-point form, `gather_direct`).
     """
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -175,4 +239,8 @@ def encode_sharded(encode: Callable, chars, offsets, gather: Optional[str] = Non
         return gather_tokens(local, B, True, group)
     if gather == "tokens_sf":
         return gather_tokens(local, B, False, group)
-    raise ValueError("gather must be None, 'onehot', 'tokens_bf' or 'tokens_sf'")
+    if gather in ("direct_onehot", "direct_tokens_sf"):
+        return gather_direct(local, 1, B, None, group)
+    if gather == "direct_tokens_bf":
+        return gather_direct(local, 0, B, None, group)
+    raise ValueError("gather must be None, 'onehot', 'tokens_bf', 'tokens_sf' or one of their 'direct_' forms")

@@ -143,6 +143,29 @@ bsq_status bsq_raw_tokens_device(const bsq_desc *d, const uint8_t *chars, const 
 bsq_status bsq_onehot_from_raw_tokens_device(const uint8_t *tokens, int64_t pitch, int64_t B, int64_t P, int32_t C,
                                              bsq_dtype t, void *out, void *hip_stream);
 
+/* ---- decode on the device: replaces Tokenizer::decode_tokens (tokenize.h:131-183) for token matrices that live in
+ * HBM (README.md:48: "if you have logits, use an argmax to convert to tokens for decoding").  The tokens never travel
+ * to the host, only the decoded text does.  A token decodes to the first byte of its alphabet group or to one of the
+ * five-byte pieces <BOS> / <EOS> / <PAD>; rows are decoded independently (1-D input: nrows = 1).
+ *   tokens: device pointer, element size `itemsize` (1, 2, 4 or 8: unsigned loads of tokenize.h:107-124), element
+ *           (r, c) at byte offset r * row_stride + c * col_stride (any strides that are multiples of itemsize).
+ * bsq_decode_sizes_device: row_offsets (device, nrows + 1 int64) <- exclusive prefix sum of the decoded row lengths,
+ *   *total <- bytes of all rows; synchronises the stream.  A token outside the tokenizer's table gives
+ *   BSQ_ERR_INVALID_ARG with *first_bad = r * ncols + c of the first one (the reference throws "Unexpected/invalid
+ *   token"), else *first_bad = -1.
+ * bsq_decode_write_device: row r's text into out_chars[row_offsets[r] .. row_offsets[r + 1]); stream-ordered.
+ * bsq_argmax_tokens_device: tokens[r] = argmax_c logits[r * row_stride + c] (first maximum, like torch.argmax),
+ *   r < n, channels contiguous; logit_kind BSQ_LOGITS_*; tokens uint8 (token_itemsize 1, C <= 256) or int32 (4). */
+enum { BSQ_LOGITS_F32 = 0, BSQ_LOGITS_F64 = 1, BSQ_LOGITS_F16 = 2, BSQ_LOGITS_BF16 = 3 };
+bsq_status bsq_decode_sizes_device(const bsq_desc *d, const void *tokens, int32_t itemsize, int64_t nrows, int64_t ncols,
+                                   int64_t row_stride, int64_t col_stride, int64_t *row_offsets, int64_t *total,
+                                   int64_t *first_bad, void *hip_stream);
+bsq_status bsq_decode_write_device(const bsq_desc *d, const void *tokens, int32_t itemsize, int64_t nrows, int64_t ncols,
+                                   int64_t row_stride, int64_t col_stride, const int64_t *row_offsets, uint8_t *out_chars,
+                                   void *hip_stream);
+bsq_status bsq_argmax_tokens_device(const void *logits, int32_t logit_kind, int64_t n, int32_t C, int64_t row_stride,
+                                    void *tokens, int32_t token_itemsize, void *hip_stream);
+
 /* ---- BLOSUM62 augmentation (the pre-step of BASELINE config 5): replaces bioseq/blosum.py:36-87.
  * bsq_blosum62_normrows: the 21x20 float64 transition table `normrows` (rows ARNDCQEGHILKMFPSTWYV+X,
  * columns ARNDCQEGHILKMFPSTWYV), bit-identical to the reference's numpy result.

@@ -46,10 +46,11 @@ def run(budget=120.0, seed=1):
         try:
             bf = bool(rng.integers(0, 2))
             e = ora.tokenize_packed(chars, offs, P, d, bf)
-            g = tok.tokenize_packed(dch, dof, P, d, bf).cpu().numpy()
+            u64 = (lambda a: a.view(np.uint64) if d in "lq" else a)  # 'q' device tensors are torch.int64 (same bits)
+            g = u64(tok.tokenize_packed(dch, dof, P, d, bf).cpu().numpy())
             assert g.dtype == e.dtype and g.tobytes() == e.tobytes(), ("tokenize", bf)
             e = ora.onehot_packed(chars, offs, P, d, mask=mask)
-            g = tok.onehot_packed(dch, dof, P, d, mask=dm).cpu().numpy()
+            g = u64(tok.onehot_packed(dch, dof, P, d, mask=dm).cpu().numpy())
             assert g.dtype == e.dtype and g.shape == e.shape and g.tobytes() == e.tobytes(), "onehot"
             g = tok.onehot_packed(dch, dof, P, d, mask=dm, layout="bcl").cpu().numpy()
             assert g.tobytes() == np.ascontiguousarray(e.transpose(1, 2, 0)).tobytes(), "onehot bcl"

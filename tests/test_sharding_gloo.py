@@ -53,6 +53,20 @@ def _worker(rank, world, port, B, P, q):
         bf = sharding.encode_sharded(lambda c, o: tok.tokenize_packed(c, o, P, "B", True), chars, offs, gather="tokens_bf")
         sf = sharding.encode_sharded(lambda c, o: tok.tokenize_packed(c, o, P, "i", False), chars, offs, gather="tokens_sf")
         keep = sharding.encode_sharded(lambda c, o: tok.onehot_packed(c, o, P, "f"), chars, offs)
+        # point-to-point assembly (gather_direct): the SAME function the GPU box runs over RCCL, here over gloo, fed by
+        # the oracle encoder -- whole batch on every rank, and to a root only, for all three layouts
+        d_oh = sharding.encode_sharded(lambda c, o: tok.onehot_packed(c, o, P, "f"), chars, offs, gather="direct_onehot")
+        d_bf = sharding.encode_sharded(lambda c, o: tok.tokenize_packed(c, o, P, "B", True), chars, offs, gather="direct_tokens_bf")
+        d_sf = sharding.encode_sharded(lambda c, o: tok.tokenize_packed(c, o, P, "i", False), chars, offs, gather="direct_tokens_sf")
+        direct_ok = (d_oh.numpy().tobytes() == full_oh.tobytes() and d_bf.numpy().tobytes() == full_bf.tobytes()
+                     and d_sf.numpy().tobytes() == full_sf.tobytes())
+        for root in range(world):
+            r_oh = sharding.gather_direct(torch.from_numpy(keep), 1, B, root, rows_per_call=5)
+            r_bf = sharding.gather_direct(torch.from_numpy(np.ascontiguousarray(full_bf[slice(*sharding.shard_bounds(B, world, rank))])), 0, B, root)
+            if rank == root:
+                direct_ok = direct_ok and r_oh.numpy().tobytes() == full_oh.tobytes() and r_bf.numpy().tobytes() == full_bf.tobytes()
+            else:
+                direct_ok = direct_ok and r_oh is None and r_bf is None
 
         # token-gather assembly (onehot_gathered) with CPU stand-ins for the two device passes
         def raw_tokens(c, o):
@@ -70,7 +84,7 @@ def _worker(rank, world, port, B, P, q):
         ok = (oh.numpy().tobytes() == full_oh.tobytes() and bf.numpy().tobytes() == full_bf.tobytes()
               and sf.numpy().tobytes() == full_sf.tobytes()
               and via_tokens.numpy().tobytes() == full_oh.tobytes()
-              and keep.tobytes() == np.ascontiguousarray(full_oh[:, b0:b1]).tobytes())
+              and keep.tobytes() == np.ascontiguousarray(full_oh[:, b0:b1]).tobytes() and direct_ok)
         # bench.py-style timing reduction: MAX over ranks
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -80,19 +94,20 @@ def _worker(rank, world, port, B, P, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [10, 11])
-def test_world2_gather_matches_single_process(B):
+@pytest.mark.parametrize("world,B", [(2, 10), (2, 11), (3, 2), (3, 13)])
+def test_gather_matches_single_process(world, B):
+    """world 2 with equal / ragged shards; world 3 with an EMPTY shard (B = 2) and ragged ones."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, 23, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, 23, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
