@@ -69,13 +69,21 @@ struct KParams {
     int32_t ntb;      // number of sequence tiles
     int32_t aligned;  // 1: every output row segment is 16-byte aligned -> vector stores
     int32_t ntt;      // number of position tiles
-    int32_t order;    // 0: sequence-tile index fastest over blockIdx, 1: position-tile index fastest
+    int32_t order;    // 0: sequence-tile index fastest over blockIdx, 1: position-tile index fastest, 2: XCD-aware
     int64_t out_pitch;  // k_tokens_raw only: bytes between two position rows of its output
     uint64_t one_bits;
 };
 
+// order 2 (XCD-aware): the position tiles of ONE sequence tile go to blocks b, b + 8, b + 16, ... -- one XCD under
+// round-robin placement, dispatched back to back -- so the character lines that neighbouring position tiles share
+// (a 128-byte line holds the characters of two 64-position tiles) are fetched into that XCD's L2 once.  The grid
+// is tile_grid() blocks; blocks whose sequence tile lies beyond the batch exit.
 __device__ __forceinline__ void tile_of_block(const KParams &p, int32_t &tb, int32_t &tt) {
-    if (p.order == 0) {
+    if (p.order == 2) {
+        const uint32_t per = 8u * static_cast<uint32_t>(p.ntt);
+        tt = static_cast<int32_t>((blockIdx.x >> 3) % static_cast<uint32_t>(p.ntt));
+        tb = static_cast<int32_t>((blockIdx.x / per) * 8u + (blockIdx.x & 7u));
+    } else if (p.order == 0) {
         tb = static_cast<int32_t>(blockIdx.x % static_cast<uint32_t>(p.ntb));
         tt = static_cast<int32_t>(blockIdx.x / static_cast<uint32_t>(p.ntb));
     } else {
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(kThreads) void k_onehot_tile(const KParams p) {
     const int wave = tid >> 6, lane = tid & 63;
     int32_t tb, tt;
     tile_of_block(p, tb, tt);
+    if (tb >= p.ntb) return;  // (order 2 rounds the sequence tiles up to a multiple of 8)
     const int64_t b0 = static_cast<int64_t>(tb) * TB;
     const int32_t t0 = tt * kTT;
 
@@ -395,6 +404,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
     const int tid = threadIdx.x;
     int32_t tb, tt;
     tile_of_block(p, tb, tt);
+    if (tb >= p.ntb) return;
     const int64_t b0 = static_cast<int64_t>(tb) * TB;
     const int32_t t0 = tt * kTT;
     build_token_tile<TB>(p, b0, t0, s_lut, s_span, s_tok);
@@ -450,6 +460,7 @@ struct EParams {
     double inv_rowbytes, inv_B;  // reciprocals for div_by()
     uint32_t rb_magic, rb_shift, rb_pow2;  // fast_div() constants of rowbytes
     int32_t force4;                        // experiment knob "expand_slots" = 4: always four token slots per step
+    int32_t mode;                          // k_expand_small: 9 = no token loads (ablation)
 };
 
 // (A variant with the four waves of a workgroup sharing one chunk -- the shape of the fastest plain fill --
@@ -508,6 +519,9 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
             if (tk[q] != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
         }
     };
+    // Token loads as DWORDS: a lane takes four consecutive rows from one (unaligned) 4-byte load -- a third to a
+    // quarter of the load instructions of the byte form when a chunk holds hundreds of rows (rows of a few bytes).
+    // The last lane's dword is pulled back to end at the last needed token (never a byte beyond it) and shifted.
     for (int32_t i0 = 0; i0 < nr_s; i0 += 256) {
         const int32_t left = p.force4 ? 256 : nr_s - i0;
         if (left > 192) step(std::integral_constant<int, 4>{}, i0);
@@ -527,6 +541,120 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     } else {  // clipped first / last piece of the tensor
         for (int32_t o = lane * static_cast<int32_t>(sizeof(ST)); o < len; o += 64 * static_cast<int32_t>(sizeof(ST)))
             *reinterpret_cast<ST *>(g + o) = *reinterpret_cast<const ST *>(img + o);
+    }
+}
+
+// The same expansion for SMALL rows (a chunk holds hundreds of rows: 7-byte rows of int8 DNA, 28-byte rows of f32
+// DNA): a lane takes FOUR consecutive rows from one unaligned dword of tokens, every token dword of the wave's
+// CPW chunks is in flight before the first one is used, and the chunks are then scattered / streamed one after
+// the other through the wave's LDS image (LDS operations of a wave execute in order, so the image is reused as
+// soon as its four ds_read_b128 are issued).  Measured (profiles/r02/expand_lab*.txt): with ~32 waves per CU the
+// write stream is saturated only while nearly every resident wave has stores in flight; the dependent token load
+// of a one-chunk wave leaves 30 % of them waiting (cfg4 int8: 0.235 ms vs 0.165 ms without token loads).
+template <typename ST, bool NT, int CPW>
+__global__ __launch_bounds__(kThreads) void k_expand_small(const EParams p) {
+    __shared__ __align__(16) uint8_t s_img[4][kChunk];
+    constexpr int kSlots = 5;  // x 256 rows per chunk: rows of >= 4 bytes
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *img = s_img[wave];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
+    const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
+    const ST one = static_cast<ST>(p.one_bits);
+    const int64_t slot0 = (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave) * CPW;
+    const int64_t k0 = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot0;  // class = blockIdx % 8, CPW consecutive slots
+    if (k0 >= p.nchunks) return;
+
+    int64_t lo[CPW];
+    int32_t len[CPW], skip[CPW], nr[CPW];
+    const uint8_t *tok[CPW];
+    bool live[CPW], wraps[CPW];
+    uint32_t w[CPW][kSlots];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int64_t k = k0 + 8 * c;
+        int64_t l = k * kChunk - p.head, h = l + kChunk;
+        if (l < 0) l = 0;
+        if (h > p.total) h = p.total;
+        live[c] = k < p.nchunks && h > l;  // wave-uniform
+        lo[c] = l;
+        len[c] = live[c] ? static_cast<int32_t>(h - l) : 0;
+        nr[c] = 0;
+        wraps[c] = false;
+        if (!live[c]) continue;
+        int64_t skip64, b_lo;
+        const int64_t r_lo = div_by(l, rowbytes, p.inv_rowbytes, &skip64);
+        skip[c] = static_cast<int32_t>(skip64);
+        nr[c] = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(
+            fast_div(static_cast<uint32_t>(skip[c] + len[c] + rowbytes - 1), p.rb_magic, p.rb_shift, p.rb_pow2)));
+        const int64_t t_lo = div_by(r_lo, p.B, p.inv_B, &b_lo);
+        tok[c] = p.tok + t_lo * p.Bp + b_lo;
+        wraps[c] = p.B - b_lo < nr[c] || nr[c] < 4;  // runs over the end of position t_lo's rows (or tiny): byte path
+#pragma unroll
+        for (int q = 0; q < kSlots; ++q) {
+            w[c][q] = kNone * 0x01010101u;
+            const int32_t i = q * 256 + 4 * lane;
+            if (!wraps[c] && p.mode != 9 && q * 256 < nr[c] && i < nr[c]) {
+                // the last lane's dword is pulled back to END at the last needed token (never a byte beyond it)
+                const int32_t off = i + 4 <= nr[c] ? i : nr[c] - 4;
+                w[c][q] = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(tok[c] + off) >> (8 * (i - off));
+            }
+            if (p.mode == 9) w[c][q] = 0x03020100u;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        if (!live[c]) continue;
+        if (!wraps[c]) {
+#pragma unroll
+            for (int q = 0; q < kSlots; ++q) {
+                if (q * 256 >= nr[c]) break;
+                const int32_t i = q * 256 + 4 * lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t tk = (w[c][q] >> (8 * j)) & 0xFFu;
+                    const int32_t pos = (i + j) * rowbytes - skip[c] + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
+                    if (i + j < nr[c] && tk != kNone && pos >= 0 && pos < len[c]) *reinterpret_cast<ST *>(img + pos) = one;
+                }
+            }
+        } else {  // rare: byte loads, row by row, across the pitch padding of the scratch
+            const int64_t k = k0 + 8 * c;
+            int64_t l = k * kChunk - p.head;
+            if (l < 0) l = 0;
+            int64_t skip64, b_lo;
+            const int64_t r_lo = div_by(l, rowbytes, p.inv_rowbytes, &skip64);
+            const int64_t t_lo = div_by(r_lo, p.B, p.inv_B, &b_lo);
+            for (int32_t i = lane; i < nr[c]; i += 64) {
+                int64_t b = b_lo + i, t = t_lo;
+                if (b >= p.B) {
+                    const int64_t q = b / p.B;
+                    t += q;
+                    b -= q * p.B;
+                }
+                const uint32_t tk = p.tok[t * p.Bp + b];
+                const int32_t pos = i * rowbytes - skip[c] + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
+                if (tk != kNone && pos >= 0 && pos < len[c]) *reinterpret_cast<ST *>(img + pos) = one;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint8_t *g = p.out + lo[c];
+        if (len[c] == kChunk && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4 *>(img + u * 1024 + lane * 16);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) store16<NT>(g + u * 1024 + lane * 16, v[u]);
+        } else {  // clipped first / last piece of the tensor
+            for (int32_t o = lane * static_cast<int32_t>(sizeof(ST)); o < len[c]; o += 64 * static_cast<int32_t>(sizeof(ST)))
+                *reinterpret_cast<ST *>(g + o) = *reinterpret_cast<const ST *>(img + o);
+        }
+        if (c + 1 < CPW) {  // wipe the image for the next chunk (in-order LDS: behind the reads above)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
+        }
     }
 }
 
@@ -551,6 +679,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     const int tid = threadIdx.x;
     int32_t tb, tt;
     tile_of_block(p, tb, tt);
+    if (tb >= p.ntb) return;
     const int64_t b0 = static_cast<int64_t>(tb) * kRawTB;
     const int32_t t0 = tt * kTT;
     stage_lut(p, s_lut);
@@ -1106,6 +1235,11 @@ __global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offs
 // ------------------------------------------------------------------------------------------
 // Launch helpers
 // ------------------------------------------------------------------------------------------
+// Blocks of a tiled launch (see tile_of_block).
+int64_t tile_grid(const KParams &k, int64_t ntt) {
+    return (k.order == 2 ? (int64_t(k.ntb) + 7) / 8 * 8 : int64_t(k.ntb)) * ntt;
+}
+
 bsq_status check_launch(const char *what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bsq_internal::set_hip_error(what, e);
@@ -1139,7 +1273,12 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     k.fill_id = d->padchar ? bsq_pad_id(d) : static_cast<int32_t>(kNone);
     k.ntb = 1;
     k.ntt = int32_t((P + kTT - 1) / kTT);
-    k.order = bsq_internal::tuning("tile_order");
+    // knob "tile_order": 0 automatic (XCD-aware), 1 position-tile index fastest, 2 XCD-aware, 3 sequence-tile index fastest.
+    // XCD-aware placement fetches the characters once instead of ~3 times on the 1M x 160 DNA batch (FETCH_SIZE 234 ->
+    // 78 MB; k_tokens_raw 97 -> 66 us, k_onehot_tile 258 -> 233 us: profiles/r02/order_lab.txt).
+    const int order_knob = bsq_internal::tuning("tile_order");
+    k.order = order_knob == 1 ? 1 : (order_knob == 3 ? 0 : 2);
+    if (k.order == 2 && (B / 64 + 8) * int64_t(k.ntt) >= (int64_t(1) << 31)) k.order = 0;  // keep the rounded-up grid in 32 bits
     k.aligned = 0;
     k.out_pitch = B;
     k.one_bits = 1;
@@ -1176,7 +1315,7 @@ bsq_status launch_onehot_tile(const KParams &k, hipStream_t s) {
     const int row_pad = (TB * k.C * int(sizeof(ST)) + 15) & ~15;
     const size_t smem = tile_fixed_bytes<TB>() + 4 * size_t(row_pad);
     const int64_t ntt = (k.P + kTT - 1) / kTT;
-    const int64_t grid = int64_t(k.ntb) * ntt;
+    const int64_t grid = tile_grid(k, ntt);
     if (bsq_internal::nontemporal_stores())
         hipLaunchKernelGGL((k_onehot_tile<ST, TB, true>), dim3(unsigned(grid)), dim3(kThreads), smem, s, k);
     else
@@ -1382,6 +1521,28 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     // the optimum also with 2-wave workgroups (16 / 14 / 12 / 10 waves: 0.83 / 0.81 / 0.76 / 0.93 ms), and 3 x 4 waves
     // (0.73 ms) beats 6 x 2.
     // Knob "expand_pad": 0 = this rule, > 0 = that many bytes, < 0 = none.
+    // Small rows (>= 4 bytes, < 64): k_expand_small.  Knob "expand_mode": 0 automatic, 1 always k_expand_chunks,
+    // 2 / 3 / 4 k_expand_small with 1 / 2 / 4 chunks per wave, 9 k_expand_small without token loads (ablation).
+    const int mode = e.mode;
+    const int64_t rb = e.C * int64_t(sizeof(ST));
+    if (rb >= 4 && mode != 1 && (mode >= 2 || (rb >= 16 && rb < 64))) {
+        const int cpw = mode == 3 ? 2 : (mode == 4 ? 4 : 1);
+        const int64_t g2 = (per_class + int64_t(4) * cpw - 1) / (int64_t(4) * cpw);
+        const dim3 grid2(unsigned(g2 * 8));
+        const int padv2 = bsq_internal::tuning("expand_pad");
+        const size_t pad2 = padv2 > 0 ? size_t(padv2) : 0;
+        const bool nt = bsq_internal::nontemporal_stores();
+#define BSQ_ES(CPWV)                                                                                              \
+        do {                                                                                                      \
+            if (nt) hipLaunchKernelGGL((k_expand_small<ST, true, CPWV>), grid2, dim3(kThreads), pad2, s, e);      \
+            else hipLaunchKernelGGL((k_expand_small<ST, false, CPWV>), grid2, dim3(kThreads), pad2, s, e);        \
+        } while (0)
+        if (cpw == 4) BSQ_ES(4);
+        else if (cpw == 2) BSQ_ES(2);
+        else BSQ_ES(1);
+#undef BSQ_ES
+        return check_launch("k_expand_small");
+    }
     const int padv = bsq_internal::tuning("expand_pad");
     const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;
     const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : (big_rows ? size_t(36864) : size_t(0)));
@@ -1402,7 +1563,7 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
     k.out_pitch = pitch;
     k.aligned = reinterpret_cast<uintptr_t>(tokens) % 16 == 0 && pitch % 16 == 0;  // every row starts 16-byte aligned
     k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
-    const dim3 grid(unsigned(int64_t(k.ntb) * k.ntt));
+    const dim3 grid(unsigned(tile_grid(k, k.ntt)));
     if (k.mask)
         hipLaunchKernelGGL(k_tokens_raw<true>, grid, dim3(kThreads), 0, s, k);
     else
@@ -1427,6 +1588,7 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
     e.inv_B = 1.0 / double(B);
     div_constants(uint32_t(C * int64_t(sz)), &e.rb_magic, &e.rb_shift, &e.rb_pow2);
     e.force4 = bsq_internal::tuning("expand_slots") == 4;
+    e.mode = bsq_internal::tuning("expand_mode");
     switch (sz) {
     case 1: return launch_expand<uint8_t>(e, s);
     case 2: return launch_expand<uint16_t>(e, s);
@@ -1448,7 +1610,7 @@ bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
     k.ntb = int32_t((k.B + TB - 1) / TB);
     const int64_t ntt = (k.P + kTT - 1) / kTT;
     const size_t smem = tile_fixed_bytes<TB>();
-    hipLaunchKernelGGL((k_tokenize_tile<T, TB>), dim3(unsigned(int64_t(k.ntb) * ntt)), dim3(kThreads), smem, s, k);
+    hipLaunchKernelGGL((k_tokenize_tile<T, TB>), dim3(unsigned(tile_grid(k, ntt))), dim3(kThreads), smem, s, k);
     return check_launch("k_tokenize_tile");
 }
 
@@ -1534,7 +1696,11 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
     if (!d) return "";
     switch (choose_onehot_path(bsq_alphabet_size(d), bsq_dtype_size(t), B, P)) {
     case 1: return "k_onehot_tile";
-    case 2: return "k_tokens_raw+k_expand_chunks";
+    case 2: {
+        const int64_t rb = bsq_alphabet_size(d) * int64_t(bsq_dtype_size(t));
+        const int mode = bsq_internal::tuning("expand_mode");
+        return (rb >= 4 && mode != 1 && (mode >= 2 || (rb >= 16 && rb < 64))) ? "k_tokens_raw+k_expand_small" : "k_tokens_raw+k_expand_chunks";
+    }
     case 3: return "k_onehot_chunks";
     default: return "k_onehot_generic";
     }
@@ -1645,7 +1811,7 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     k.aligned = (addr % 16 == 0) && ((B * int64_t(sz)) % 16 == 0);
     if (t == BSQ_I8 && bsq_internal::tuning("tokenize_path") != 1) {  // int8 (P,B): the raw-token kernel in value mode
         k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
-        hipLaunchKernelGGL((k_tokens_raw<false, false>), dim3(unsigned(int64_t(k.ntb) * k.ntt)), dim3(kThreads), 0, s, k);
+        hipLaunchKernelGGL((k_tokens_raw<false, false>), dim3(unsigned(tile_grid(k, k.ntt))), dim3(kThreads), 0, s, k);
         return check_launch("k_tokens_raw<value>");
     }
     switch (t) {

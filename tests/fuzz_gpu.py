@@ -35,12 +35,17 @@ def run(budget=120.0, seed=1):
         path = int(rng.integers(0, 4))
         capi.check(lib.bsq_tuning_set(b"onehot_path", path))
         capi.check(lib.bsq_tuning_set(b"tokenize_path", int(rng.integers(0, 2))))
+        knobs = (int(rng.integers(0, 4)), int(rng.choice([0, 0, 1, 2, 3, 4])), int(rng.integers(0, 3)), int(rng.integers(0, 2)))
+        capi.check(lib.bsq_tuning_set(b"tile_order", knobs[0]))
+        capi.check(lib.bsq_tuning_set(b"expand_mode", knobs[1]))
+        capi.check(lib.bsq_tuning_set(b"tokens8_lookup", knobs[2]))
+        capi.check(lib.bsq_tuning_set(b"tokens8", knobs[3]))
         tok, ora = bsq.Tokenizer(key, eos, bos, pad), O.OracleTokenizer(key, eos, bos, pad)
         shift = int(rng.integers(0, 4))  # misaligned device views of the inputs
         dch = torch.from_numpy(np.concatenate([np.zeros(shift, np.uint8), chars])).to(dev)[shift:]
         dof = torch.from_numpy(offs).to(dev)
         dm = None if mask is None else torch.from_numpy(np.concatenate([np.zeros(5 - shift, np.uint8), mask])).to(dev)[5 - shift:]
-        desc = (key, eos, bos, pad, B, P, lo, hi, d, path, use_mask, shift)
+        desc = (key, eos, bos, pad, B, P, lo, hi, d, path, use_mask, shift, knobs)
         with open("/tmp/fuzz_last.txt", "w") as f:  # survives a GPU fault that kills the process
             f.write(repr(desc) + " total_chars=%d\n" % chars.size)
         try:
@@ -62,7 +67,8 @@ def run(budget=120.0, seed=1):
         except AssertionError as ex:
             raise AssertionError("MISMATCH %s %r" % (ex, desc))
         n += 1
-    capi.check(lib.bsq_tuning_set(b"onehot_path", 0)); capi.check(lib.bsq_tuning_set(b"tokenize_path", 0))
+    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"expand_mode", b"tokens8_lookup", b"tokens8"):
+        capi.check(lib.bsq_tuning_set(name, 0))
     return n
 
 

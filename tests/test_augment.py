@@ -153,3 +153,36 @@ def test_cfg5_pipeline_augment_then_tokenize(gpu, bsq, oracle):
     got = tok.tokenize_packed(dch, dof, c["padlen"], "B", True).cpu().numpy()
     exp = oracle.OracleTokenizer("SEB8").tokenize_packed(mutated, offs, c["padlen"], "B", True)
     assert got.tobytes() == exp.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+@pytest.mark.parametrize("chain_len,frac", [(1, 0.5), (3, 1.0)])
+def test_cfg5_full_size_augment_then_tokenize(gpu, bsq, oracle, chain_len, frac):
+    """BASELINE config 5 AT ITS STATED SIZE (262 144 x 512, SEB8): BLOSUM62 augmentation in place on the device,
+    then the token matrix -- tokens == the oracle's encode of the mutated bytes (bit-exact on identical inputs),
+    at most chain_len residues change per sequence, lengths never change, about `frac` of the sequences are touched,
+    and every changed residue became a DIFFERENT one of the 20 amino acids."""
+    import torch
+    from bioseq_amd import blosum, synth
+    c = synth.CONFIGS["cfg5"]
+    n, P = c["n"], c["padlen"]
+    assert (n, P) == (262144, 512)
+    chars, offs = synth.synth_packed(c["seed"], n, c["lo"], c["hi"], c["letters"])
+    dch, dof = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+    blosum.augment_packed(dch, dof, chain_len=chain_len, augment_frac=frac, seed=20260505 + chain_len)
+    mutated = dch.cpu().numpy()
+    diff = mutated != chars
+    per_seq = np.add.reduceat(diff.astype(np.int64), offs[:-1])
+    assert per_seq.max() <= chain_len and mutated.size == chars.size
+    touched = int((per_seq > 0).sum())
+    if frac >= 1.0:
+        assert touched > 0.97 * n        # chains of 3 can undo themselves only rarely
+    else:
+        assert abs(touched - frac * n) < 6 * np.sqrt(n * frac * (1 - frac))   # binomial, 6 sigma
+    aa = np.frombuffer(synth.AA.encode(), dtype=np.uint8)
+    assert np.isin(mutated[diff], aa).all()
+    tok = bsq.Tokenizer(c["key"], c["eos"], c["bos"], c["padchar"])
+    got = tok.tokenize_packed(dch, dof, P, "B", True).cpu().numpy()
+    exp = oracle.OracleTokenizer(c["key"], c["eos"], c["bos"], c["padchar"]).tokenize_packed(mutated, offs, P, "B", True, 8)
+    assert got.tobytes() == exp.tobytes()
