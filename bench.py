@@ -267,6 +267,17 @@ def main():
     if os.environ.get("BSQ_BENCH_DUMP"):  # per-step device times, for variance hunting
         print("per-step ms:", " ".join("%.3f" % v for v in kern_ms), file=sys.stderr)
 
+    # the same K steps once more, back to back between ONE pair of events: per-step event pairs put an event record (and
+    # its ~1-2 us of queue time) between any two launches, which matters for the 20-40 us kernels of cfg2 / cfg5
+    la, lb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    la.record(stream)
+    for _ in range(args.steps):
+        step()
+    lb.record(stream)
+    torch.cuda.synchronize()
+    loop_ms = la.elapsed_time(lb) / args.steps
+
     gather_info = None
     if world > 1 and args.gather > 0:
         from bioseq_amd import sharding
@@ -368,6 +379,8 @@ def main():
                          "frac_wall": algo_bytes / (wall_max / args.steps) / 1e9 / HBM_PEAK_GBPS,  # from ms_per_step (host clock)
                          "traffic": traffic, "kernel": kernel_name,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_avg_ms": kern_avg_ms,
+                         "kernel_back_to_back_ms": loop_ms,  # K steps between one pair of events, / K
+                         "frac_back_to_back": algo_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "kernel_min_ms": float(np.min(kern_ms)), "kernel_median_ms": float(np.median(kern_ms)),
                          "fill_yardstick_gbps": fill_gbps,
                          "frac_of_fill": (out_bytes / (kern_avg_ms * 1e-3) / 1e9) / fill_gbps},

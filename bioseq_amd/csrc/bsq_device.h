@@ -61,4 +61,30 @@ __host__ __device__ __forceinline__ int64_t div_by(int64_t n, int64_t d, double 
     return q;
 }
 
+// floor(n / d) for 0 <= n < 2^63 and 1 <= d < 2^63 by ONE 64 x 64 -> high-64 multiply with a precomputed magic
+// (round-up method: magic = floor(2^(64+s) / d) + 1 with s = floor(log2 d) lies in (2^63, 2^64]; the error term
+// n * e / 2^(64+s), e <= 1, stays below 1/d while n < 2^63); powers of two are shifts.  On WAVE-UNIFORM operands the
+// whole thing is scalar-ALU work (s_mul_hi_u32 / s_mul_i32), unlike div_by() whose double arithmetic always runs on
+// the vector ALU at the FP64 rate -- at 12 resident waves per CU that chain was ~15 % of a chunk wave's lifetime.
+struct Div64 {
+    uint64_t magic;
+    uint32_t shift, pow2;
+};
+inline Div64 div64_constants(uint64_t d) {
+    Div64 c;
+    uint32_t sh = 0;
+    while (sh < 62 && (uint64_t(2) << sh) <= d) ++sh;
+    c.shift = sh;
+    c.pow2 = (d & (d - 1)) == 0;
+    c.magic = c.pow2 ? 0 : uint64_t((static_cast<unsigned __int128>(1) << (64 + sh)) / d + 1);
+    return c;
+}
+__host__ __device__ __forceinline__ uint64_t div64(uint64_t n, const Div64 &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return c.pow2 ? n >> c.shift : __umul64hi(n, c.magic) >> c.shift;
+#else
+    return c.pow2 ? n >> c.shift : uint64_t((static_cast<unsigned __int128>(n) * c.magic) >> 64) >> c.shift;
+#endif
+}
+
 }  // namespace bsq_dev

@@ -325,6 +325,7 @@ Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
                   {"expand_slots", "BSQ_EXPAND_SLOTS", 0, false},
                   {"tokenize_nch", "BSQ_TOKENIZE_NCH", 0, false},
                   {"expand_mode", "BSQ_EXPAND_MODE", 0, false},
+                  {"chunk_math", "BSQ_CHUNK_MATH", 0, false},
                   {"tokens8", "BSQ_TOKENS8", 0, false},
                   {"tokens8_abl", "BSQ_TOKENS8_ABL", 0, false},
                   {"tokens8_lookup", "BSQ_TOKENS8_LOOKUP", 0, false},

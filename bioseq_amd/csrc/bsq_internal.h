@@ -20,6 +20,8 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokenize_path 1: never use k_tokenize_chunks / the raw-token kernel for batch_tokenize
 //   tokenize_pad  unused dynamic LDS of k_tokenize_chunks (experiments: no cap helps it)
 //   tokenize_nch  4: software-pipelined four chunks per wave in k_tokenize_chunks (experiments: slower than 1)
+//   chunk_math    2: scalar 64-bit integer reciprocals (div64) for the chunk coordinates of the expansion kernels
+//                 instead of the double reciprocals (div_by); measured 1 % slower at the optimum occupancy
 //   tokens8       1: never use k_tokens_bp8 for the (B,P) int8 token matrix (falls back to k_tokenize_chunks)
 //   tokens8_lookup  0 automatic, 1 LDS byte table, 2 register table (v_perm_b32)
 //   tokens8_pad   unused dynamic LDS of k_tokens_bp8;  tokens8_abl  ablation experiments (diagnostic)

@@ -17,6 +17,8 @@
 //   k_tokens_raw +     two-pass (P,B,C) one-hot for any pitch: raw uint8 tokens through tiled, coalesced
 //   k_expand_chunks    character reads into a scratch matrix, then the chunk-wise flat expansion of it.
 //                      Large outputs; cfg3: 92 % of HBM peak (the expansion alone writes at 7.5-7.8 TB/s).
+//   k_expand_small     the expansion for rows of 16..63 bytes (hundreds of rows per chunk): four rows per lane from
+//                      one unaligned dword of tokens, all of a chunk's token loads in flight together.
 //   k_onehot_chunks    (P,B,C) one-hot, chunk-owner form, one launch: a wave gathers the characters of the
 //                      ~4096/rowbytes rows of its chunk (consecutive sequences at one position), LUT from a
 //                      wave-private LDS table, scatters the ones into a 4-KiB LDS image, streams it out.
@@ -25,6 +27,7 @@
 //                      images; small rows / small outputs.
 //   k_tokenize_chunks  (B,P) tokens and the channels-first (B,C,P) one-hot: flat chunk stream, a lane owns 16
 //                      output bytes of one sequence row, unaligned vector loads of its characters.
+//                      (The (B,P) int8 matrix has its own kernel: k_tokens_bp8, bsq_tokens8.hip.)
 //   k_tokenize_rows    (B,P) tokens for odd padlen / unaligned bases.
 //   k_tokens_raw<value>, k_tokenize_tile   (P,B) tokens (int8 / wider types): tiled transpose through LDS.
 //   k_*_generic        one thread per output element; any shape / alignment / alphabet (BYTES has ids > 255).
@@ -461,11 +464,52 @@ struct EParams {
     uint32_t rb_magic, rb_shift, rb_pow2;  // fast_div() constants of rowbytes
     int32_t force4;                        // experiment knob "expand_slots" = 4: always four token slots per step
     int32_t mode;                          // k_expand_small: 9 = no token loads (ablation)
+    int64_t pitch;                         // B * rowbytes: bytes of one position row of the output
+    Div64 dv_pitch, dv_rb;                 // div64() constants of pitch and rowbytes (scalar chunk arithmetic)
 };
+
+// Where chunk k of the flat output lies: byte range [lo, lo + len) relative to `out`, first row r_lo = t_lo * B +
+// b_lo intersecting it, `skip` bytes of that row before the chunk, `nr` rows intersecting it.  k is WAVE-UNIFORM.
+// MATH 1: 64-bit integer reciprocal multiplies -- scalar-ALU work on uniform operands; MATH 0: the double
+// reciprocals of round 1 (div_by; always vector-ALU work at the FP64 rate).
+struct ChunkCoord {
+    int64_t lo, t_lo, b_lo;
+    int32_t len, skip, nr;
+    bool live;
+};
+template <int MATH>
+__device__ __forceinline__ ChunkCoord chunk_coord(const EParams &p, int64_t k, int32_t rowbytes) {
+    ChunkCoord c;
+    int64_t lo = k * kChunk - p.head, hi = lo + kChunk;  // byte range relative to `out`
+    if (lo < 0) lo = 0;
+    if (hi > p.total) hi = p.total;
+    c.live = k < p.nchunks && hi > lo;
+    c.lo = lo;
+    c.len = c.live ? static_cast<int32_t>(hi - lo) : 0;
+    c.t_lo = c.b_lo = 0;
+    c.skip = c.nr = 0;
+    if (!c.live) return c;
+    if constexpr (MATH == 1) {
+        const uint64_t t = div64(static_cast<uint64_t>(lo), p.dv_pitch);      // position
+        const uint64_t rem = static_cast<uint64_t>(lo) - t * static_cast<uint64_t>(p.pitch);
+        const uint64_t b = div64(rem, p.dv_rb);                               // sequence
+        c.t_lo = static_cast<int64_t>(t);
+        c.b_lo = static_cast<int64_t>(b);
+        c.skip = static_cast<int32_t>(rem - b * static_cast<uint64_t>(rowbytes));
+    } else {
+        int64_t skip64, b_lo;
+        const int64_t r_lo = div_by(lo, rowbytes, p.inv_rowbytes, &skip64);
+        c.skip = static_cast<int32_t>(skip64);
+        c.t_lo = div_by(r_lo, p.B, p.inv_B, &b_lo);
+        c.b_lo = b_lo;
+    }
+    c.nr = static_cast<int32_t>(fast_div(static_cast<uint32_t>(c.skip + c.len + rowbytes - 1), p.rb_magic, p.rb_shift, p.rb_pow2));
+    return c;
+}
 
 // (A variant with the four waves of a workgroup sharing one chunk -- the shape of the fastest plain fill --
 // measured 1.6x slower: every wave then pays the token-load latency for a single 1-KiB store.)
-template <typename ST, bool NT>
+template <typename ST, bool NT, int MATH>
 __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     constexpr int PIECE = kChunk;             // bytes per wave
     constexpr int NS = PIECE / 1024;          // 16-byte stores per lane
@@ -475,23 +519,18 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
 
-    // chunk of this wave: class = blockIdx % 8 (pinned to the XCD the block lands on)
-    const int64_t slot = static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave;
+    // chunk of this wave: class = blockIdx % 8 (pinned to the XCD the block lands on).  The wave index goes through
+    // readfirstlane so that the chunk arithmetic below is scalar-ALU work.
+    const int wave_s = MATH == 1 ? __builtin_amdgcn_readfirstlane(wave) : wave;
+    const int64_t slot = static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s;
     const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot;
     if (k >= p.nchunks) return;
     const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
     const ST one = static_cast<ST>(p.one_bits);
-    int64_t lo = k * kChunk - p.head, hi = lo + PIECE;  // byte range relative to `out`
-    if (lo < 0) lo = 0;
-    if (hi > p.total) hi = p.total;
-    if (hi <= lo) return;
-    const int32_t len = static_cast<int32_t>(hi - lo);
-    int64_t skip64, b_lo;
-    const int64_t r_lo = div_by(lo, rowbytes, p.inv_rowbytes, &skip64);  // first row intersecting the piece
-    const int32_t skip = static_cast<int32_t>(skip64);                   // bytes of row r_lo before the piece
-    const int32_t nr = static_cast<int32_t>(fast_div(static_cast<uint32_t>(skip + len + rowbytes - 1), p.rb_magic,
-                                                     p.rb_shift, p.rb_pow2));  // rows intersecting it
-    const int64_t t_lo = div_by(r_lo, p.B, p.inv_B, &b_lo);              // flat row r = t*B + b
+    const ChunkCoord cc = chunk_coord<MATH>(p, k, rowbytes);
+    if (!cc.live) return;
+    const int64_t lo = cc.lo, b_lo = cc.b_lo, t_lo = cc.t_lo;
+    const int32_t len = cc.len, skip = cc.skip, nr = cc.nr;
     const uint8_t *tok = p.tok + t_lo * p.Bp + b_lo;
     const int64_t wrap_at = p.B - b_lo;  // rows i >= wrap_at belong to position t_lo + 1 (or later)
     // scatter: row r_lo + i has its one at image byte i*rowbytes - skip + tok*sizeof(ST).
@@ -519,9 +558,6 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
             if (tk[q] != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
         }
     };
-    // Token loads as DWORDS: a lane takes four consecutive rows from one (unaligned) 4-byte load -- a third to a
-    // quarter of the load instructions of the byte form when a chunk holds hundreds of rows (rows of a few bytes).
-    // The last lane's dword is pulled back to end at the last needed token (never a byte beyond it) and shifted.
     for (int32_t i0 = 0; i0 < nr_s; i0 += 256) {
         const int32_t left = p.force4 ? 256 : nr_s - i0;
         if (left > 192) step(std::integral_constant<int, 4>{}, i0);
@@ -551,7 +587,7 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
 // soon as its four ds_read_b128 are issued).  Measured (profiles/r02/expand_lab*.txt): with ~32 waves per CU the
 // write stream is saturated only while nearly every resident wave has stores in flight; the dependent token load
 // of a one-chunk wave leaves 30 % of them waiting (cfg4 int8: 0.235 ms vs 0.165 ms without token loads).
-template <typename ST, bool NT, int CPW>
+template <typename ST, bool NT, int CPW, int MATH>
 __global__ __launch_bounds__(kThreads) void k_expand_small(const EParams p) {
     __shared__ __align__(16) uint8_t s_img[4][kChunk];
     constexpr int kSlots = 5;  // x 256 rows per chunk: rows of >= 4 bytes
@@ -561,7 +597,8 @@ __global__ __launch_bounds__(kThreads) void k_expand_small(const EParams p) {
     for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
     const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
     const ST one = static_cast<ST>(p.one_bits);
-    const int64_t slot0 = (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave) * CPW;
+    const int wave_s = MATH == 1 ? __builtin_amdgcn_readfirstlane(wave) : wave;
+    const int64_t slot0 = (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s) * CPW;
     const int64_t k0 = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot0;  // class = blockIdx % 8, CPW consecutive slots
     if (k0 >= p.nchunks) return;
 
@@ -572,23 +609,17 @@ __global__ __launch_bounds__(kThreads) void k_expand_small(const EParams p) {
     uint32_t w[CPW][kSlots];
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
-        const int64_t k = k0 + 8 * c;
-        int64_t l = k * kChunk - p.head, h = l + kChunk;
-        if (l < 0) l = 0;
-        if (h > p.total) h = p.total;
-        live[c] = k < p.nchunks && h > l;  // wave-uniform
-        lo[c] = l;
-        len[c] = live[c] ? static_cast<int32_t>(h - l) : 0;
+        const ChunkCoord cc = chunk_coord<MATH>(p, k0 + 8 * c, rowbytes);
+        live[c] = cc.live;  // wave-uniform
+        lo[c] = cc.lo;
+        len[c] = cc.len;
         nr[c] = 0;
         wraps[c] = false;
         if (!live[c]) continue;
-        int64_t skip64, b_lo;
-        const int64_t r_lo = div_by(l, rowbytes, p.inv_rowbytes, &skip64);
-        skip[c] = static_cast<int32_t>(skip64);
-        nr[c] = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(
-            fast_div(static_cast<uint32_t>(skip[c] + len[c] + rowbytes - 1), p.rb_magic, p.rb_shift, p.rb_pow2)));
-        const int64_t t_lo = div_by(r_lo, p.B, p.inv_B, &b_lo);
-        tok[c] = p.tok + t_lo * p.Bp + b_lo;
+        skip[c] = cc.skip;
+        nr[c] = __builtin_amdgcn_readfirstlane(cc.nr);
+        const int64_t b_lo = cc.b_lo;
+        tok[c] = p.tok + cc.t_lo * p.Bp + b_lo;
         wraps[c] = p.B - b_lo < nr[c] || nr[c] < 4;  // runs over the end of position t_lo's rows (or tiny): byte path
 #pragma unroll
         for (int q = 0; q < kSlots; ++q) {
@@ -618,12 +649,8 @@ __global__ __launch_bounds__(kThreads) void k_expand_small(const EParams p) {
                 }
             }
         } else {  // rare: byte loads, row by row, across the pitch padding of the scratch
-            const int64_t k = k0 + 8 * c;
-            int64_t l = k * kChunk - p.head;
-            if (l < 0) l = 0;
-            int64_t skip64, b_lo;
-            const int64_t r_lo = div_by(l, rowbytes, p.inv_rowbytes, &skip64);
-            const int64_t t_lo = div_by(r_lo, p.B, p.inv_B, &b_lo);
+            const ChunkCoord cw = chunk_coord<MATH>(p, k0 + 8 * c, rowbytes);
+            const int64_t b_lo = cw.b_lo, t_lo = cw.t_lo;
             for (int32_t i = lane; i < nr[c]; i += 64) {
                 int64_t b = b_lo + i, t = t_lo;
                 if (b >= p.B) {
@@ -1516,26 +1543,37 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     const dim3 grid(unsigned(groups * 8));
     // Occupancy cap through unused dynamic LDS (3 x (16 KiB image + 36 KiB) = 156 KiB <= 160 KiB; 37 KiB already
     // rounds up to 2 per CU).  Rows >= 64 B (one token load per lane and chunk): 3 workgroups per CU stream
-    // cfg3 at 7.5-7.8 TB/s, 8 at 6.3, 4 at 6.7, 2 at 5.5.  Smaller rows: no cap -- shapes disagree (1M x 160 x 28 B
-    // wants all 8, 64k x 2048 x 28 B is 6 % faster at 4; profiles/r01/sweep_occupancy2.txt).  12 waves per CU is
+    // cfg3 at 7.5-7.8 TB/s, 8 at 6.3, 4 at 6.7, 2 at 5.5.  Smaller rows: 5 workgroups per CU (16 KiB + 16 KiB each).
+    // In round 1 a cap HURT the 1M x 160 x 28-byte batch (0.90 ms at 5 per CU vs 0.78 uncapped) -- because the token pass
+    // then fetched every character three times and pushed its own scratch out of the Infinity Cache; with the XCD-aware
+    // tile order the token loads of the expansion are cache hits and the cap pays: 0.687 ms at 5, 0.689 at 4, 0.725 at
+    // 3, 0.731 uncapped (profiles/r02/pad_lab2.txt, pad_lab3.txt).  12 waves per CU is
     // the optimum also with 2-wave workgroups (16 / 14 / 12 / 10 waves: 0.83 / 0.81 / 0.76 / 0.93 ms), and 3 x 4 waves
     // (0.73 ms) beats 6 x 2.
     // Knob "expand_pad": 0 = this rule, > 0 = that many bytes, < 0 = none.
-    // Small rows (>= 4 bytes, < 64): k_expand_small.  Knob "expand_mode": 0 automatic, 1 always k_expand_chunks,
-    // 2 / 3 / 4 k_expand_small with 1 / 2 / 4 chunks per wave, 9 k_expand_small without token loads (ablation).
+    // Knob "expand_mode": 0 / 1 k_expand_chunks; 2 / 3 / 4 k_expand_small (dword token loads) with 1 / 2 / 4 chunks per
+    // wave, 9 k_expand_small without token loads (ablation).  k_expand_small is an experiment that lost: once the token
+    // scratch is written in XCD-aware tile order the byte-load kernel under an occupancy cap is 1-2 % ahead of it
+    // (profiles/r02/pad_lab*.txt).
     const int mode = e.mode;
     const int64_t rb = e.C * int64_t(sizeof(ST));
-    if (rb >= 4 && mode != 1 && (mode >= 2 || (rb >= 16 && rb < 64))) {
+    if (rb >= 4 && mode >= 2) {
         const int cpw = mode == 3 ? 2 : (mode == 4 ? 4 : 1);
         const int64_t g2 = (per_class + int64_t(4) * cpw - 1) / (int64_t(4) * cpw);
         const dim3 grid2(unsigned(g2 * 8));
         const int padv2 = bsq_internal::tuning("expand_pad");
         const size_t pad2 = padv2 > 0 ? size_t(padv2) : 0;
         const bool nt = bsq_internal::nontemporal_stores();
+        const bool scalar_math = bsq_internal::tuning("chunk_math") == 2;
 #define BSQ_ES(CPWV)                                                                                              \
         do {                                                                                                      \
-            if (nt) hipLaunchKernelGGL((k_expand_small<ST, true, CPWV>), grid2, dim3(kThreads), pad2, s, e);      \
-            else hipLaunchKernelGGL((k_expand_small<ST, false, CPWV>), grid2, dim3(kThreads), pad2, s, e);        \
+            if (scalar_math) {                                                                                    \
+                if (nt) hipLaunchKernelGGL((k_expand_small<ST, true, CPWV, 1>), grid2, dim3(kThreads), pad2, s, e);  \
+                else hipLaunchKernelGGL((k_expand_small<ST, false, CPWV, 1>), grid2, dim3(kThreads), pad2, s, e);    \
+            } else {                                                                                              \
+                if (nt) hipLaunchKernelGGL((k_expand_small<ST, true, CPWV, 0>), grid2, dim3(kThreads), pad2, s, e);  \
+                else hipLaunchKernelGGL((k_expand_small<ST, false, CPWV, 0>), grid2, dim3(kThreads), pad2, s, e);    \
+            }                                                                                                     \
         } while (0)
         if (cpw == 4) BSQ_ES(4);
         else if (cpw == 2) BSQ_ES(2);
@@ -1545,11 +1583,23 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     }
     const int padv = bsq_internal::tuning("expand_pad");
     const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;
-    const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : (big_rows ? size_t(36864) : size_t(0)));
-    if (bsq_internal::nontemporal_stores())
-        hipLaunchKernelGGL((k_expand_chunks<ST, true>), grid, dim3(kThreads), pad, s, e);
-    else
-        hipLaunchKernelGGL((k_expand_chunks<ST, false>), grid, dim3(kThreads), pad, s, e);
+    const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : (big_rows ? size_t(36864) : size_t(16384)));
+    // knob "chunk_math": 2 = scalar 64-bit reciprocal multiplies (div64) instead of the double reciprocals (div_by).
+    // Measured (profiles/r02/math_lab1.txt): the scalar prologue is ~90 SALU instructions instead of ~130 VALU ones
+    // (22 of them FP64) and wins where a wave's latency is exposed (2 workgroups per CU: 0.938 vs 0.969 ms on cfg3),
+    // but at the bandwidth optimum (3 per CU) the double form is 1 % FASTER (0.734 vs 0.741 ms): the stream is paced by
+    // the memory system there, not by the prologue.  So the double form stays the default.
+    if (bsq_internal::tuning("chunk_math") == 2) {
+        if (bsq_internal::nontemporal_stores())
+            hipLaunchKernelGGL((k_expand_chunks<ST, true, 1>), grid, dim3(kThreads), pad, s, e);
+        else
+            hipLaunchKernelGGL((k_expand_chunks<ST, false, 1>), grid, dim3(kThreads), pad, s, e);
+    } else {
+        if (bsq_internal::nontemporal_stores())
+            hipLaunchKernelGGL((k_expand_chunks<ST, true, 0>), grid, dim3(kThreads), pad, s, e);
+        else
+            hipLaunchKernelGGL((k_expand_chunks<ST, false, 0>), grid, dim3(kThreads), pad, s, e);
+    }
     return check_launch("k_expand_chunks");
 }
 
@@ -1586,6 +1636,9 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
     e.one_bits = one_bits;
     e.inv_rowbytes = 1.0 / double(C * int64_t(sz));
     e.inv_B = 1.0 / double(B);
+    e.pitch = B * C * int64_t(sz);
+    e.dv_pitch = div64_constants(uint64_t(e.pitch));
+    e.dv_rb = div64_constants(uint64_t(C * int64_t(sz)));
     div_constants(uint32_t(C * int64_t(sz)), &e.rb_magic, &e.rb_shift, &e.rb_pow2);
     e.force4 = bsq_internal::tuning("expand_slots") == 4;
     e.mode = bsq_internal::tuning("expand_mode");
@@ -1699,7 +1752,7 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
     case 2: {
         const int64_t rb = bsq_alphabet_size(d) * int64_t(bsq_dtype_size(t));
         const int mode = bsq_internal::tuning("expand_mode");
-        return (rb >= 4 && mode != 1 && (mode >= 2 || (rb >= 16 && rb < 64))) ? "k_tokens_raw+k_expand_small" : "k_tokens_raw+k_expand_chunks";
+        return (rb >= 4 && mode >= 2) ? "k_tokens_raw+k_expand_small" : "k_tokens_raw+k_expand_chunks";
     }
     case 3: return "k_onehot_chunks";
     default: return "k_onehot_generic";
@@ -1996,6 +2049,14 @@ int64_t bsq_selftest_index_math(void) {
             int64_t rem = -1;
             const int64_t q = div_by(big, int64_t(d), inv, &rem);
             if (q != big / int64_t(d) || rem != big % int64_t(d)) return 2000000 + it;
+            // div64: dividends up to 2^63 - 1, divisors up to 2^42 (a position row of 2^31 sequences x 2000 bytes)
+            const uint64_t d64 = (j % 3 == 0) ? uint64_t(d) : ((j % 3 == 1) ? uint64_t(d) * 2000u : (next() >> 22) + 1);
+            const Div64 dc = div64_constants(d64);
+            uint64_t n64 = next() >> 1;
+            if (j % 8 == 2) n64 = (n64 / d64) * d64;
+            if (j % 8 == 6) n64 = (n64 / d64) * d64 + d64 - 1;
+            if (j % 8 == 7) n64 = (uint64_t(1) << 63) - 1 - uint64_t(j);
+            if (div64(n64, dc) != n64 / d64) return 3000000 + it;
         }
     }
     return 0;
