@@ -17,8 +17,8 @@ additionally times the whole-batch assembly over xGMI in each of its forms, neve
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      algorithmic bytes per launch / average kernel duration (HIP events on the launch
-                stream: the K steps back to back between one pair of events; the per-step event
-                pairs of the timed region are reported next to it) against the 8 TB/s HBM3E peak; `traffic` = measured HBM bytes per launch
+                stream: one pair of events around the K timed launches; a second, untimed pass
+                with one pair per step gives min / median) against the 8 TB/s HBM3E peak; `traffic` = measured HBM bytes per launch
                 from the committed rocprofv3 PMC pass (profiles/traffic.json) or null.
   cpu_baseline  the reference's CPU path on this box's host cores, same batch (N=1, rank 0 only):
                 oracle/_ref (the reference's own C++ compiled in place, kind "reference") when that
@@ -254,30 +254,33 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # THE timed region: exactly K steps between barriers.  One pair of HIP events around the same K launches (recorded on
+    # the launch stream) gives the kernel time of a step for the roofline -- rocprofv3's average kernel durations add up
+    # to it within 0-7 % on every workload.
+    la, lb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        step()
-        b.record(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
-    kern_avg_ms = float(np.mean(kern_ms))
-    if os.environ.get("BSQ_BENCH_DUMP"):  # per-step device times, for variance hunting
-        print("per-step ms:", " ".join("%.3f" % v for v in kern_ms), file=sys.stderr)
-
-    # the same K steps once more, back to back between ONE pair of events: per-step event pairs put an event record (and
-    # its ~1-2 us of queue time) between any two launches, which matters for the 20-40 us kernels of cfg2 / cfg5
-    la, lb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
     la.record(stream)
     for _ in range(args.steps):
         step()
     lb.record(stream)
-    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
     loop_ms = la.elapsed_time(lb) / args.steps
+
+    # Afterwards, untimed: the same K steps once more with one event pair PER STEP (spread: min / median).  The event
+    # records cost ~2 us of queue time per step -- 10 % of the 17-35 us steps of cfg2 / cfg5, nothing on the others --
+    # which is why they are not in the timed region.
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg_ms = float(np.mean(kern_ms))
+    if os.environ.get("BSQ_BENCH_DUMP"):  # per-step device times, for variance hunting
+        print("per-step ms:", " ".join("%.3f" % v for v in kern_ms), file=sys.stderr)
 
     gather_info = None
     if world > 1 and args.gather > 0:
@@ -337,9 +340,7 @@ def main():
     job_chars, job_out_bytes = float(tot_t[0].item()), float(tot_t[1].item())
 
     if rank == 0:
-        # kernel time of one step: the K timed steps run once more back to back between ONE pair of events (what rocprofv3
-        # reports as the kernels' average duration, within 0-7 %); the per-step event pairs of the timed region itself put an
-        # event record between any two launches, ~2 us per step, which is 10 % of the 17-35 us steps of cfg2 / cfg5 (both kept).
+        # kernel time of one step = one pair of events around the K timed launches, / K
         achieved = algo_bytes / (loop_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -383,8 +384,8 @@ def main():
                          "frac_wall": algo_bytes / (wall_max / args.steps) / 1e9 / HBM_PEAK_GBPS,  # from ms_per_step (host clock)
                          "traffic": traffic, "kernel": kernel_name,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "kernel_avg_ms": loop_ms,                    # K steps between ONE pair of events, / K
-                         "kernel_avg_ms_per_step_events": kern_avg_ms,  # one event pair per step (incl. the event records)
+                         "kernel_avg_ms": loop_ms,                    # the K timed steps between ONE pair of events, / K
+                         "kernel_avg_ms_per_step_events": kern_avg_ms,  # second, untimed pass: one event pair per step
                          "frac_per_step_events": algo_bytes / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "kernel_min_ms": float(np.min(kern_ms)), "kernel_median_ms": float(np.median(kern_ms)),
                          "fill_yardstick_gbps": fill_gbps,

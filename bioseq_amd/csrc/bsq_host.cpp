@@ -325,6 +325,8 @@ Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
                   {"expand_slots", "BSQ_EXPAND_SLOTS", 0, false},
                   {"tokenize_nch", "BSQ_TOKENIZE_NCH", 0, false},
                   {"expand_mode", "BSQ_EXPAND_MODE", 0, false},
+                  {"tile_group", "BSQ_TILE_GROUP", 0, false},
+                  {"workspace_cache", "BSQ_WORKSPACE_CACHE", 0, false},
                   {"chunk_math", "BSQ_CHUNK_MATH", 0, false},
                   {"tokens8", "BSQ_TOKENS8", 0, false},
                   {"tokens8_abl", "BSQ_TOKENS8_ABL", 0, false},
@@ -338,28 +340,113 @@ Knob *find_knob(const char *name) {
 }
 }  // namespace
 
-bsq_status workspace_acquire(size_t nbytes, hipStream_t stream, void **ptr) {
+// Stream-ordered scratch.  The two-pass one-hot path needs P x B bytes per call; a hipMallocAsync / hipFreeAsync pair
+// per call puts ~5 us of stream operations between two steps (0.7 % of a cfg3 step), so the scratch of the last few
+// (device, stream) pairs is KEPT: work on one stream is ordered, so consecutive calls on it may share the buffer without
+// any further synchronisation.  While a stream is being captured into a HIP graph the allocation is made with
+// hipMallocAsync / hipFreeAsync instead, so that the graph owns its memory and never points into this cache.
+namespace {
+struct WsEntry {
+    hipStream_t stream = nullptr;
+    int device = -1;
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    uint64_t tick = 0;
+};
+constexpr int kWsSlots = 4;
+WsEntry g_ws[kWsSlots];
+uint64_t g_ws_tick = 0;
+std::mutex g_ws_mu;
+
+bool capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
+void keep_pool_memory(int dev) {
     static std::once_flag once[kMaxDevices];
+    if (dev < 0 || dev >= kMaxDevices) return;
+    std::call_once(once[dev], [dev] {  // keep freed blocks in the pool instead of returning them to the OS
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            uint64_t keep = ~uint64_t(0);
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+    });
+}
+}  // namespace
+
+bsq_status workspace_acquire(size_t nbytes, hipStream_t stream, void **ptr) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return set_hip_error("hipGetDevice", e);
-    if (dev >= 0 && dev < kMaxDevices) {
-        std::call_once(once[dev], [dev] {  // keep freed blocks in the pool instead of returning them to the OS
-            hipMemPool_t pool = nullptr;
-            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-                uint64_t keep = ~uint64_t(0);
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-            }
-            (void)hipGetLastError();
-        });
+    keep_pool_memory(dev);
+    if (nbytes == 0) nbytes = 16;
+    if (capturing(stream) || tuning("workspace_cache") == 1) {
+        e = hipMallocAsync(ptr, nbytes, stream);
+        if (e != hipSuccess) return set_hip_error("hipMallocAsync(workspace)", e);
+        return BSQ_OK;
     }
-    e = hipMallocAsync(ptr, nbytes ? nbytes : 16, stream);
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    WsEntry *hit = nullptr, *victim = &g_ws[0];
+    for (WsEntry &w : g_ws) {
+        if (w.ptr && w.device == dev && w.stream == stream) hit = &w;
+        if (!w.ptr || (victim->ptr && w.tick < victim->tick)) victim = &w;
+    }
+    if (hit && hit->bytes >= nbytes) {
+        hit->tick = ++g_ws_tick;
+        *ptr = hit->ptr;
+        return BSQ_OK;
+    }
+    WsEntry *slot = hit ? hit : victim;
+    if (slot->ptr) {  // too small, or the least recently used stream makes room: freed in ITS stream's order
+        int prev = dev;
+        if (slot->device != dev) (void)hipSetDevice(slot->device);
+        if (hipFreeAsync(slot->ptr, slot->stream) != hipSuccess) {  // e.g. the stream was destroyed meanwhile
+            (void)hipGetLastError();
+            (void)hipFree(slot->ptr);
+        }
+        if (slot->device != dev) (void)hipSetDevice(prev);
+        *slot = WsEntry();
+    }
+    e = hipMallocAsync(ptr, nbytes, stream);
     if (e != hipSuccess) return set_hip_error("hipMallocAsync(workspace)", e);
+    slot->stream = stream;
+    slot->device = dev;
+    slot->ptr = *ptr;
+    slot->bytes = nbytes;
+    slot->tick = ++g_ws_tick;
     return BSQ_OK;
 }
 
 void workspace_release(void *ptr, hipStream_t stream) {
-    if (ptr) (void)hipFreeAsync(ptr, stream);
+    if (!ptr) return;
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        for (const WsEntry &w : g_ws)
+            if (w.ptr == ptr) return;  // cached: stays allocated for the next call on this stream
+    }
+    (void)hipFreeAsync(ptr, stream);
+}
+
+void workspace_drop_cache() {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (WsEntry &w : g_ws) {
+        if (!w.ptr) continue;
+        (void)hipSetDevice(w.device);
+        (void)hipStreamSynchronize(w.stream);
+        (void)hipFree(w.ptr);
+        w = WsEntry();
+    }
+    (void)hipSetDevice(prev);
+    (void)hipGetLastError();
 }
 
 int tuning(const char *name) {
@@ -427,6 +514,7 @@ void *bsq_pinned_scratch(size_t nbytes) {
 }
 
 void bsq_release_staging(void) {
+    bsq_internal::workspace_drop_cache();
     std::lock_guard<std::mutex> lock(g_mu);
     for (Staging &s : g_staging) {
         if (s.device < 0) continue;

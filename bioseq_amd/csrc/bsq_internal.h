@@ -20,6 +20,8 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokenize_path 1: never use k_tokenize_chunks / the raw-token kernel for batch_tokenize
 //   tokenize_pad  unused dynamic LDS of k_tokenize_chunks (experiments: no cap helps it)
 //   tokenize_nch  4: software-pipelined four chunks per wave in k_tokenize_chunks (experiments: slower than 1)
+//   tile_group    G > 1: XCD-aware tile order in groups of 8 x G sequence tiles (G = 16..64: +1 % on cfg4 int8; >= 128 loses
+//                 the L2 reuse: cfg4 f32 0.69 -> 0.90 ms at 512; profiles/r02/tile_lab3.txt)
 //   chunk_math    2: scalar 64-bit integer reciprocals (div64) for the chunk coordinates of the expansion kernels
 //                 instead of the double reciprocals (div_by); measured 1 % slower at the optimum occupancy
 //   tokens8       1: never use k_tokens_bp8 for the (B,P) int8 token matrix (falls back to k_tokenize_chunks)
@@ -35,9 +37,11 @@ int tuning(const char *name);
 bool set_tuning(const char *name, int value);
 inline bool nontemporal_stores() { return tuning("nt_stores") != 0; }
 
-// Stream-ordered scratch (hipMallocAsync from a pool that keeps its memory between calls).
+// Stream-ordered scratch: the buffer of the last few (device, stream) pairs is kept between calls (knob
+// "workspace_cache" = 1: a hipMallocAsync / hipFreeAsync pair per call instead, as under graph capture).
 bsq_status workspace_acquire(size_t nbytes, hipStream_t stream, void **ptr);
 void workspace_release(void *ptr, hipStream_t stream);
+void workspace_drop_cache();  // bsq_release_staging()
 
 // bsq_tokens8.hip: the (B,P) int8 token matrix (register-table lookups, LDS rule tables).
 bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out);

@@ -73,6 +73,7 @@ struct KParams {
     int32_t aligned;  // 1: every output row segment is 16-byte aligned -> vector stores
     int32_t ntt;      // number of position tiles
     int32_t order;    // 0: sequence-tile index fastest over blockIdx, 1: position-tile index fastest, 2: XCD-aware
+    int32_t group;    // order 2: sequence tiles per XCD and group (see tile_of_block)
     int64_t out_pitch;  // k_tokens_raw only: bytes between two position rows of its output
     uint64_t one_bits;
 };
@@ -83,9 +84,15 @@ struct KParams {
 // is tile_grid() blocks; blocks whose sequence tile lies beyond the batch exit.
 __device__ __forceinline__ void tile_of_block(const KParams &p, int32_t &tb, int32_t &tt) {
     if (p.order == 2) {
-        const uint32_t per = 8u * static_cast<uint32_t>(p.ntt);
-        tt = static_cast<int32_t>((blockIdx.x >> 3) % static_cast<uint32_t>(p.ntt));
-        tb = static_cast<int32_t>((blockIdx.x / per) * 8u + (blockIdx.x & 7u));
+        // groups of 8 * G sequence tiles: inside a group all tiles of position tile 0 first, then position tile 1, ...
+        // (G = 1: the plain XCD-aware order).  A larger G keeps the rows that are written at the same time together
+        // (DRAM locality of the store stream) while the group's characters still sit in the XCDs' L2s.
+        const uint32_t G = static_cast<uint32_t>(p.group);
+        const uint32_t per = 8u * G * static_cast<uint32_t>(p.ntt);
+        const uint32_t g = blockIdx.x / per, r = blockIdx.x % per;
+        tt = static_cast<int32_t>(r / (8u * G));
+        const uint32_t q = r % (8u * G);
+        tb = static_cast<int32_t>((g * G + (q >> 3)) * 8u + (q & 7u));
     } else if (p.order == 0) {
         tb = static_cast<int32_t>(blockIdx.x % static_cast<uint32_t>(p.ntb));
         tt = static_cast<int32_t>(blockIdx.x / static_cast<uint32_t>(p.ntb));
@@ -1264,7 +1271,8 @@ __global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offs
 // ------------------------------------------------------------------------------------------
 // Blocks of a tiled launch (see tile_of_block).
 int64_t tile_grid(const KParams &k, int64_t ntt) {
-    return (k.order == 2 ? (int64_t(k.ntb) + 7) / 8 * 8 : int64_t(k.ntb)) * ntt;
+    const int64_t unit = 8 * int64_t(k.group);
+    return (k.order == 2 ? (int64_t(k.ntb) + unit - 1) / unit * unit : int64_t(k.ntb)) * ntt;
 }
 
 bsq_status check_launch(const char *what) {
@@ -1305,7 +1313,9 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     // 78 MB; k_tokens_raw 97 -> 66 us, k_onehot_tile 258 -> 233 us: profiles/r02/order_lab.txt).
     const int order_knob = bsq_internal::tuning("tile_order");
     k.order = order_knob == 1 ? 1 : (order_knob == 3 ? 0 : 2);
-    if (k.order == 2 && (B / 64 + 8) * int64_t(k.ntt) >= (int64_t(1) << 31)) k.order = 0;  // keep the rounded-up grid in 32 bits
+    const int group_knob = bsq_internal::tuning("tile_group");
+    k.group = group_knob > 0 && group_knob <= 4096 ? group_knob : 1;
+    if (k.order == 2 && (B / 64 + 8 * int64_t(k.group)) * int64_t(k.ntt) >= (int64_t(1) << 31)) k.order = 0;  // keep the rounded-up grid in 32 bits
     k.aligned = 0;
     k.out_pitch = B;
     k.one_bits = 1;
