@@ -100,7 +100,7 @@ def _gather(local, batch_axis: int, B: int, group=None):
     return torch.cat(_all_gather_padded(local, batch_axis, B, group), dim=batch_axis)
 
 
-def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, group=None, rows_per_call: int = 128):
+def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, group=None, rows_per_call: int = 64):
     """Whole batch from per-rank shards by grouped point-to-point transfers written straight into the result.
 
     local: this rank's shard, contiguous; batch_axis 0 = (B_g, ...) slabs, 1 = (P, B_g, ...) column blocks.
