@@ -130,3 +130,44 @@ def test_unvalidated_overlong_sequences_are_clamped(gpu, variant):
         capi.check(lib.bsq_tokenize_device_generic(ctypes.byref(d), dch.data_ptr(), dof.data_ptr(), B, P, 1, capi.I8, b.data_ptr(), None))
         torch.cuda.synchronize()
         assert torch.equal(a, b), flags
+
+
+@pytest.mark.slow
+def test_more_than_2_31_output_elements(gpu, bsq):
+    """B * padlen >= 2^31: the kernel's chunk coordinates leave 32-bit arithmetic (div_by path).  Built and checked ON
+    the device against plain torch indexing, both lookup forms."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    B, lo, hi, P = 2_200_000, 900, 1000, 1008
+    assert B * P >= (1 << 31) and P % 16 == 0
+    g = torch.Generator(device=gpu).manual_seed(7)
+    lens = torch.randint(lo, hi + 1, (B,), device=gpu, generator=g, dtype=torch.int64)
+    offs = torch.zeros(B + 1, dtype=torch.int64, device=gpu)
+    offs[1:] = torch.cumsum(lens, 0)
+    total = int(offs[-1])
+    letters = torch.tensor(list(b"ACGTNacgt*"), dtype=torch.uint8, device=gpu)   # N and * are unmapped in DNA4
+    chars = letters[torch.randint(0, letters.numel(), (total,), device=gpu, generator=g)]
+    tok = bsq.Tokenizer("DNA4", 1, 1, 1)
+    lut = torch.from_numpy(np.asarray(tok.byte_table())).to(gpu).to(torch.int16)
+
+    def expected(b0, b1):
+        pos = torch.arange(P, device=gpu)[None, :] - 1
+        L = lens[b0:b1, None]
+        idx = (offs[b0:b1, None] + pos).clamp_(0, total - 1)
+        ids = lut[chars[idx].long()]
+        ids = torch.where(pos < 0, torch.full_like(ids, tok.bos()), ids)
+        ids = torch.where(pos == L, torch.full_like(ids, tok.eos()), ids)
+        ids = torch.where(pos > L, torch.full_like(ids, tok.pad()), ids)
+        return ids.clamp_(min=0).to(torch.int8)
+
+    for lookup in (2, 1):
+        capi.check(lib.bsq_tuning_set(b"tokens8_lookup", lookup))
+        try:
+            t = tok.tokenize_packed(chars, offs, P, "B", True)
+        finally:
+            capi.check(lib.bsq_tuning_set(b"tokens8_lookup", 0))
+        for b0 in list(range(0, B, 400_000)) + [B - 50_000]:
+            b1 = min(B, b0 + 50_000)
+            assert torch.equal(t[b0:b1], expected(b0, b1)), (lookup, b0)
+        del t
