@@ -150,6 +150,113 @@ __global__ __launch_bounds__(256) void k_augment(uint8_t *chars, const int64_t *
     }
 }
 
+// Attempt-parallel form of the same algorithm and the SAME random stream (results are identical to k_augment; the
+// numpy twin in tests/test_augment.py is the judge of both).  k_augment gives every sequence one lane, so a wave runs
+// until its unluckiest lane is accepted and ~93 % of its vector work is spent on lanes that are already done or were
+// never selected (frac = 0.5), all of it 64-bit multiplies of the counter RNG: 27 us on cfg5.  Here a wave owns 64
+// sequences (state in LDS, one home lane each) and spends its 64 lanes on A ATTEMPTS x 64/A pending sequences per
+// step, A = 64 / (pending sequences rounded up to a power of two): lane (g, a) evaluates attempt ctr + a of the g-th
+// pending sequence (one random word, one gathered character, one table lookup), a group ballot finds the first
+// accepted attempt in counter order, that lane draws the new residue and writes it.  32 pending sequences take 2
+// attempts each, the ~16 left 4 each, the ~4 left 16 each: three or four dependent memory round trips per wave.
+constexpr int kSeqPerWave = 64;
+__global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len,
+                                                        double frac, uint64_t seed, const AugTable *tab) {
+    __shared__ AugTable s_tab;
+    __shared__ int64_t s_start[4][kSeqPerWave], s_len[4][kSeqPerWave];
+    __shared__ uint64_t s_h0[4][kSeqPerWave];
+    __shared__ uint32_t s_ctr[4][kSeqPerWave];
+    __shared__ int32_t s_rem[4][kSeqPerWave], s_tries[4][kSeqPerWave];
+    for (int i = threadIdx.x; i < int(sizeof(AugTable) / 4); i += 256)
+        reinterpret_cast<uint32_t *>(&s_tab)[i] = reinterpret_cast<const uint32_t *>(tab)[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (static_cast<int64_t>(blockIdx.x) * 4 + wave) * kSeqPerWave + lane;
+    {   // home lanes: which sequences are augmented at all (word 0 of their stream), their spans and keys
+        int32_t rem = 0;
+        int64_t start = 0, L = 0;
+        uint64_t h0 = 0;
+        if (b < B) {
+            start = offsets[b];
+            L = offsets[b + 1] - start;
+            h0 = mix64(seed + 0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(b) + 1));
+            const bool pick = L > 0 && (!(frac < 1.0) || unit(mix64(h0 + 0xD1342543DE82EF95ull)) < frac);
+            rem = pick ? chain_len : 0;
+        }
+        s_start[wave][lane] = start;
+        s_len[wave][lane] = L;
+        s_h0[wave][lane] = h0;
+        s_ctr[wave][lane] = 1;
+        s_rem[wave][lane] = rem;
+        s_tries[wave][lane] = 0;
+    }
+    __shared__ int32_t s_sel[4][kSeqPerWave];
+    for (;;) {
+        // state written in the previous step (LDS: in order within a wave); a sequence that is visited AGAIN after a
+        // mutation (chain_len > 1) must also see the character that was stored: wait for the stores then
+        if (chain_len > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool pending = s_rem[wave][lane] > 0;
+        const uint64_t todo = __builtin_amdgcn_ballot_w64(pending);
+        if (todo == 0) break;
+        // A = attempts per sequence this step = 64 / (pending sequences rounded up to a power of two): 32 pending -> 2
+        // attempts each, 16 -> 4, ..., 1 -> 64.  The home lane of the r-th pending sequence publishes itself in s_sel[r].
+        const int npend = __builtin_popcountll(todo);
+        const int groups = npend <= 1 ? 1 : 1 << (32 - __builtin_clz(static_cast<unsigned>(npend - 1)));  // wave-uniform
+        const int shiftA = __builtin_ctz(64 / groups), A = 1 << shiftA;
+        if (pending) s_sel[wave][__builtin_popcountll(todo & ((uint64_t(1) << lane) - 1))] = lane;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int g = lane >> shiftA, a = lane & (A - 1);
+        const bool have = g < npend;
+        const int sidx = have ? s_sel[wave][g] : 0;
+        const int64_t start = s_start[wave][sidx], L = s_len[wave][sidx];
+        const uint64_t h0 = s_h0[wave][sidx];
+        const uint32_t c = s_ctr[wave][sidx] + static_cast<uint32_t>(a);  // counter of this lane's attempt
+        const int32_t tries = s_tries[wave][sidx];
+        const uint64_t r = mix64(h0 + 0xD1342543DE82EF95ull * (static_cast<uint64_t>(c) + 1));
+        const int64_t idx = static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(L)));  // uniform in [0, L)
+        bool accepted = false;
+        int row = 0;
+        double pself = 0.0;
+        if (have && tries + a < kMaxAttempts) {  // (attempts beyond the cap of this mutation are not made)
+            row = s_tab.row_of[chars[start + idx]];
+            pself = s_tab.self[row];
+            accepted = static_cast<double>(static_cast<uint32_t>(r)) * 0x1.0p-32 < 1.0 - pself;
+        }
+        const uint64_t acc = __builtin_amdgcn_ballot_w64(accepted);
+        const uint64_t mine = (acc >> (g << shiftA)) & (A == 64 ? ~uint64_t(0) : ((uint64_t(1) << A) - 1));  // this group's attempts
+        if (have) {
+            if (mine != 0) {
+                if (a == __builtin_ctzll(mine)) {  // first accepted attempt in counter order: draw the new residue, write it
+                    const double *cdf = s_tab.cdf[row];
+                    const double u = unit(mix64(h0 + 0xD1342543DE82EF95ull * (static_cast<uint64_t>(c) + 2))) * (cdf[kCols - 1] - pself);
+                    int pick = -1;
+                    for (int k = 0; k < kCols; ++k) {
+                        if (k == row) continue;
+                        pick = k;
+                        if (u < cdf[k] - (k > row ? pself : 0.0)) break;
+                    }
+                    chars[start + idx] = s_tab.letter[pick];
+                    s_ctr[wave][sidx] = c + 2;
+                    s_rem[wave][sidx] -= 1;
+                    s_tries[wave][sidx] = 0;
+                }
+            } else if (a == 0) {  // A rejections: the next counters, or give this mutation up at the cap like the twin
+                const int32_t made = tries + A < kMaxAttempts ? A : kMaxAttempts - tries;
+                s_ctr[wave][sidx] = c + static_cast<uint32_t>(made);
+                if (tries + made >= kMaxAttempts) {
+                    s_rem[wave][sidx] -= 1;
+                    s_tries[wave][sidx] = 0;
+                } else {
+                    s_tries[wave][sidx] = tries + made;
+                }
+            }
+        }
+    }
+}
+
 AugTable *g_dev_table[16] = {};
 std::mutex g_table_mu;
 
@@ -207,8 +314,12 @@ bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B,
     if (st != BSQ_OK) return st;
     const int64_t blocks = (B + 255) / 256;
     if (blocks >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "batch too large");
-    hipLaunchKernelGGL(k_augment, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
-                       offsets, B, chain_len, frac, seed, tab);
+    if (bsq_internal::tuning("augment_mode") == 1)  // one lane per sequence (round 1)
+        hipLaunchKernelGGL(k_augment, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
+                           offsets, B, chain_len, frac, seed, tab);
+    else
+        hipLaunchKernelGGL(k_augment_groups, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
+                           offsets, B, chain_len, frac, seed, tab);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bsq_internal::set_hip_error("k_augment", e);
     return BSQ_OK;

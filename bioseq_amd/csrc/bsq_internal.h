@@ -22,6 +22,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokenize_nch  4: software-pipelined four chunks per wave in k_tokenize_chunks (experiments: slower than 1)
 //   tile_group    G > 1: XCD-aware tile order in groups of 8 x G sequence tiles (G = 16..64: +1 % on cfg4 int8; >= 128 loses
 //                 the L2 reuse: cfg4 f32 0.69 -> 0.90 ms at 512; profiles/r02/tile_lab3.txt)
+//   augment_mode  1: one lane per sequence (round-1 k_augment) instead of the attempt-parallel k_augment_groups
 //   chunk_math    2: scalar 64-bit integer reciprocals (div64) for the chunk coordinates of the expansion kernels
 //                 instead of the double reciprocals (div_by); measured 1 % slower at the optimum occupancy
 //   tokens8       1: never use k_tokens_bp8 for the (B,P) int8 token matrix (falls back to k_tokenize_chunks)
