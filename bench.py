@@ -353,7 +353,7 @@ def main():
                        else (("k_tokens_bp8" if sz == 1 and P >= 128 and P % 16 == 0 else "k_tokenize_chunks")
                              if batch_first else "k_tokenize_tile"))
         if op == "augment+tokenize":
-            kernel_name = "k_augment+" + kernel_name
+            kernel_name = "k_augment_groups+" + kernel_name
         if op == "onehot_bcl":
             kernel_name = "k_tokenize_chunks<onehot bcl>"
         res = {

@@ -30,8 +30,8 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokens8_pad   unused dynamic LDS of k_tokens_bp8;  tokens8_abl  ablation experiments (diagnostic)
 //   onehot_tb     0: automatic, else force 64 / 128 / 256 sequences per tile of k_onehot_tile
 //   tile_order    0: automatic (XCD-aware), 1: position-tile index fastest, 2: XCD-aware, 3: sequence-tile index fastest
-//   expand_mode   0: automatic (k_expand_small for 16..63-byte rows), 1: always k_expand_chunks, 2 / 3 / 4: k_expand_small
-//                 with 1 / 2 / 4 chunks per wave, 9: k_expand_small without token loads (ablation)
+//   expand_mode   0 / 1: k_expand_chunks, 2: k_expand_small (dword token loads; an experiment that lost), 9: the same
+//                 without token loads (ablation)
 //   fill_mode, fill_pad   access pattern / occupancy of bsq_fill_device (write-bandwidth yardsticks)
 //   host_copy_threads     worker threads of the pipelined device -> host result copy (0: 8)
 int tuning(const char *name);

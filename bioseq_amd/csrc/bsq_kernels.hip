@@ -1561,34 +1561,19 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     // the optimum also with 2-wave workgroups (16 / 14 / 12 / 10 waves: 0.83 / 0.81 / 0.76 / 0.93 ms), and 3 x 4 waves
     // (0.73 ms) beats 6 x 2.
     // Knob "expand_pad": 0 = this rule, > 0 = that many bytes, < 0 = none.
-    // Knob "expand_mode": 0 / 1 k_expand_chunks; 2 / 3 / 4 k_expand_small (dword token loads) with 1 / 2 / 4 chunks per
-    // wave, 9 k_expand_small without token loads (ablation).  k_expand_small is an experiment that lost: once the token
-    // scratch is written in XCD-aware tile order the byte-load kernel under an occupancy cap is 1-2 % ahead of it
-    // (profiles/r02/pad_lab*.txt).
+    // Knob "expand_mode": 0 / 1 k_expand_chunks; 2 k_expand_small (dword token loads), 9 the same without token loads
+    // (ablation).  k_expand_small is an experiment that lost: once the token scratch is written in XCD-aware tile
+    // order the byte-load kernel under an occupancy cap is 1-2 % ahead of it, and two or four chunks per wave were
+    // 20-40 % slower (profiles/r02/pad_lab*.txt, expand_lab3.txt; those instantiations are no longer built).
     const int mode = e.mode;
     const int64_t rb = e.C * int64_t(sizeof(ST));
-    if (rb >= 4 && mode >= 2) {
-        const int cpw = mode == 3 ? 2 : (mode == 4 ? 4 : 1);
-        const int64_t g2 = (per_class + int64_t(4) * cpw - 1) / (int64_t(4) * cpw);
-        const dim3 grid2(unsigned(g2 * 8));
+    if (rb >= 4 && (mode == 2 || mode == 9)) {
         const int padv2 = bsq_internal::tuning("expand_pad");
         const size_t pad2 = padv2 > 0 ? size_t(padv2) : 0;
-        const bool nt = bsq_internal::nontemporal_stores();
-        const bool scalar_math = bsq_internal::tuning("chunk_math") == 2;
-#define BSQ_ES(CPWV)                                                                                              \
-        do {                                                                                                      \
-            if (scalar_math) {                                                                                    \
-                if (nt) hipLaunchKernelGGL((k_expand_small<ST, true, CPWV, 1>), grid2, dim3(kThreads), pad2, s, e);  \
-                else hipLaunchKernelGGL((k_expand_small<ST, false, CPWV, 1>), grid2, dim3(kThreads), pad2, s, e);    \
-            } else {                                                                                              \
-                if (nt) hipLaunchKernelGGL((k_expand_small<ST, true, CPWV, 0>), grid2, dim3(kThreads), pad2, s, e);  \
-                else hipLaunchKernelGGL((k_expand_small<ST, false, CPWV, 0>), grid2, dim3(kThreads), pad2, s, e);    \
-            }                                                                                                     \
-        } while (0)
-        if (cpw == 4) BSQ_ES(4);
-        else if (cpw == 2) BSQ_ES(2);
-        else BSQ_ES(1);
-#undef BSQ_ES
+        if (bsq_internal::nontemporal_stores())
+            hipLaunchKernelGGL((k_expand_small<ST, true, 1, 0>), grid, dim3(kThreads), pad2, s, e);
+        else
+            hipLaunchKernelGGL((k_expand_small<ST, false, 1, 0>), grid, dim3(kThreads), pad2, s, e);
         return check_launch("k_expand_small");
     }
     const int padv = bsq_internal::tuning("expand_pad");
@@ -1762,7 +1747,7 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
     case 2: {
         const int64_t rb = bsq_alphabet_size(d) * int64_t(bsq_dtype_size(t));
         const int mode = bsq_internal::tuning("expand_mode");
-        return (rb >= 4 && mode >= 2) ? "k_tokens_raw+k_expand_small" : "k_tokens_raw+k_expand_chunks";
+        return (rb >= 4 && (mode == 2 || mode == 9)) ? "k_tokens_raw+k_expand_small" : "k_tokens_raw+k_expand_chunks";
     }
     case 3: return "k_onehot_chunks";
     default: return "k_onehot_generic";

@@ -35,7 +35,7 @@ def run(budget=120.0, seed=1):
         path = int(rng.integers(0, 4))
         capi.check(lib.bsq_tuning_set(b"onehot_path", path))
         capi.check(lib.bsq_tuning_set(b"tokenize_path", int(rng.integers(0, 2))))
-        knobs = (int(rng.integers(0, 4)), int(rng.choice([0, 0, 1, 2, 3, 4])), int(rng.integers(0, 3)), int(rng.integers(0, 2)))
+        knobs = (int(rng.integers(0, 4)), int(rng.choice([0, 0, 1, 2])), int(rng.integers(0, 3)), int(rng.integers(0, 2)))
         capi.check(lib.bsq_tuning_set(b"tile_order", knobs[0]))
         capi.check(lib.bsq_tuning_set(b"expand_mode", knobs[1]))
         capi.check(lib.bsq_tuning_set(b"tokens8_lookup", knobs[2]))
