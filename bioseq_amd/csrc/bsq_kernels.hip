@@ -472,6 +472,8 @@ struct EParams {
     int32_t force4;                        // experiment knob "expand_slots" = 4: always four token slots per step
     int32_t mode;                          // k_expand_small: 9 = no token loads (ablation)
     int64_t pitch;                         // B * rowbytes: bytes of one position row of the output
+    unsigned int *claim;                   // CLAIM: 8 counters, 128 bytes apart, zeroed before the launch
+    int64_t groups_per_class;              // CLAIM: slots-of-4 per class
     Div64 dv_pitch, dv_rb;                 // div64() constants of pitch and rowbytes (scalar chunk arithmetic)
 };
 
@@ -516,7 +518,11 @@ __device__ __forceinline__ ChunkCoord chunk_coord(const EParams &p, int64_t k, i
 
 // (A variant with the four waves of a workgroup sharing one chunk -- the shape of the fastest plain fill --
 // measured 1.6x slower: every wave then pays the token-load latency for a single 1-KiB store.)
-template <typename ST, bool NT, int MATH>
+// CLAIM = 1 (knob "xcd_claim", measurement only): the chunk class is not blockIdx % 8 but the XCD the workgroup
+// really runs on (HW_REG_XCC_ID), and its slot comes from that class's atomic counter (p.claim[class * 32], zeroed
+// before the launch); a class that has run out hands the workgroup on to the next one, so every slot is taken
+// exactly once whatever the placement.  No workgroup waits for another.
+template <typename ST, bool NT, int MATH, int CLAIM = 0>
 __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     constexpr int PIECE = kChunk;             // bytes per wave
     constexpr int NS = PIECE / 1024;          // 16-byte stores per lane
@@ -529,8 +535,32 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     // chunk of this wave: class = blockIdx % 8 (pinned to the XCD the block lands on).  The wave index goes through
     // readfirstlane so that the chunk arithmetic below is scalar-ALU work.
     const int wave_s = MATH == 1 ? __builtin_amdgcn_readfirstlane(wave) : wave;
-    const int64_t slot = static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s;
-    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot;
+    int64_t group = static_cast<int64_t>(blockIdx.x >> 3);
+    int32_t cls = static_cast<int32_t>(blockIdx.x & 7u);
+    if constexpr (CLAIM == 1) {
+        __shared__ int64_t s_claim[2];
+        if (threadIdx.x == 0) {
+            uint32_t id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+            int32_t c = static_cast<int32_t>(id & 7u);
+            int64_t got = -1;
+            for (int tries = 0; tries < 8 && got < 0; ++tries, c = (c + 1) & 7) {
+                const unsigned int s = atomicAdd(p.claim + c * 32, 1u);
+                if (static_cast<int64_t>(s) < p.groups_per_class) {
+                    got = s;
+                    break;
+                }
+            }
+            s_claim[0] = got;
+            s_claim[1] = c;
+        }
+        __syncthreads();
+        group = s_claim[0];
+        cls = static_cast<int32_t>(s_claim[1]);
+        if (group < 0) return;
+    }
+    const int64_t slot = group * 4 + wave_s;
+    const int64_t k = static_cast<int64_t>(cls) + 8 * slot;
     if (k >= p.nchunks) return;
     const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
     const ST one = static_cast<ST>(p.one_bits);
@@ -1579,6 +1609,22 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     const int padv = bsq_internal::tuning("expand_pad");
     const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;
     const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : (big_rows ? size_t(36864) : size_t(16384)));
+    if (bsq_internal::tuning("xcd_claim") == 1) {  // measurement only: placement-independent chunk classes (see the kernel)
+        static unsigned int *counters[16] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return bsq_internal::set_error(BSQ_ERR_HIP, "hipGetDevice");
+        if (!counters[dev] && hipMalloc(reinterpret_cast<void **>(&counters[dev]), 8 * 128) != hipSuccess)
+            return bsq_internal::set_error(BSQ_ERR_ALLOC, "claim counters");
+        if (hipMemsetAsync(counters[dev], 0, 8 * 128, s) != hipSuccess) return bsq_internal::set_error(BSQ_ERR_HIP, "hipMemsetAsync");
+        EParams ec = e;
+        ec.claim = counters[dev];
+        ec.groups_per_class = groups;
+        if (bsq_internal::nontemporal_stores())
+            hipLaunchKernelGGL((k_expand_chunks<ST, true, 0, 1>), grid, dim3(kThreads), pad, s, ec);
+        else
+            hipLaunchKernelGGL((k_expand_chunks<ST, false, 0, 1>), grid, dim3(kThreads), pad, s, ec);
+        return check_launch("k_expand_chunks<claim>");
+    }
     // knob "chunk_math": 2 = scalar 64-bit reciprocal multiplies (div64) instead of the double reciprocals (div_by).
     // Measured (profiles/r02/math_lab1.txt): the scalar prologue is ~90 SALU instructions instead of ~130 VALU ones
     // (22 of them FP64) and wins where a wave's latency is exposed (2 workgroups per CU: 0.938 vs 0.969 ms on cfg3),
@@ -1634,6 +1680,8 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
     e.pitch = B * C * int64_t(sz);
     e.dv_pitch = div64_constants(uint64_t(e.pitch));
     e.dv_rb = div64_constants(uint64_t(C * int64_t(sz)));
+    e.claim = nullptr;
+    e.groups_per_class = 0;
     div_constants(uint32_t(C * int64_t(sz)), &e.rb_magic, &e.rb_shift, &e.rb_pow2);
     e.force4 = bsq_internal::tuning("expand_slots") == 4;
     e.mode = bsq_internal::tuning("expand_mode");
