@@ -136,6 +136,9 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
         reinterpret_cast<uint32_t *>(s_lut4[wave])[lane] = w;
     }
     const uint8_t *lut = s_lut4[LK == 0 ? wave : 0];
+    // the tables are wave-private: LDS operations of one wave execute in order, only the compiler must not reorder them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     const bool small = p.total < (int64_t(1) << 31);
     const uint32_t P = p.P;
