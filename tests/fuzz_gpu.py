@@ -22,6 +22,8 @@ def run(budget=120.0, seed=1):
         eos, bos, pad = (int(x) for x in rng.integers(0, 2, 3))
         B = int(rng.choice([1, 2, 7, 63, 64, 65, 200, 255, 256, 257, 1000, 4096, 5000, 20000]))
         P = int(rng.choice([1, 3, 15, 16, 17, 63, 64, 65, 100, 128, 255, 300, 512])) + eos + bos
+        if rng.random() < 0.25:  # multiples of 16 from 128 up: the (B,P) int8 kernel k_tokens_bp8 applies
+            P = int(rng.choice([128, 144, 160, 272, 512, 1024, 2048, 4112]))
         hi = P - eos - bos
         lo = int(rng.integers(0, hi + 1))
         if B * P > 6_000_000:
