@@ -42,6 +42,7 @@ WORKLOADS = {
     "cfg3": ("cfg3", "onehot", "f", False),
     "cfg3bcl": ("cfg3", "onehot_bcl", "f", False),  # channels-first (B,C,P) written directly (loader layout)
     "cfg2": ("cfg2", "tokenize", "B", True),
+    "cfg2sf": ("cfg2", "tokenize", "B", False),   # the reference's DEFAULT layout of batch_tokenize: (padlen, batch)
     "cfg4f": ("cfg4", "onehot", "f", False),
     "cfg4b": ("cfg4", "onehot", "B", False),
     "cfg5": ("cfg5", "tokenize", "B", True),
@@ -351,7 +352,7 @@ def main():
                 traffic = None
         kernel_name = (lib.bsq_onehot_kernel_name(ctypes.byref(desc), n, P, dt_code).decode() if op == "onehot"
                        else (("k_tokens_bp8" if sz == 1 and P >= 128 and P % 16 == 0 else "k_tokenize_chunks")
-                             if batch_first else "k_tokenize_tile"))
+                             if batch_first else ("k_tokens_raw<value>" if sz == 1 else "k_tokenize_tile")))
         if op == "augment+tokenize":
             kernel_name = "k_augment_groups+" + kernel_name
         if op == "onehot_bcl":

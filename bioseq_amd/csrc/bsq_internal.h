@@ -22,6 +22,8 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokenize_nch  4: software-pipelined four chunks per wave in k_tokenize_chunks (experiments: slower than 1)
 //   tile_group    G > 1: XCD-aware tile order in groups of 8 x G sequence tiles (G = 16..64: +1 % on cfg4 int8; >= 128 loses
 //                 the L2 reuse: cfg4 f32 0.69 -> 0.90 ms at 512; profiles/r02/tile_lab3.txt)
+//   raw_mode      2 / 3: k_tokens_raw2 (4 x 4 byte transpose in registers via v_permlane32/16_swap; LDS / register
+//                 alphabet table) instead of k_tokens_raw; measured 7-15 % slower (profiles/r02/raw_lab.txt)
 //   xcd_claim     1: k_expand_chunks takes its chunk class from HW_REG_XCC_ID and its slot from per-class atomic counters
 //                 (placement-independent; measured 17-32 % slower: profiles/r02/claim_lab.txt)
 //   augment_mode  1: one lane per sequence (round-1 k_augment) instead of the attempt-parallel k_augment_groups

@@ -76,6 +76,8 @@ struct KParams {
     int32_t group;    // order 2: sequence tiles per XCD and group (see tile_of_block)
     int64_t out_pitch;  // k_tokens_raw only: bytes between two position rows of its output
     uint64_t one_bits;
+    uint32_t tab_raw[8], tab_val[8];  // 32-entry folded alphabet (index c & 31): ids with kNone / values with 0 for unmapped
+    int32_t foldable;                 // the folded tables represent lut[] exactly (letters only, both cases alike)
 };
 
 // order 2 (XCD-aware): the position tiles of ONE sequence tile go to blocks b, b + 8, b + 16, ... -- one XCD under
@@ -224,6 +226,35 @@ __device__ __forceinline__ uint32_t finish4(const TokenRule p, const uint8_t *s_
     const uint32_t first = j0 < 0 ? 0xFFu : 0u;
     w = (w & ~first) | (p.bos_id & first);
     return w;
+}
+
+// The position rules of finish4 on an already looked-up word (bytes = positions tpos .. tpos + 3).
+__device__ __forceinline__ uint32_t rules4(const TokenRule p, uint32_t w, int32_t L, int32_t tpos) {
+    const int32_t j0 = tpos - p.bos;
+    const int32_t nv = L - j0;
+    const int32_t nvc = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+    const uint32_t keep = static_cast<uint32_t>((uint64_t(1) << (8 * nvc)) - 1u);  // low nvc bytes
+    w = (w & keep) | ((p.fill_id * 0x01010101u) & ~keep);
+    const uint32_t at = (nv >= 0 && nv < 4) ? (0xFFu << (8 * nvc)) : 0u;
+    w = (w & ~at) | ((p.at_len_id * 0x01010101u) & at);
+    const uint32_t first = j0 < 0 ? 0xFFu : 0u;
+    w = (w & ~first) | (p.bos_id & first);
+    return w;
+}
+
+// Four lookups in the 32-entry folded table (index c & 31, eight dwords in registers): 4 + 2 + 1 v_perm_b32 over
+// bits 2:0, 3 and 4 of each byte (the same scheme as k_tokens_bp8, bsq_tokens8.hip).
+__device__ __forceinline__ uint32_t lookup4_folded(uint32_t cw, const uint32_t (&T)[8]) {
+    const uint32_t sel = cw & 0x07070707u;
+    const uint32_t r0 = __builtin_amdgcn_perm(T[1], T[0], sel);
+    const uint32_t r1 = __builtin_amdgcn_perm(T[3], T[2], sel);
+    const uint32_t r2 = __builtin_amdgcn_perm(T[5], T[4], sel);
+    const uint32_t r3 = __builtin_amdgcn_perm(T[7], T[6], sel);
+    const uint32_t s3 = ((cw >> 1) & 0x04040404u) | 0x03020100u;
+    const uint32_t lo = __builtin_amdgcn_perm(r1, r0, s3);
+    const uint32_t hi = __builtin_amdgcn_perm(r3, r2, s3);
+    const uint32_t s4 = ((cw >> 2) & 0x04040404u) | 0x03020100u;
+    return __builtin_amdgcn_perm(hi, lo, s4);
 }
 
 __device__ __forceinline__ uint32_t resolve4(const TokenRule p, const uint8_t *s_lut, uint32_t start, int32_t L,
@@ -813,6 +844,113 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     }
 }
 
+// Round-2 EXPERIMENT on the same tile (no mask; knob "raw_mode" 2 / 3; measured slower, see launch_tokens_raw).  The idea:
+// k_tokens_raw spends four ds_read_u8 lookups and four transposed ds_write_b8 per word of four tokens.  Here
+//   * the 4 x 4 byte transpose happens in registers: the four lanes l, l+16, l+32, l+48 hold the same four positions of
+//     four CONSECUTIVE sequences; v_permlane32_swap + v_perm_b32, then v_permlane16_swap + v_perm_b32 leave lane (g, s)
+//     with position 4g + s of those four sequences -- one ds_write_b32 instead of four byte writes;
+//   * PERM: the alphabet lookup runs in registers (32-entry folded table, v_perm_b32: see bsq_tokens8.hip), non-letters
+//     fixed on a wave-uniform slow path; otherwise the LDS byte table.
+template <bool RAW, bool PERM>
+__global__ __launch_bounds__(kThreads) void k_tokens_raw2(const KParams p) {
+    __shared__ __align__(16) uint8_t s_lut[256];
+    __shared__ __align__(16) SeqSpan s_span[kRawTB];
+    __shared__ __align__(16) uint8_t s_t[kTT * kRawStride];
+    const int tid = threadIdx.x;
+    int32_t tb, tt;
+    tile_of_block(p, tb, tt);
+    if (tb >= p.ntb) return;
+    const int64_t b0 = static_cast<int64_t>(tb) * kRawTB;
+    const int32_t t0 = tt * kTT;
+    if constexpr (!PERM) stage_lut(p, s_lut);
+    TokenRule rule = make_rule(p, b0, kRawTB);
+    stage_spans(p, rule, b0, kRawTB, s_span);
+    __syncthreads();
+    if (!RAW) {  // value space: "no token" is the memset 0 of tokenize.h:427
+        if constexpr (!PERM) {
+            if (tid < 64) {
+                uint32_t w = reinterpret_cast<uint32_t *>(s_lut)[tid];
+                uint32_t z = (~w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;   // bytes equal to 0xFF <=> ~byte == 0
+                z = ~(z | ~w | 0x7F7F7F7Fu);
+                reinterpret_cast<uint32_t *>(s_lut)[tid] = w & ~((z >> 7) * 0xFFu);
+            }
+            __syncthreads();
+        }
+        if (rule.fill_id == kNone) rule.fill_id = 0;
+        if (rule.at_len_id == kNone) rule.at_len_id = 0;
+    }
+    uint32_t T[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) T[i] = RAW ? p.tab_raw[i] : p.tab_val[i];
+    const uint32_t none_w = RAW ? 0xFFFFFFFFu : 0u;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane & 15, sq = lane >> 4;  // positions 4g .. 4g+3 of sequence 4m + sq
+    const int32_t tpos = t0 + 4 * g;
+    // byte selectors of the two transpose stages (v_perm_b32(S0, S1, sel): bytes 0-3 = S1, 4-7 = S0)
+    const uint32_t selA = lane < 32 ? 0x05040100u : 0x07060302u;
+    const uint32_t selB = (lane & 16) ? 0x07030501u : 0x06020400u;
+    constexpr int NI = kRawTB / 16, BATCH = 8;  // 16 steps of 16 sequences (4 per wave)
+#pragma unroll 1
+    for (int i0 = 0; i0 < NI; i0 += BATCH) {
+        Raw4 raw[BATCH];
+        int32_t len[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int sb = 4 * (wave + 4 * (i0 + k)) + sq;
+            const SeqSpan sp = s_span[sb];
+            len[k] = sp.len;
+            raw[k] = fetch4<false>(rule, sp.start, tpos);
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            uint32_t w;
+            if constexpr (PERM) {
+                const uint32_t cw = __builtin_amdgcn_alignbyte(raw[k].b, raw[k].a, raw[k].sh & 3u);
+                w = lookup4_folded(cw, T);
+                const uint32_t bad = (cw ^ 0x40404040u) & 0xC0C0C0C0u;
+                if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {  // some lane holds a non-letter (rare): exact masks
+                    const uint32_t f = ((bad >> 6) | (bad >> 7)) & 0x01010101u;
+                    const uint32_t nl = (f << 8) - f;
+                    w = (w & ~nl) | (none_w & nl);
+                }
+                w = rules4(rule, w, len[k], tpos);
+            } else {
+                w = finish4<false>(rule, s_lut, raw[k], len[k], tpos);
+            }
+            // 4 x 4 byte transpose over the lanes l, l + 16, l + 32, l + 48
+            auto a = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+            const uint32_t h = __builtin_amdgcn_perm(a[1], a[0], selA);
+            auto b = __builtin_amdgcn_permlane16_swap(h, h, false, false);
+            const uint32_t f4 = __builtin_amdgcn_perm(b[1], b[0], selB);  // position 4g + sq of sequences 4m .. 4m + 3
+            const int m = wave + 4 * (i0 + k);
+            *reinterpret_cast<uint32_t *>(s_t + (4 * g + sq) * kRawStride + 4 * m) = f4;  // columns >= B are never read
+        }
+    }
+    __syncthreads();
+    uint8_t *out = static_cast<uint8_t *>(p.out);
+    for (int f = tid; f < kTT * (kRawTB / 16); f += kThreads) {
+        const int32_t tl = f >> 4, q = f & 15;
+        const int64_t t = static_cast<int64_t>(t0) + tl;
+        if (t >= p.P) continue;
+        const uint8_t *src = s_t + tl * kRawStride + q * 16;
+        uint8_t *dst = out + t * p.out_pitch + b0 + q * 16;
+        if (p.aligned && b0 + q * 16 + 16 <= p.out_pitch) {
+            uint4 v;  // LDS rows are only 4-byte aligned (stride 260): four dword reads
+            v.x = *reinterpret_cast<const uint32_t *>(src);
+            v.y = *reinterpret_cast<const uint32_t *>(src + 4);
+            v.z = *reinterpret_cast<const uint32_t *>(src + 8);
+            v.w = *reinterpret_cast<const uint32_t *>(src + 12);
+            if constexpr (RAW)
+                *reinterpret_cast<uint4 *>(dst) = v;  // scratch: re-read by the expansion pass right away
+            else
+                store16<true>(dst, v);               // final token matrix: streamed once
+        } else {
+            for (int i = 0; i < 16; ++i)
+                if (b0 + q * 16 + i < p.B) dst[i] = src[i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Tokens, (B,P) layout: one wave per sequence, 4 positions per lane per step, no transpose.
 // ------------------------------------------------------------------------------------------
@@ -1349,6 +1487,23 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     k.aligned = 0;
     k.out_pitch = B;
     k.one_bits = 1;
+    {   // folded tables (see k_tokens_raw2): exact iff only letter positions are mapped and both cases map alike
+        bool ok = true;
+        for (int i = 0; i < 8; ++i) k.tab_raw[i] = 0xFFFFFFFFu, k.tab_val[i] = 0;
+        for (int c = 0; c < 256 && ok; ++c) {
+            const bool mapped = c < 128 && d->lut[c] >= 0;
+            if (!mapped) continue;
+            if (c < 0x40 || d->lut[c ^ 0x20] != d->lut[c]) {
+                ok = false;
+                break;
+            }
+            const uint32_t id = uint32_t(uint8_t(d->lut[c])), sh = 8 * (c & 3);
+            uint32_t &tr = k.tab_raw[(c & 31) >> 2], &tv = k.tab_val[(c & 31) >> 2];
+            tr = (tr & ~(0xFFu << sh)) | (id << sh);
+            tv = (tv & ~(0xFFu << sh)) | (id << sh);
+        }
+        k.foldable = ok;
+    }
     return BSQ_OK;
 }
 
@@ -1655,10 +1810,18 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
     k.aligned = reinterpret_cast<uintptr_t>(tokens) % 16 == 0 && pitch % 16 == 0;  // every row starts 16-byte aligned
     k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
     const dim3 grid(unsigned(tile_grid(k, k.ntt)));
-    if (k.mask)
-        hipLaunchKernelGGL(k_tokens_raw<true>, grid, dim3(kThreads), 0, s, k);
+    // knob "raw_mode": 0 / 1 k_tokens_raw; 2 k_tokens_raw2 (register transpose) with the LDS byte table, 3 with the
+    // register table.  k_tokens_raw2 is an experiment that LOST (profiles/r02/raw_lab.txt: cfg2 as (P,B) int8 tokens
+    // 24.0 us -> 25.8 (2) / 27.4 (3); cfg3 / cfg4 f32 steps +0.1 / +0.3 %): the tile is bound by vector instructions at
+    // least as much as by LDS traffic, and the transpose trades 3 LDS writes for 6 vector instructions per word.
+    const int rm = bsq_internal::tuning("raw_mode");
+    if (k.mask || rm < 2)
+        if (k.mask) hipLaunchKernelGGL(k_tokens_raw<true>, grid, dim3(kThreads), 0, s, k);
+        else hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
+    else if (rm == 3 && k.foldable)
+        hipLaunchKernelGGL((k_tokens_raw2<true, true>), grid, dim3(kThreads), 0, s, k);
     else
-        hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
+        hipLaunchKernelGGL((k_tokens_raw2<true, false>), grid, dim3(kThreads), 0, s, k);
     return check_launch("k_tokens_raw");
 }
 
@@ -1907,7 +2070,14 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     k.aligned = (addr % 16 == 0) && ((B * int64_t(sz)) % 16 == 0);
     if (t == BSQ_I8 && bsq_internal::tuning("tokenize_path") != 1) {  // int8 (P,B): the raw-token kernel in value mode
         k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
-        hipLaunchKernelGGL((k_tokens_raw<false, false>), dim3(unsigned(tile_grid(k, k.ntt))), dim3(kThreads), 0, s, k);
+        const int rm = bsq_internal::tuning("raw_mode");
+        const dim3 vgrid(unsigned(tile_grid(k, k.ntt)));
+        if (rm < 2)
+            hipLaunchKernelGGL((k_tokens_raw<false, false>), vgrid, dim3(kThreads), 0, s, k);
+        else if (rm == 3 && k.foldable)
+            hipLaunchKernelGGL((k_tokens_raw2<false, true>), vgrid, dim3(kThreads), 0, s, k);
+        else
+            hipLaunchKernelGGL((k_tokens_raw2<false, false>), vgrid, dim3(kThreads), 0, s, k);
         return check_launch("k_tokens_raw<value>");
     }
     switch (t) {
