@@ -356,7 +356,7 @@ def main():
         if op == "augment+tokenize":
             kernel_name = "k_augment_groups+" + kernel_name
         if op == "onehot_bcl":
-            kernel_name = "k_tokenize_chunks<onehot bcl>"
+            kernel_name = "k_tokens_bp8<raw>+k_expand_bcl" if (P >= 128 and P % 16 == 0 and out_bytes >= (256 << 20)) else "k_tokenize_chunks<onehot bcl>"
         res = {
             "metric": baseline_metric() if args.workload == "cfg3"
                       else "Gseq-chars/s + GB/s written (%s)" % args.workload,

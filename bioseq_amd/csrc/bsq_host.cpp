@@ -326,6 +326,8 @@ Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
                   {"tokenize_nch", "BSQ_TOKENIZE_NCH", 0, false},
                   {"expand_mode", "BSQ_EXPAND_MODE", 0, false},
                   {"tile_group", "BSQ_TILE_GROUP", 0, false},
+                  {"bcl_path", "BSQ_BCL_PATH", 0, false},
+                  {"bcl_pad", "BSQ_BCL_PAD", 0, false},
                   {"raw_mode", "BSQ_RAW_MODE", 0, false},
                   {"xcd_claim", "BSQ_XCD_CLAIM", 0, false},
                   {"augment_mode", "BSQ_AUGMENT_MODE", 0, false},

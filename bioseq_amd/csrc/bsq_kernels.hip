@@ -1275,6 +1275,94 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Channels-first one-hot (B, C, P), two-pass form: raw (B, P) uint8 ids from k_tokens_bp8 (bsq_tokens8.hip), then
+// this expansion.  The output is the flat (B*C, P) matrix, row b*C + c = (tok[b, :] == c); one wave = one aligned
+// 4-KiB chunk (class pinned to the XCD), a lane owns 16 output bytes = EPL consecutive positions of one row, i.e. ONE
+// aligned EPL-byte load of tokens, EPL compares, one nt store.  No LDS, no dependent second load: the kernel is a pure
+// write stream (capped at 3 workgroups per CU like the (P,B,C) expansion) that re-reads each token row C times out of
+// the caches.  Needs P % EPL == 0 and a 16-byte aligned output.
+// ------------------------------------------------------------------------------------------
+struct BParams {
+    const uint8_t *tok;  // (B, P) raw ids, kNone = no one
+    uint8_t *out;
+    int64_t total, nchunks, nrows;  // output bytes, chunks, B * C
+    int64_t P;
+    int32_t C;
+    uint64_t one_bits;
+    uint32_t magic, shift, pow2;        // fast_div constants of P
+    uint32_t magic_c, shift_c, pow2_c;  // ... of C
+    double inv_P;                       // div_by constant (outputs of 2^31 elements and more)
+};
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(kThreads) void k_expand_bcl(const BParams p) {
+    constexpr int SZ = static_cast<int>(sizeof(T));
+    constexpr int EPL = 16 / SZ;
+    const int lane = threadIdx.x & 63;
+    const int wave_s = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s);
+    if (k >= p.nchunks) return;
+    const int64_t lo = k * kChunk;
+    const int64_t ec = lo / SZ;  // first element of the chunk (wave-uniform)
+    const bool small = p.nrows * p.P < (int64_t(1) << 31);
+    const uint32_t Pu = static_cast<uint32_t>(p.P);
+    int64_t rc;   // row of the chunk's first element
+    uint32_t tc;  // its position
+    if (small) {
+        const uint32_t q = fast_div(static_cast<uint32_t>(ec), p.magic, p.shift, p.pow2);
+        rc = q;
+        tc = static_cast<uint32_t>(ec) - q * Pu;
+    } else {
+        int64_t rem;
+        rc = div_by(ec, p.P, p.inv_P, &rem);
+        tc = static_cast<uint32_t>(rem);
+    }
+    const T one = static_cast<T>(p.one_bits);
+    // the four stores of the lane: element ec + u * (1024 / SZ) + lane * EPL
+    uint32_t tok[4][EPL >= 4 ? EPL / 4 : 1];
+    uint32_t chan[4];
+    bool live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t tl = tc + static_cast<uint32_t>(u * (1024 / SZ) + lane * EPL);  // < P + 4096
+        const uint32_t ql = fast_div(tl, p.magic, p.shift, p.pow2);
+        const int64_t r = rc + ql;
+        const uint32_t t = tl - ql * Pu;
+        live[u] = r < p.nrows;
+        const int64_t rr = live[u] ? r : 0;
+        int64_t b;
+        if (p.nrows < (int64_t(1) << 31))
+            b = fast_div(static_cast<uint32_t>(rr), p.magic_c, p.shift_c, p.pow2_c);
+        else
+            b = rr / p.C;
+        chan[u] = static_cast<uint32_t>(rr - b * p.C);
+        const uint8_t *src = p.tok + b * p.P + t;  // EPL-byte aligned: P % EPL == 0, t % EPL == 0
+        if constexpr (EPL == 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src);
+            tok[u][0] = v.x, tok[u][1] = v.y, tok[u][2] = v.z, tok[u][3] = v.w;
+        } else if constexpr (EPL == 8) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(src);
+            tok[u][0] = v.x, tok[u][1] = v.y;
+        } else if constexpr (EPL == 4) {
+            tok[u][0] = *reinterpret_cast<const uint32_t *>(src);
+        } else {
+            tok[u][0] = *reinterpret_cast<const uint16_t *>(src);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (!live[u]) continue;
+        alignas(16) T vals[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            const uint32_t tk = (tok[u][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            vals[i] = tk == chan[u] ? one : T(0);
+        }
+        store16<NT>(p.out + lo + u * 1024 + lane * 16, *reinterpret_cast<const uint4 *>(vals));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic one-thread-per-element kernels (ids up to 258, any alignment).
 // ------------------------------------------------------------------------------------------
 struct GParams {
@@ -1917,6 +2005,31 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     return check_launch(HOT ? "k_tokenize_chunks<onehot bcl>" : "k_tokenize_chunks");
 }
 
+template <typename T>
+bsq_status launch_expand_bcl(const uint8_t *tokens, int64_t B, int64_t P, int32_t C, uint64_t one_bits, void *out, hipStream_t s) {
+    BParams b;
+    b.tok = tokens;
+    b.out = static_cast<uint8_t *>(out);
+    b.nrows = B * C;
+    b.P = P;
+    b.C = C;
+    b.total = b.nrows * P * int64_t(sizeof(T));
+    b.nchunks = (b.total + kChunk - 1) / kChunk;
+    b.one_bits = one_bits;
+    b.inv_P = 1.0 / double(P);
+    div_constants(uint32_t(P), &b.magic, &b.shift, &b.pow2);
+    div_constants(uint32_t(C), &b.magic_c, &b.shift_c, &b.pow2_c);
+    const int64_t groups = ((b.nchunks + 7) / 8 + 3) / 4;
+    if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
+    const int padv = bsq_internal::tuning("bcl_pad");  // unused dynamic LDS = occupancy cap: 0 -> 3 workgroups per CU
+    const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : size_t(53248));
+    if (bsq_internal::nontemporal_stores())
+        hipLaunchKernelGGL((k_expand_bcl<T, true>), dim3(unsigned(groups * 8)), dim3(kThreads), pad, s, b);
+    else
+        hipLaunchKernelGGL((k_expand_bcl<T, false>), dim3(unsigned(groups * 8)), dim3(kThreads), pad, s, b);
+    return check_launch("k_expand_bcl");
+}
+
 }  // namespace
 
 extern "C" {
@@ -2104,6 +2217,29 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     k.one_bits = one_bits_of(t);
+    // Two-pass form (raw (B,P) ids, then k_expand_bcl) for large unmasked outputs; knob "bcl_path": 0 automatic,
+    // 1 never, 2 whenever it applies.
+    const int bcl_path = bsq_internal::tuning("bcl_path");
+    const int64_t total_bytes = B * int64_t(k.C) * P * int64_t(sz);
+    if (!mask_or_null && bcl_path != 1 && (bcl_path == 2 || total_bytes >= (int64_t(256) << 20)) && k.C <= 250 &&
+        reinterpret_cast<uintptr_t>(out) % 16 == 0 && P % 16 == 0 && B * int64_t(k.C) * P < (int64_t(1) << 51) &&
+        bsq_internal::tokens_bp8_applicable(d, B, P, out)) {
+        void *ws = nullptr;
+        bsq_status wst = bsq_internal::workspace_acquire(size_t(B) * size_t(P), s, &ws);
+        if (wst != BSQ_OK) return wst;
+        wst = bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, ws, s, true);
+        if (wst == BSQ_OK) {
+            const uint8_t *tk = static_cast<const uint8_t *>(ws);
+            switch (sz) {
+            case 1: wst = launch_expand_bcl<uint8_t>(tk, B, P, k.C, k.one_bits, out, s); break;
+            case 2: wst = launch_expand_bcl<uint16_t>(tk, B, P, k.C, k.one_bits, out, s); break;
+            case 4: wst = launch_expand_bcl<uint32_t>(tk, B, P, k.C, k.one_bits, out, s); break;
+            default: wst = launch_expand_bcl<uint64_t>(tk, B, P, k.C, k.one_bits, out, s); break;
+            }
+        }
+        bsq_internal::workspace_release(ws, s);
+        return wst;
+    }
     if (k.C <= 250 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && P % int64_t(16 / sz) == 0) {
         switch (sz) {
         case 1: return launch_tokenize_chunks<uint8_t, true>(k, s);

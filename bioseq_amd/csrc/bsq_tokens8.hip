@@ -43,6 +43,7 @@ struct T8Params {
     int32_t bos, room;
     uint32_t bos_id, at_len_v, fill_v;  // token VALUES at position 0, bos + L and beyond (0 where the reference leaves the memset)
     int32_t abl;       // ablation experiments (diagnostic builds of the kernel only)
+    uint32_t none_v;   // value of an unmapped character: 0 (token VALUES, tokenize.h:427) or 0xFF (raw ids for the one-hot expansion)
 };
 
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
         for (int q = 0; q < 4; ++q) {
             const int idx = lane * 4 + q;
             const int8_t v = p.lut[idx];
-            w |= ((idx < 128 && v >= 0) ? static_cast<uint32_t>(v) : 0u) << (8 * q);
+            w |= ((idx < 128 && v >= 0) ? static_cast<uint32_t>(v) : p.none_v) << (8 * q);
         }
         reinterpret_cast<uint32_t *>(s_lut4[wave])[lane] = w;
     }
@@ -272,7 +273,10 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
                 }
                 if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {  // some lane holds a non-letter: exact masks (rare)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) w[q] &= ~nonletter_mask(in[q]);
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t m = nonletter_mask(in[q]);
+                        w[q] = (w[q] & ~m) | (m & (p.none_v * 0x01010101u));
+                    }
                 }
             } else {
 #pragma unroll
@@ -315,15 +319,16 @@ namespace bsq_internal {
 
 // True when every mapped byte of `lut` is a letter position (0x40..0x7F) and both cases map alike: the
 // 32-entry folded table represents it exactly (all reference alphabets but BYTES, alphabet.h:39,44).
-static bool fold_table(const int8_t lut[256], uint32_t tab[8]) {
-    for (int i = 0; i < 8; ++i) tab[i] = 0;
+static bool fold_table(const int8_t lut[256], uint32_t tab[8], uint32_t none_v) {
+    for (int i = 0; i < 8; ++i) tab[i] = none_v * 0x01010101u;
     for (int c = 0; c < 256; ++c) {
         const bool mapped = c < 128 && lut[c] >= 0;
         if (!mapped) continue;
         if (c < 0x40) return false;
         const int other = c ^ 0x20;
         if (lut[other] != lut[c]) return false;
-        tab[(c & 31) >> 2] |= static_cast<uint32_t>(static_cast<uint8_t>(lut[c])) << (8 * (c & 3));
+        uint32_t &t = tab[(c & 31) >> 2];
+        t = (t & ~(0xFFu << (8 * (c & 3)))) | (static_cast<uint32_t>(static_cast<uint8_t>(lut[c])) << (8 * (c & 3)));
     }
     // a letter position that is unmapped in one case must be unmapped in the other (checked above for mapped ones)
     for (int c = 0x40; c < 0x80; ++c)
@@ -338,10 +343,11 @@ bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
 }
 
 bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
-                             void *out, hipStream_t s) {
+                             void *out, hipStream_t s, bool raw) {
     T8Params c;
     for (int i = 0; i < 256; ++i) c.lut[i] = d->lut[i];
-    const bool foldable = fold_table(d->lut, c.tab);
+    c.none_v = raw ? 0xFFu : 0u;  // raw: ids with BSQ_NO_TOKEN where the one-hot row is all zero (plain stores: re-read at once)
+    const bool foldable = fold_table(d->lut, c.tab, c.none_v);
     c.chars = chars;
     c.offsets = offsets;
     c.out = static_cast<uint8_t *>(out);
@@ -355,7 +361,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
     const int64_t room = P - d->bos - d->eos;
     c.room = int32_t(room < 0 ? 0 : room);
     c.bos_id = uint32_t(bsq_bos_id(d)) & 0xFFu;
-    const uint32_t fill = d->padchar ? uint32_t(bsq_pad_id(d)) : 0u;  // no padchar: the memset 0 of tokenize.h:427 stays
+    const uint32_t fill = d->padchar ? uint32_t(bsq_pad_id(d)) : c.none_v;  // no padchar: the memset 0 of tokenize.h:427 stays
     c.fill_v = fill;
     c.at_len_v = d->eos ? uint32_t(bsq_eos_id(d)) : fill;
     c.abl = tuning("tokens8_abl");
@@ -367,7 +373,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
     const dim3 grid(unsigned(groups * 8));
     const int padv = tuning("tokens8_pad");  // unused dynamic LDS = occupancy cap (experiments)
     const size_t pad = padv > 0 ? size_t(padv) : 0;
-    const bool nt = nontemporal_stores();
+    const bool nt = nontemporal_stores() && !raw;
 #define BSQ_T8(NTV, LKV) launch_variant<NTV, LKV>(c, grid, pad, s)
     if (lk == 2) { if (nt) BSQ_T8(true, 1); else BSQ_T8(false, 1); }
     else { if (nt) BSQ_T8(true, 0); else BSQ_T8(false, 0); }

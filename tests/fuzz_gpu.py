@@ -43,6 +43,7 @@ def run(budget=120.0, seed=1):
         capi.check(lib.bsq_tuning_set(b"tokens8_lookup", knobs[2]))
         capi.check(lib.bsq_tuning_set(b"tokens8", knobs[3]))
         capi.check(lib.bsq_tuning_set(b"raw_mode", int(rng.integers(0, 4))))
+        capi.check(lib.bsq_tuning_set(b"bcl_path", int(rng.integers(0, 3))))
         tok, ora = bsq.Tokenizer(key, eos, bos, pad), O.OracleTokenizer(key, eos, bos, pad)
         shift = int(rng.integers(0, 4))  # misaligned device views of the inputs
         dch = torch.from_numpy(np.concatenate([np.zeros(shift, np.uint8), chars])).to(dev)[shift:]
@@ -70,7 +71,7 @@ def run(budget=120.0, seed=1):
         except AssertionError as ex:
             raise AssertionError("MISMATCH %s %r" % (ex, desc))
         n += 1
-    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"expand_mode", b"tokens8_lookup", b"tokens8", b"raw_mode"):
+    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"expand_mode", b"tokens8_lookup", b"tokens8", b"raw_mode", b"bcl_path"):
         capi.check(lib.bsq_tuning_set(name, 0))
     return n
 

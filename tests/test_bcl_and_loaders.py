@@ -72,3 +72,28 @@ def test_dataset_batches_match_per_item_reference_semantics(gpu, bsq, oracle, tm
     # FF2NP: token memmap of the whole store
     mat, path = FF2NP(ff, tok, str(tmp_path / "toks.u8"), batch_size=128)
     assert mat.shape == (500, P) and (np.asarray(mat).view(np.int8) == exp_tok).all()
+
+
+@pytest.mark.parametrize("key,flags", [("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1)), ("SEB8", (1, 0, 1)), ("DNA5", (0, 1, 0))])
+def test_bcl_two_pass_form_equals_single_pass_and_oracle(gpu, bsq, oracle, key, flags):
+    """The two-pass channels-first path (raw (B,P) ids from k_tokens_bp8 + k_expand_bcl; automatic for outputs >= 256 MB,
+    forced here with the knob `bcl_path`) against the single-pass kernel and the transposed oracle: every element type,
+    padlens of 128 and more that are multiples of 16, dirty input (every kind of unmapped byte -> all-zero column)."""
+    import torch
+    from bioseq_amd import capi, synth
+    lib = capi.load()
+    tok, ora = bsq.Tokenizer(key, *flags), oracle.OracleTokenizer(key, *flags)
+    for B, P in ((300, 128), (77, 272), (5, 1024), (1, 144)):
+        chars, offs = synth.synth_packed(B * 3 + P, B, 0, P - 2, synth.DIRTY)
+        dch, dof = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+        for d in "bhifd":
+            exp = np.ascontiguousarray(ora.onehot_packed(chars, offs, P, d).transpose(1, 2, 0))
+            got = {}
+            for path in (1, 2):
+                capi.check(lib.bsq_tuning_set(b"bcl_path", path))
+                try:
+                    got[path] = tok.onehot_packed(dch, dof, P, d, layout="bcl").cpu().numpy()
+                finally:
+                    capi.check(lib.bsq_tuning_set(b"bcl_path", 0))
+            assert got[2].tobytes() == exp.tobytes(), (B, P, d)
+            assert got[1].tobytes() == exp.tobytes(), (B, P, d)
