@@ -5,7 +5,7 @@
 # rebuilds profiles/traffic.json (what bench.py reports as roofline.traffic).
 TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-for w in cfg3 cfg2 cfg5 cfg4f cfg4b cfg5aug cfg3bcl; do
+for w in ${WORKLOADS:-cfg3 cfg2 cfg5 cfg4f cfg4b cfg5aug cfg3bcl}; do
   bash "$REPO/scripts/profile_gpu.sh" ${TAG}_$w --workload $w > "$REPO/gpurun_out/${TAG}_$w.log" 2>&1
   echo "$w: $(grep -c . "$REPO/gpurun_out/${TAG}_$w/summary.txt") summary lines"
 done
