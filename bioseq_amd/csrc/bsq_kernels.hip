@@ -1642,6 +1642,10 @@ bsq_status dispatch_onehot_tile(KParams &k, hipStream_t s) {
     if ((forced == 64 || forced == 128 || forced == 256) &&
         4 * (forced * k.C * int(sizeof(ST)) + 16) + tile_fixed_bytes<256>() <= 64 * 1024)
         tb = forced;
+    // automatic tile order: XCD-aware only for the 256-sequence tiles of tiny rows (cfg4 int8: 258 -> 233 us); the
+    // 64-sequence tiles of wide rows stream 5-9 % faster with the sequence-tile index fastest (sweep_shapes_r02.txt
+    // vs profiles/r01/sweep_shapes5.txt, column p1)
+    if (bsq_internal::tuning("tile_order") == 0 && tb != 256) k.order = 0;
     k.ntb = int32_t((k.B + tb - 1) / tb);
     if (tb == 64) return launch_onehot_tile<ST, 64>(k, s);
     if (tb == 128) return launch_onehot_tile<ST, 128>(k, s);
@@ -1954,6 +1958,10 @@ bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s
 
 template <typename T, int TB>
 bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
+    // automatic tile order: sequence-tile index fastest.  This kernel writes TB * sizeof(T) = 256..512-byte row segments;
+    // with the XCD-aware order their neighbours in a row are written far apart in time and the (P,B) int32 / f32 matrix of
+    // the cfg2 batch takes 62 us instead of 48 (profiles/r02/tokens_dtypes.txt); its character re-reads are small beside that.
+    if (bsq_internal::tuning("tile_order") == 0) k.order = 0;
     k.ntb = int32_t((k.B + TB - 1) / TB);
     const int64_t ntt = (k.P + kTT - 1) / kTT;
     const size_t smem = tile_fixed_bytes<TB>();
