@@ -212,6 +212,7 @@ bsq_status bsq_decode_sizes_device(const bsq_desc *d, const void *tokens, int32_
     *first_bad = -1;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     if ((nrows + 3) / 4 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "too many rows");
+    std::lock_guard<std::mutex> turn(bsq_internal::workspace_mutex());  // the flag lives in the stream's shared scratch
     void *ws = nullptr;
     st = bsq_internal::workspace_acquire(sizeof(unsigned long long), s, &ws);
     if (st != BSQ_OK) return st;

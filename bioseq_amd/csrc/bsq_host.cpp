@@ -439,6 +439,11 @@ void workspace_release(void *ptr, hipStream_t stream) {
     (void)hipFreeAsync(ptr, stream);
 }
 
+std::mutex &workspace_mutex() {
+    static std::mutex m;
+    return m;
+}
+
 void workspace_drop_cache() {
     std::lock_guard<std::mutex> lock(g_ws_mu);
     int prev = 0;

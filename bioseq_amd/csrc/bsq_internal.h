@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <mutex>
+
 #include "bsq.h"
 
 namespace bsq_internal {
@@ -49,6 +51,9 @@ inline bool nontemporal_stores() { return tuning("nt_stores") != 0; }
 bsq_status workspace_acquire(size_t nbytes, hipStream_t stream, void **ptr);
 void workspace_release(void *ptr, hipStream_t stream);
 void workspace_drop_cache();  // bsq_release_staging()
+// Held by a caller from workspace_acquire() until its last launch that uses the scratch is enqueued: calls on one
+// stream share the cached buffer, so their launches must not interleave.
+std::mutex &workspace_mutex();
 
 // bsq_tokens8.hip: the (B,P) int8 token matrix (register-table lookups, LDS rule tables).
 bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out);

@@ -2108,6 +2108,9 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     // multiple of 32 KiB (each XCD then keeps to its own chunk columns) and B is moderate, or B is small.
     if (path == 3) return onehot_chunk_owner(k, sz, s);
     if (path == 2) {
+        // The scratch is shared by the calls of one stream (workspace cache): the two launches of a call must be enqueued
+        // back to back, so concurrent host threads take turns here (enqueueing takes microseconds; the GPU work overlaps).
+        std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());
         void *ws = nullptr;
         bsq_status wst = bsq_internal::workspace_acquire(two_pass_workspace_bytes(B, P), s, &ws);
         if (wst != BSQ_OK) return wst;
@@ -2232,6 +2235,7 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
     if (!mask_or_null && bcl_path != 1 && (bcl_path == 2 || total_bytes >= (int64_t(256) << 20)) && k.C <= 250 &&
         reinterpret_cast<uintptr_t>(out) % 16 == 0 && P % 16 == 0 && B * int64_t(k.C) * P < (int64_t(1) << 51) &&
         bsq_internal::tokens_bp8_applicable(d, B, P, out)) {
+        std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());  // see bsq_onehot_device
         void *ws = nullptr;
         bsq_status wst = bsq_internal::workspace_acquire(size_t(B) * size_t(P), s, &ws);
         if (wst != BSQ_OK) return wst;
