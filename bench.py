@@ -41,6 +41,7 @@ WORKLOADS = {
     #        synth config, op, destchar, batch_first
     "cfg3": ("cfg3", "onehot", "f", False),
     "cfg3bcl": ("cfg3", "onehot_bcl", "f", False),  # channels-first (B,C,P) written directly (loader layout)
+    "cfg1oh": ("cfg1", "onehot", "f", False),     # BASELINE configs[0]'s batch as a one-hot: tiny, for smoke runs of the N > 1 path
     "cfg2": ("cfg2", "tokenize", "B", True),
     "cfg2sf": ("cfg2", "tokenize", "B", False),   # the reference's DEFAULT layout of batch_tokenize: (padlen, batch)
     "cfg4f": ("cfg4", "onehot", "f", False),
