@@ -2058,13 +2058,18 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P) {
         //                 0.757 vs 0.733) when a row is >= 48 B and its
         //                 per-position gather set stays L2-resident, i.e. the pitch is a multiple of 32 KiB (each
         //                 XCD keeps to its own chunk columns) and B <= 128k, or B <= 16k whatever the pitch;
-        //  1 tiled      : the rest (tiny rows such as int8 DNA, small outputs).
+        //                 Small batches (profiles/r02/path_small.txt): the tile kernel has a ~15 us floor, the
+        //                 chunk-owner none -- 1000 x 256 DNA f32 6 vs 19 us, 1024 x 512 DNA int8 9 vs 16 us,
+        //                 4096 x 512 DNA f32 17 vs 20 us -- so it also takes every output <= 8 MB and rows >= 24 B
+        //                 up to 128 MB;
+        //  1 tiled      : the rest (tiny rows such as int8 DNA once the batch is not small).
         const int64_t rowbytes = C * int64_t(sz), pitch = B * rowbytes, total = pitch * P;
         const bool pinned_columns = pitch % (8 * kChunk) == 0;
-        const bool owner_ok = rowbytes >= 48 && ((pinned_columns && B <= 131072) || B <= 16384);
-        if (owner_ok && total < (int64_t(4) << 30))
+        const bool owner_big = rowbytes >= 48 && ((pinned_columns && B <= 131072) || B <= 16384);
+        const bool owner_small = total <= (int64_t(8) << 20) || (rowbytes >= 24 && total <= (int64_t(128) << 20));
+        if ((owner_big || owner_small) && total < (int64_t(4) << 30))
             path = 3;
-        else if (rowbytes >= 16 && total >= (int64_t(256) << 20))
+        else if (rowbytes >= 16 && total >= (int64_t(192) << 20))
             path = 2;
         else
             path = 1;
