@@ -27,7 +27,9 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   bcl_path      channels-first one-hot: 0 automatic (two-pass k_tokens_bp8<raw> + k_expand_bcl for unmasked outputs >= 256 MB),
 //                 1 never two-pass, 2 two-pass whenever it applies;  bcl_pad  occupancy cap of k_expand_bcl (0: 3 workgroups per CU)
 //   raw_mode      2 / 3: k_tokens_raw2 (4 x 4 byte transpose in registers via v_permlane32/16_swap; LDS / register
-//                 alphabet table) instead of k_tokens_raw; measured 7-15 % slower (profiles/r02/raw_lab.txt)
+//                 alphabet table) instead of k_tokens_raw; measured 7-15 % slower (profiles/r02/raw_lab.txt);
+//                 1 / 4: force the 256 x 64 / the wide 1024 x 16 tile of k_tokens_raw (0: wide for the final (P,B)
+//                 int8 matrix of >= 4096 sequences, 256 x 64 for the expansion scratch)
 //   xcd_claim     1: k_expand_chunks takes its chunk class from HW_REG_XCC_ID and its slot from per-class atomic counters
 //                 (placement-independent; measured 17-32 % slower: profiles/r02/claim_lab.txt)
 //   augment_mode  1: one lane per sequence (round-1 k_augment) instead of the attempt-parallel k_augment_groups
@@ -41,6 +43,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   expand_mode   0 / 1: k_expand_chunks, 2: k_expand_small (dword token loads; an experiment that lost), 9: the same
 //                 without token loads (ablation)
 //   fill_mode, fill_pad   access pattern / occupancy of bsq_fill_device (write-bandwidth yardsticks)
+//   pattern_wait          bsq_fill_pattern_device: n > 0 = s_waitcnt vmcnt(n - 1) after every row of a wave
 //   host_copy_threads     worker threads of the pipelined device -> host result copy (0: 8)
 int tuning(const char *name);
 bool set_tuning(const char *name, int value);

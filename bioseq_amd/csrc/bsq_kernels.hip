@@ -71,6 +71,7 @@ struct KParams {
     int32_t fill_id;  // token of positions >= L+bos+eos: pad id, or kNone without padchar
     int32_t ntb;      // number of sequence tiles
     int32_t aligned;  // 1: every output row segment is 16-byte aligned -> vector stores
+    int32_t vw;       // k_tokens_raw: bytes per store that the alignment of its output rows allows (16, 8, 4 or 1)
     int32_t ntt;      // number of position tiles
     int32_t order;    // 0: sequence-tile index fastest over blockIdx, 1: position-tile index fastest, 2: XCD-aware
     int32_t group;    // order 2: sequence tiles per XCD and group (see tile_of_block)
@@ -763,23 +764,41 @@ __global__ __launch_bounds__(kThreads) void k_expand_small(const EParams p) {
 // flight per thread -- the kernel is bound by its ~17 VALU instructions per token, not by memory.)
 constexpr int kRawTB = 256;
 constexpr int kRawStride = kRawTB + 4;  // 65 dwords: odd stride
+// EXPERIMENT (knob "raw_mode" 4, lost): a WIDE tile of 1024 sequences x 16 positions, so that a position row of the tile
+// is 1 KiB of the output (one full-wave 16-byte store) instead of 256 bytes.  Stores alone on the cfg2 geometry (1024
+// rows x 64 KiB; profiles/r02/pattern_cfg2sf.txt) take 17.6 us in 256-byte segments and 11-12 us in 1-KiB segments,
+// but the kernel got SLOWER (cfg2 24.3 -> 35.0 us, cfg5 42 -> 59, cfg4 57 -> 71; profiles/r02/seqfirst_lab1.txt):
+// every sequence then contributes 16 characters per tile, so a 128-byte character line is fetched by eight tiles and
+// the two dwords behind a lane's four characters are rarely shared -- the character side, not the store pattern, is
+// what the tile pays for.  (A 512 x 32 tile measured within +-4 % of 256 x 64: profiles/r02/seqfirst_lab3.txt.)
+constexpr int kWideTB = 1024, kWideTT = 16;
+// LDS row stride of a TB-sequence tile: the byte-writes of one instruction (TT/4 position groups x 64/(TT/4) sequences
+// 4 apart) must spread over the 32 banks twice -- 65 dwords for 16 x 4, 260 dwords (= 4 mod 32, 16-byte rows) for 4 x 16.
+template <int TB>
+__host__ __device__ constexpr int raw_stride() {
+    return TB == 256 ? kRawStride : TB + 16;
+}
 
 // RAW = false: the same kernel produces the final int8 (P,B) token matrix of batch_tokenize(batch_first=False)
 // (unmapped / unpadded positions are 0 instead of kNone).
-template <bool MASK, bool RAW = true>
+template <bool MASK, bool RAW = true, int TB = kRawTB, int TT = kTT>
 __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
+    constexpr int STRIDE = raw_stride<TB>();
+    constexpr int LPS = TT / 4;          // lanes per sequence (4 characters each)
+    constexpr int SPP = kThreads / LPS;  // sequences per step of the workgroup
+    static_assert(TB * TT == kRawTB * kTT && TB % SPP == 0 && SPP % 16 == 0, "tile shape");
     __shared__ __align__(16) uint8_t s_lut[256];
-    __shared__ __align__(16) SeqSpan s_span[kRawTB];
-    __shared__ __align__(16) uint8_t s_t[kTT * kRawStride];
+    __shared__ __align__(16) SeqSpan s_span[TB];
+    __shared__ __align__(16) uint8_t s_t[TT * STRIDE];
     const int tid = threadIdx.x;
     int32_t tb, tt;
     tile_of_block(p, tb, tt);
     if (tb >= p.ntb) return;
-    const int64_t b0 = static_cast<int64_t>(tb) * kRawTB;
-    const int32_t t0 = tt * kTT;
+    const int64_t b0 = static_cast<int64_t>(tb) * TB;
+    const int32_t t0 = tt * TT;
     stage_lut(p, s_lut);
-    TokenRule rule = make_rule(p, b0, kRawTB);
-    stage_spans(p, rule, b0, kRawTB, s_span);
+    TokenRule rule = make_rule(p, b0, TB);
+    stage_spans(p, rule, b0, TB, s_span);
     __syncthreads();
     if (!RAW) {  // value space: "no token" is the memset 0 of tokenize.h:427
         if (tid < 64) {  // s_lut was staged with kNone markers: rewrite them (one dword per lane)
@@ -792,54 +811,87 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
         if (rule.fill_id == kNone) rule.fill_id = 0;
         if (rule.at_len_id == kNone) rule.at_len_id = 0;
     }
-    const int g = tid & 15;
+    const int g = tid % LPS;
     const int32_t tpos = t0 + 4 * g;
-    constexpr int NI = kRawTB / 16, BATCH = 8;
-    // Sequence of (thread group tg = tid/16, step k): 4*(tg&3) + (tg>>2) + 16k.
-    const int sb0 = 4 * ((tid >> 4) & 3) + (tid >> 6);
+    constexpr int NI = TB / SPP, BATCH = 8;
+    // Sequence of (thread group tg = tid / LPS, step k): 4 * (tg % (SPP/4)) + tg / (SPP/4) + SPP * k -- the sequences
+    // of one wave are 4 apart.
+    const int tg = tid / LPS;
+    const int sb0 = 4 * (tg % (SPP / 4)) + tg / (SPP / 4);
 #pragma unroll 1
     for (int i0 = 0; i0 < NI; i0 += BATCH) {
         Raw4 raw[BATCH];
         int32_t len[BATCH];
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
-            const int sb = sb0 + 16 * (i0 + k);
+            const int sb = sb0 + SPP * (i0 + k);
             const SeqSpan sp = s_span[sb];
             len[k] = sp.len;
             raw[k] = fetch4<MASK>(rule, sp.start, tpos);
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
-            const int sb = sb0 + 16 * (i0 + k);
+            const int sb = sb0 + SPP * (i0 + k);
             const uint32_t w = finish4<MASK>(rule, s_lut, raw[k], len[k], tpos);  // columns >= B are never read
-            uint8_t *col = s_t + (4 * g) * kRawStride + sb;
+            uint8_t *col = s_t + (4 * g) * STRIDE + sb;
             col[0] = static_cast<uint8_t>(w);
-            col[kRawStride] = static_cast<uint8_t>(w >> 8);
-            col[2 * kRawStride] = static_cast<uint8_t>(w >> 16);
-            col[3 * kRawStride] = static_cast<uint8_t>(w >> 24);
+            col[STRIDE] = static_cast<uint8_t>(w >> 8);
+            col[2 * STRIDE] = static_cast<uint8_t>(w >> 16);
+            col[3 * STRIDE] = static_cast<uint8_t>(w >> 24);
         }
     }
     __syncthreads();
     uint8_t *out = static_cast<uint8_t *>(p.out);
-    for (int f = tid; f < kTT * (kRawTB / 16); f += kThreads) {
-        const int32_t tl = f >> 4, q = f & 15;
-        const int64_t t = static_cast<int64_t>(t0) + tl;
-        if (t >= p.P) continue;
-        const uint8_t *src = s_t + tl * kRawStride + q * 16;
-        uint8_t *dst = out + t * p.out_pitch + b0 + q * 16;
-        if (p.aligned && b0 + q * 16 + 16 <= p.out_pitch) {
-            uint4 v;  // LDS rows are only 4-byte aligned (stride 260): four dword reads
-            v.x = *reinterpret_cast<const uint32_t *>(src);
-            v.y = *reinterpret_cast<const uint32_t *>(src + 4);
-            v.z = *reinterpret_cast<const uint32_t *>(src + 8);
-            v.w = *reinterpret_cast<const uint32_t *>(src + 12);
-            if constexpr (RAW)
-                *reinterpret_cast<uint4 *>(dst) = v;  // scratch: re-read by the expansion pass right away
-            else
-                store16<true>(dst, v);               // final token matrix: streamed once
-        } else {
-            for (int i = 0; i < 16; ++i)
-                if (b0 + q * 16 + i < p.B) dst[i] = src[i];
+    if (p.vw == 16) {
+        for (int f = tid; f < TT * (TB / 16); f += kThreads) {
+            const int32_t tl = f / (TB / 16), q = f % (TB / 16);
+            const int64_t t = static_cast<int64_t>(t0) + tl;
+            if (t >= p.P) continue;
+            const uint8_t *src = s_t + tl * STRIDE + q * 16;
+            uint8_t *dst = out + t * p.out_pitch + b0 + q * 16;
+            if (b0 + q * 16 + 16 <= p.out_pitch) {
+                uint4 v;
+                if constexpr (STRIDE % 16 == 0) {
+                    v = *reinterpret_cast<const uint4 *>(src);
+                } else {  // LDS rows are only 4-byte aligned (stride 260): four dword reads
+                    v.x = *reinterpret_cast<const uint32_t *>(src);
+                    v.y = *reinterpret_cast<const uint32_t *>(src + 4);
+                    v.z = *reinterpret_cast<const uint32_t *>(src + 8);
+                    v.w = *reinterpret_cast<const uint32_t *>(src + 12);
+                }
+                if constexpr (RAW)
+                    *reinterpret_cast<uint4 *>(dst) = v;  // scratch: re-read by the expansion pass right away
+                else
+                    store16<true>(dst, v);               // final token matrix: streamed once
+            } else {
+                for (int i = 0; i < 16; ++i)
+                    if (b0 + q * 16 + i < p.B) dst[i] = src[i];
+            }
+        }
+    } else if (p.vw >= 4) {  // rows (batch size) only 8- or 4-byte aligned: 8- / 4-byte stores, still one row per wave step
+        const int lg = p.vw == 8 ? 3 : 2, ppr = TB >> lg;  // pieces per tile row
+        for (int f = tid; f < TT * ppr; f += kThreads) {
+            const int32_t tl = f / ppr, q = f % ppr;
+            const int64_t t = static_cast<int64_t>(t0) + tl;
+            if (t >= p.P) continue;
+            const uint8_t *src = s_t + tl * STRIDE + (q << lg);
+            uint8_t *dst = out + t * p.out_pitch + b0 + (q << lg);
+            if (b0 + (q << lg) + p.vw <= p.B) {
+                const uint32_t lo = *reinterpret_cast<const uint32_t *>(src);
+                if (lg == 3)
+                    *reinterpret_cast<uint2 *>(dst) = uint2{lo, *reinterpret_cast<const uint32_t *>(src + 4)};
+                else
+                    *reinterpret_cast<uint32_t *>(dst) = lo;
+            } else {
+                for (int i = 0; i < p.vw; ++i)
+                    if (b0 + (q << lg) + i < p.B) dst[i] = src[i];
+            }
+        }
+    } else {  // any batch size: byte stores, consecutive lanes on consecutive bytes
+        for (int f = tid; f < TT * TB; f += kThreads) {
+            const int32_t tl = f / TB, c = f % TB;
+            const int64_t t = static_cast<int64_t>(t0) + tl;
+            if (t < p.P && b0 + c < p.B) out[t * p.out_pitch + b0 + c] = s_t[tl * STRIDE + c];
         }
     }
 }
@@ -1461,7 +1513,7 @@ __global__ __launch_bounds__(kThreads) void k_fill_blocks(uint4 *dst, size_t n16
 template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_fill_pattern(uint8_t *dst, int64_t rows, int64_t pitch, int32_t seg,
                                                            int32_t rpw, int32_t ncb, int32_t nrb, int32_t order,
-                                                           int32_t interleave) {
+                                                           int32_t interleave, int32_t wait) {
     int32_t cb, rb;
     if (order >= 2) {  // permutations of the block -> column-chunk map (ncb must be a multiple of 64)
         const uint32_t b = blockIdx.x % ncb;
@@ -1496,6 +1548,11 @@ __global__ __launch_bounds__(kThreads) void k_fill_pattern(uint8_t *dst, int64_t
         if (row >= rows) break;
         uint8_t *g = dst + row * pitch + static_cast<int64_t>(cb) * seg;
         for (int32_t o = lane * 16; o < seg; o += 1024) store16<NT>(g + o, v);
+        // knob "pattern_wait" n > 0: at most n - 1 (0 / 1 / 2 / 4) stores of the wave in flight before its next row
+        if (wait == 1) __builtin_amdgcn_s_waitcnt(0x0F70);
+        else if (wait == 2) __builtin_amdgcn_s_waitcnt(0x0F71);
+        else if (wait == 3) __builtin_amdgcn_s_waitcnt(0x0F72);
+        else if (wait == 5) __builtin_amdgcn_s_waitcnt(0x0F74);
     }
 }
 
@@ -1573,6 +1630,7 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     k.group = group_knob > 0 && group_knob <= 4096 ? group_knob : 1;
     if (k.order == 2 && (B / 64 + 8 * int64_t(k.group)) * int64_t(k.ntt) >= (int64_t(1) << 31)) k.order = 0;  // keep the rounded-up grid in 32 bits
     k.aligned = 0;
+    k.vw = 1;
     k.out_pitch = B;
     k.one_bits = 1;
     {   // folded tables (see k_tokens_raw2): exact iff only letter positions are mapped and both cases map alike
@@ -1900,6 +1958,7 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
     k.out = tokens;
     k.out_pitch = pitch;
     k.aligned = reinterpret_cast<uintptr_t>(tokens) % 16 == 0 && pitch % 16 == 0;  // every row starts 16-byte aligned
+    k.vw = k.aligned ? 16 : 1;
     k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
     const dim3 grid(unsigned(tile_grid(k, k.ntt)));
     // knob "raw_mode": 0 / 1 k_tokens_raw; 2 k_tokens_raw2 (register transpose) with the LDS byte table, 3 with the
@@ -1907,7 +1966,15 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
     // 24.0 us -> 25.8 (2) / 27.4 (3); cfg3 / cfg4 f32 steps +0.1 / +0.3 %): the tile is bound by vector instructions at
     // least as much as by LDS traffic, and the transpose trades 3 LDS writes for 6 vector instructions per word.
     const int rm = bsq_internal::tuning("raw_mode");
-    if (k.mask || rm < 2)
+    if (!k.mask && rm == 4 && k.P <= (int64_t(1) << 20)) {  // measurement: the wide tile of the (P,B) int8 token matrix
+        k.ntb = int32_t((k.B + kWideTB - 1) / kWideTB);
+        k.ntt = int32_t((k.P + kWideTT - 1) / kWideTT);
+        if ((int64_t(k.ntb) + 8 * int64_t(k.group)) * int64_t(k.ntt) >= (int64_t(1) << 31)) k.order = 0;
+        hipLaunchKernelGGL((k_tokens_raw<false, true, kWideTB, kWideTT>), dim3(unsigned(tile_grid(k, k.ntt))),
+                           dim3(kThreads), 0, s, k);
+        return check_launch("k_tokens_raw<wide>");
+    }
+    if (k.mask || rm < 2 || rm == 4)
         if (k.mask) hipLaunchKernelGGL(k_tokens_raw<true>, grid, dim3(kThreads), 0, s, k);
         else hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
     else if (rm == 3 && k.foldable)
@@ -2198,10 +2265,22 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     }
     k.aligned = (addr % 16 == 0) && ((B * int64_t(sz)) % 16 == 0);
     if (t == BSQ_I8 && bsq_internal::tuning("tokenize_path") != 1) {  // int8 (P,B): the raw-token kernel in value mode
-        k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
+        const uint64_t al = uint64_t(addr) | uint64_t(B);  // every row starts at out + t * B
+        k.vw = al % 16 == 0 ? 16 : (al % 8 == 0 ? 8 : (al % 4 == 0 ? 4 : 1));
         const int rm = bsq_internal::tuning("raw_mode");
+        // knob "raw_mode": 0 automatic, 1 the 256 x 64 tile, 4 the wide 1024 x 16 tile, 2 / 3 the round-2 experiments
+        const bool wide_ok = P <= (int64_t(1) << 20);  // 1024 sequences x padlen in 32-bit window offsets
+        if (wide_ok && rm == 4) {  // measurement only: 35 vs 24 us on cfg2 (profiles/r02/seqfirst_lab1.txt)
+            k.ntb = int32_t((k.B + kWideTB - 1) / kWideTB);
+            k.ntt = int32_t((P + kWideTT - 1) / kWideTT);
+            if ((int64_t(k.ntb) + 8 * int64_t(k.group)) * int64_t(k.ntt) >= (int64_t(1) << 31)) k.order = 0;
+            hipLaunchKernelGGL((k_tokens_raw<false, false, kWideTB, kWideTT>), dim3(unsigned(tile_grid(k, k.ntt))),
+                               dim3(kThreads), 0, s, k);
+            return check_launch("k_tokens_raw<value, wide>");
+        }
+        k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
         const dim3 vgrid(unsigned(tile_grid(k, k.ntt)));
-        if (rm < 2)
+        if (rm < 2 || rm >= 4)
             hipLaunchKernelGGL((k_tokens_raw<false, false>), vgrid, dim3(kThreads), 0, s, k);
         else if (rm == 3 && k.foldable)
             hipLaunchKernelGGL((k_tokens_raw2<false, true>), vgrid, dim3(kThreads), 0, s, k);
@@ -2365,12 +2444,14 @@ bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32
     }
     const dim3 grid(unsigned(int64_t(ncb) * nrb));
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const size_t pad = size_t(bsq_internal::tuning("fill_pad"));  // unused dynamic LDS: caps the workgroups per CU
+    const int32_t wait = bsq_internal::tuning("pattern_wait");
     if (nt)
-        hipLaunchKernelGGL((k_fill_pattern<true>), grid, dim3(kThreads), 0, s, static_cast<uint8_t *>(dst), rows, pitch,
-                           seg, rows_per_wave, ncb, nrb, order, interleave);
+        hipLaunchKernelGGL((k_fill_pattern<true>), grid, dim3(kThreads), pad, s, static_cast<uint8_t *>(dst), rows, pitch,
+                           seg, rows_per_wave, ncb, nrb, order, interleave, wait);
     else
-        hipLaunchKernelGGL((k_fill_pattern<false>), grid, dim3(kThreads), 0, s, static_cast<uint8_t *>(dst), rows, pitch,
-                           seg, rows_per_wave, ncb, nrb, order, interleave);
+        hipLaunchKernelGGL((k_fill_pattern<false>), grid, dim3(kThreads), pad, s, static_cast<uint8_t *>(dst), rows, pitch,
+                           seg, rows_per_wave, ncb, nrb, order, interleave, wait);
     return check_launch("k_fill_pattern");
 }
 

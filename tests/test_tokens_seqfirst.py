@@ -1,0 +1,95 @@
+"""The (P,B) int8 token matrix -- batch_tokenize's DEFAULT layout (batch_first=False, destchar 'B';
+/root/reference/src/tokenize.cpp:82-98, tokenize.h:454-479) -- from k_tokens_raw in value mode, for both of its
+tile shapes (256 sequences x 64 positions, and the wide 1024 x 16 tile) and as the expansion scratch of the
+two-pass one-hot.  Bit-exact against the oracle."""
+import ctypes
+import itertools
+
+import numpy as np
+import pytest
+
+from bioseq_amd import synth
+from test_tokens8 import nasty_batch
+
+pytestmark = pytest.mark.gpu
+
+COMBOS = list(itertools.product([0, 1], repeat=3))  # (eos, bos, padchar)
+
+
+@pytest.fixture(params=[0, 1, 4], ids=["auto", "tile256x64", "tile1024x16"])
+def raw_mode(request):
+    from bioseq_amd import capi
+    lib = capi.load()
+    capi.check(lib.bsq_tuning_set(b"raw_mode", request.param))
+    yield request.param
+    capi.check(lib.bsq_tuning_set(b"raw_mode", 0))
+
+
+def dev_tokens_pb(lib, capi, desc, chars, offs, P, gpu, shift=0, out_shift=0):
+    import torch
+    B = len(offs) - 1
+    dch = torch.from_numpy(np.concatenate([np.zeros(shift, np.uint8), chars, np.full(1, 0x41, np.uint8)])).to(gpu)[shift:shift + len(chars)]
+    dof = torch.from_numpy(offs).to(gpu)
+    buf = torch.full((P * B + 32,), 99, dtype=torch.int8, device=gpu)
+    out = buf[out_shift:out_shift + P * B].view(P, B)  # rows at 16- / 8- / 4- / 1-byte alignment
+    capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 0, capi.I8,
+                                       out.data_ptr(), None))
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    assert (host[:out_shift] == 99).all() and (host[out_shift + P * B:] == 99).all(), "wrote outside the matrix"
+    return host[out_shift:out_shift + P * B].reshape(P, B)
+
+
+@pytest.mark.parametrize("B,lo,hi,P", [(1, 0, 0, 1), (1, 5, 5, 7), (3, 0, 9, 16), (1000, 1, 254, 256), (1004, 0, 62, 64), (1024, 0, 30, 33),
+                                       (1025, 0, 14, 17), (4096, 0, 100, 100), (5000, 3, 60, 64), (9000, 0, 15, 15),
+                                       (2047, 100, 300, 302), (70000, 0, 20, 24)])
+def test_shapes_vs_oracle(gpu, oracle, raw_mode, B, lo, hi, P):
+    """Single sequences, ragged tails of the sequence tile (B not a multiple of 16 / 256 / 1024), padlen that is not a
+    multiple of the tile's 16 / 64 positions, empty sequences, every byte value; output rows at every alignment the
+    kernel distinguishes (16-, 8-, 4-byte and byte stores)."""
+    from bioseq_amd import capi
+    lib = capi.load()
+    hi = max(0, min(hi, P - 2))
+    c2, o2 = nasty_batch(900 + B + P, B, min(lo, hi), hi)
+    for key, (eos, bos, pad) in (("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1)), ("SEB8", (1, 0, 1)), ("DNA5", (0, 1, 0))):
+        if hi + eos + bos > P:
+            continue
+        ora = oracle.OracleTokenizer(key, eos, bos, pad)
+        want = ora.tokenize_packed(c2, o2, P, "b", False)
+        for shift, out_shift in ((0, 0), (3, 8), (1, 4), (2, 1)):
+            got = dev_tokens_pb(lib, capi, capi.make_desc(key, eos, bos, pad), c2, o2, P, gpu, shift, out_shift)
+            assert got.shape == want.shape and got.tobytes() == want.tobytes(), (key, eos, bos, pad, B, P, shift, out_shift)
+
+
+def test_cfg2_seq_first_digest(gpu, raw_mode):
+    """BASELINE cfg2 seq-first at full size against the reference's digest."""
+    import hashlib
+    from bioseq_amd import capi
+    lib = capi.load()
+    chars, offs = synth.synth_packed(202, 65536, 50, 1024, synth.AA)
+    got = dev_tokens_pb(lib, capi, capi.make_desc("AMINO20", 0, 0, 0), chars, offs, 1024, gpu)
+    assert int(got.sum(dtype=np.int64)) == 333614835
+    assert hashlib.sha256(got.tobytes()).hexdigest() == "9d6b9328e8e6605dff897d6ebec8a1f77b81f69ed666bd9b5a59e5f750cd1b73"
+
+
+def test_two_pass_onehot_with_either_scratch_tile(gpu, oracle, raw_mode):
+    """The expansion scratch written by the wide tile expands to the same one-hot."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    capi.check(lib.bsq_tuning_set(b"onehot_path", 2))
+    try:
+        B, P = 3000, 70
+        chars, offs = nasty_batch(77, B, 0, P - 2)
+        for key, (eos, bos, pad) in (("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1))):
+            desc = capi.make_desc(key, eos, bos, pad)
+            C = lib.bsq_alphabet_size(ctypes.byref(desc))
+            dch, dof = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+            out = torch.full((P, B, C), 9, dtype=torch.float32, device=gpu)
+            capi.check(lib.bsq_onehot_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), None, B, P, capi.F32,
+                                             out.data_ptr(), None))
+            torch.cuda.synchronize()
+            want = oracle.OracleTokenizer(key, eos, bos, pad).onehot_packed(chars, offs, P, "f")
+            assert out.cpu().numpy().tobytes() == want.tobytes(), key
+    finally:
+        capi.check(lib.bsq_tuning_set(b"onehot_path", 0))
