@@ -35,7 +35,8 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   augment_mode  1: one lane per sequence (round-1 k_augment) instead of the attempt-parallel k_augment_groups
 //   chunk_math    2: scalar 64-bit integer reciprocals (div64) for the chunk coordinates of the expansion kernels
 //                 instead of the double reciprocals (div_by); measured 1 % slower at the optimum occupancy
-//   tokens8       1: never use k_tokens_bp8 for the (B,P) int8 token matrix (falls back to k_tokenize_chunks)
+//   tokens8       1: never use k_tokens_bp8 for the (B,P) int8 token matrix (falls back to k_tokenize_chunks / _rows);
+//                 2: only for padlen % 16 == 0 and 16-byte aligned outputs (no row-piece form)
 //   tokens8_lookup  0 automatic, 1 LDS byte table, 2 register table (v_perm_b32)
 //   tokens8_pad   unused dynamic LDS of k_tokens_bp8;  tokens8_abl  ablation experiments (diagnostic)
 //   onehot_tb     0: automatic, else force 64 / 128 / 256 sequences per tile of k_onehot_tile

@@ -2234,10 +2234,13 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         return bsq_tokenize_device_generic(d, chars, offsets, B, P, batch_first, t, out, hip_stream);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const uintptr_t addr = reinterpret_cast<uintptr_t>(out);
+    // int8 (B,P): k_tokens_bp8 takes any padlen >= 128 and any alignment (its row-piece form when P % 16 != 0)
+    if (batch_first && t == BSQ_I8 && bsq_internal::tuning("tokenize_path") != 1 && bsq_internal::tuning("tokens8") != 1 &&
+        bsq_internal::tokens_bp8_applicable(d, B, P, out) &&
+        ((addr % 16 == 0 && P % 16 == 0) || bsq_internal::tuning("tokens8") != 2))  // knob 2: aligned shapes only (round-2 state)
+        return bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, out, s);
     if (batch_first && bsq_internal::tuning("tokenize_path") != 1 && addr % 16 == 0 &&
         P % int64_t(16 / sz) == 0) {  // chunk kernel: every lane's 16 output bytes lie inside one row
-        if (t == BSQ_I8 && bsq_internal::tuning("tokens8") != 1 && bsq_internal::tokens_bp8_applicable(d, B, P, out))
-            return bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, out, s);
         switch (t) {
         case BSQ_I8: return launch_tokenize_chunks<int8_t, false>(k, s);
         case BSQ_I16: return launch_tokenize_chunks<int16_t, false>(k, s);

@@ -38,8 +38,9 @@ struct T8Params {
     int64_t total;     // output bytes = B * P
     int64_t nchunks;
     int64_t B;
-    double inv_P;      // div_by() constant (outputs of 2^31 bytes and more)
-    uint32_t P, magic, shift, pow2;  // fast_div() constants of P
+    double inv_ppr;    // div_by() constant of ppr (outputs of 2^31 pieces and more)
+    uint32_t P, ppr;   // padlen; 16-byte PIECES per row = ceil(P / 16) (the last one is partial when P % 16 != 0)
+    uint32_t magic, shift, pow2;  // fast_div() constants of ppr
     int32_t bos, room;
     uint32_t bos_id, at_len_v, fill_v;  // token VALUES at position 0, bos + L and beyond (0 where the reference leaves the memset)
     int32_t abl;       // ablation experiments (diagnostic builds of the kernel only)
@@ -73,8 +74,8 @@ __device__ __forceinline__ uint32_t nonletter_mask(uint32_t cw) {
 // synthetic addresses that do not depend on the offsets.
 struct OffStage {   // stage A of one chunk: where it lies, the offsets of its rows in flight
     bool valid;     // wave-uniform
-    int64_t lo, bc; // byte offset of the chunk in the output, its first row
-    uint32_t tc;    // position inside row bc of the chunk's first element
+    int64_t lo, bc; // byte offset of the chunk in the output (RG: unused), its first row
+    uint32_t tc;    // PIECE index inside row bc of the chunk's first piece
     int64_t o0, o1; // lane i: offsets[bc + i], offsets[bc + i + 1]
 };
 struct CharStage {  // stage B: the lane's four 16-byte character vectors in flight + what stage C needs
@@ -83,10 +84,19 @@ struct CharStage {  // stage B: the lane's four 16-byte character vectors in fli
     uint32_t tc;
     u32x4u cw[4];
     int32_t j0[4], L[4];
+    uint32_t q[4];  // RG: row of the lane's piece relative to bc
     bool live[4], slow[4];
 };
 
-template <bool NT, int LK, int ABL>
+// RG ("ragged"): any padlen >= 128 and any output alignment.  The unit is still 256 consecutive 16-byte pieces per
+// wave, but pieces are counted per ROW (ceil(P / 16) of them, the last one partial), so that a lane's bytes always lie
+// inside one row: piece m of row b goes to out + b * P + 16 m with an unaligned 16-byte store, the partial piece with
+// 8 / 4 / 2 / 1-byte stores.  With P % 16 == 0 and a 16-byte aligned output this is the same mapping as RG = false.
+typedef uint64_t u64u __attribute__((aligned(1)));
+typedef uint32_t u32u __attribute__((aligned(1)));
+typedef uint16_t u16u __attribute__((aligned(1)));
+
+template <bool NT, int LK, int ABL, bool RG = false>
 __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
     __shared__ __align__(16) uint4 s_rule[4][2][18];
     __shared__ __align__(16) uint8_t s_lut4[LK == 0 ? 4 : 1][256];
@@ -141,8 +151,8 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    const bool small = p.total < (int64_t(1) << 31);
-    const uint32_t P = p.P;
+    const bool small = p.nchunks < (int64_t(1) << 23);  // piece indices below 2^31
+    const uint32_t P = p.P, PPR = p.ppr;
     auto div_p = [&](uint32_t n) { return fast_div(n, p.magic, p.shift, p.pow2); };
     constexpr bool kLoadOffsets = ABL != 3 && ABL != 5;
     constexpr bool kLoadChars = ABL < 2 || ABL >= 5;
@@ -157,16 +167,17 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
         a.tc = 0;
         if (!a.valid) return a;
         a.lo = k * kChunk;
+        const int64_t g0 = k * (kChunk / 16);  // first piece of the chunk
         if (small) {
-            const uint32_t q = div_p(static_cast<uint32_t>(a.lo));
+            const uint32_t q = div_p(static_cast<uint32_t>(g0));
             a.bc = q;
-            a.tc = static_cast<uint32_t>(a.lo) - q * P;
+            a.tc = static_cast<uint32_t>(g0) - q * PPR;
         } else {
             int64_t rem;
-            a.bc = div_by(a.lo, P, p.inv_P, &rem);
+            a.bc = div_by(g0, PPR, p.inv_ppr, &rem);
             a.tc = static_cast<uint32_t>(rem);
         }
-        const uint32_t nr = div_p(a.tc + (kChunk - 1));  // rows bc .. bc + nr intersect the chunk (nr <= 62: P >= 128)
+        const uint32_t nr = div_p(a.tc + (kChunk / 16 - 1));  // rows bc .. bc + nr intersect the chunk (nr <= 32: P >= 128)
         if (kLoadOffsets && static_cast<uint32_t>(lane) <= nr) {
             const int64_t i0 = a.bc + lane, i1 = i0 + 1;
             a.o0 = p.offsets[i0 < p.B ? i0 : p.B];
@@ -210,9 +221,10 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
         uint32_t uoff[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t tl = a.tc + static_cast<uint32_t>(u * 1024 + lane * 16);
+            const uint32_t tl = a.tc + static_cast<uint32_t>(u * 64 + lane);
             const uint32_t q = div_p(tl);
-            const int32_t t0 = static_cast<int32_t>(tl - q * P);
+            const int32_t t0 = static_cast<int32_t>((tl - q * PPR) << 4);
+            b.q[u] = q;
             b.live[u] = q < rows_left;
             const uint32_t rs = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(q << 2), static_cast<int>(rel)));
             b.L[u] = __builtin_amdgcn_ds_bpermute(static_cast<int>(q << 2), Lr);
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (kLoadChars && ABL != 5 && b.slow[u]) {  // first / last bytes of the buffer: never read outside it
-                const uint32_t tl = b.tc + static_cast<uint32_t>(u * 1024 + lane * 16);
+                const uint32_t tl = b.tc + static_cast<uint32_t>(u * 64 + lane);
                 const int64_t row = b.bc + div_p(tl);
                 const int64_t start = p.offsets[row];
                 uint32_t w[4] = {0, 0, 0, 0};
@@ -292,7 +304,39 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
             o.z = (w[2] & keep.z) | cst.z;
             o.w = (w[3] & keep.w) | cst.w;
             if (b.j0[u] < 0) o.x = (o.x & ~0xFFu) | p.bos_id;  // position 0 with BOS
-            if (b.live[u]) store16<NT>(p.out + b.lo + u * 1024 + lane * 16, o);
+            if constexpr (!RG) {
+                if (b.live[u]) store16<NT>(p.out + b.lo + u * 1024 + lane * 16, o);
+            } else {
+                const int32_t t0 = b.j0[u] + p.bos;
+                uint8_t *dst = p.out + (b.bc + b.q[u]) * static_cast<int64_t>(P) + t0;
+                const uint32_t nb = P - static_cast<uint32_t>(t0);  // bytes of the row from this piece on
+                if (b.live[u] && nb >= 16) {
+                    const u32x4 x = {o.x, o.y, o.z, o.w};
+                    if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<u32x4u *>(dst));
+                    else *reinterpret_cast<u32x4u *>(dst) = x;
+                }
+                const uint32_t r = P & 15u;  // wave-uniform: the partial piece of every row holds r bytes
+                if (r != 0) {
+                    const bool part = b.live[u] && nb < 16;
+                    uint64_t lo64 = (static_cast<uint64_t>(o.y) << 32) | o.x;
+                    if (r & 8u) {
+                        if (part) *reinterpret_cast<u64u *>(dst) = lo64;
+                        lo64 = (static_cast<uint64_t>(o.w) << 32) | o.z;
+                        dst += 8;
+                    }
+                    if (r & 4u) {
+                        if (part) *reinterpret_cast<u32u *>(dst) = static_cast<uint32_t>(lo64);
+                        lo64 >>= 32;
+                        dst += 4;
+                    }
+                    if (r & 2u) {
+                        if (part) *reinterpret_cast<u16u *>(dst) = static_cast<uint16_t>(lo64);
+                        lo64 >>= 16;
+                        dst += 2;
+                    }
+                    if ((r & 1u) && part) *dst = static_cast<uint8_t>(lo64);
+                }
+            }
         }
     };
 
@@ -309,7 +353,12 @@ void launch_variant(const T8Params &c, dim3 grid, size_t pad, hipStream_t s) {
     case 3: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 3>), grid, dim3(kThreads), pad, s, c); break;
     case 4: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 4>), grid, dim3(kThreads), pad, s, c); break;
     case 5: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 5>), grid, dim3(kThreads), pad, s, c); break;
-    default: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0>), grid, dim3(kThreads), pad, s, c); break;
+    default:
+        if (c.P % 16 != 0 || reinterpret_cast<uintptr_t>(c.out) % 16 != 0)
+            hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0, true>), grid, dim3(kThreads), pad, s, c);
+        else
+            hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0>), grid, dim3(kThreads), pad, s, c);
+        break;
     }
 }
 
@@ -338,8 +387,8 @@ static bool fold_table(const int8_t lut[256], uint32_t tab[8], uint32_t none_v) 
 
 bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out) {
     (void)d;
-    return B > 0 && P >= 128 && P % 16 == 0 && P <= (int64_t(1) << 30) && reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
-           bsq_alphabet_size(d) <= 250 && B * P < (int64_t(1) << 51);
+    (void)out;  // any alignment: P % 16 != 0 or a misaligned output take the kernel's row-piece form (RG)
+    return B > 0 && P >= 128 && P <= (int64_t(1) << 30) && bsq_alphabet_size(d) <= 250 && B * P < (int64_t(1) << 51);
 }
 
 bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
@@ -354,9 +403,10 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
     c.B = B;
     c.P = uint32_t(P);
     c.total = B * P;
-    c.nchunks = (c.total + kChunk - 1) / kChunk;
-    c.inv_P = 1.0 / double(P);
-    div_constants(uint32_t(P), &c.magic, &c.shift, &c.pow2);
+    c.ppr = uint32_t((P + 15) / 16);
+    c.nchunks = (B * int64_t(c.ppr) + kChunk / 16 - 1) / (kChunk / 16);  // 256 pieces per wave
+    c.inv_ppr = 1.0 / double(c.ppr);
+    div_constants(c.ppr, &c.magic, &c.shift, &c.pow2);
     c.bos = d->bos;
     const int64_t room = P - d->bos - d->eos;
     c.room = int32_t(room < 0 ? 0 : room);

@@ -42,17 +42,20 @@ def variant(request):
     capi.check(lib.bsq_tuning_set(b"tokens8_lookup", 0))
 
 
-def dev_tokens(lib, capi, desc, chars, offs, P, gpu):
+def dev_tokens(lib, capi, desc, chars, offs, P, gpu, out_shift=0):
     import torch
     B = len(offs) - 1
     # one spare byte keeps the buffer non-empty; the kernel must never read it
     dch = torch.from_numpy(np.concatenate([chars, np.full(1, 0x41, np.uint8)])).to(gpu)[:len(chars)]
     dof = torch.from_numpy(offs).to(gpu)
-    out = torch.full((B, P), 99, dtype=torch.int8, device=gpu)
+    buf = torch.full((B * P + 48,), 99, dtype=torch.int8, device=gpu)
+    out = buf[out_shift:out_shift + B * P]
     capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 1, capi.I8,
                                        out.data_ptr(), None))
     torch.cuda.synchronize()
-    return out.cpu().numpy()
+    host = buf.cpu().numpy()
+    assert (host[:out_shift] == 99).all() and (host[out_shift + B * P:] == 99).all(), "wrote outside the matrix"
+    return host[out_shift:out_shift + B * P].reshape(B, P)
 
 
 def test_all_keys_and_flags_vs_oracle(gpu, oracle, variant):
@@ -86,6 +89,26 @@ def test_shapes_vs_oracle(gpu, oracle, variant, B, lo, hi, P):
         want = ora.tokenize_packed(chars, offs, P, "b", True)
         got = dev_tokens(lib, capi, capi.make_desc(key, *flags), chars, offs, P, gpu)
         assert got.tobytes() == want.tobytes(), (key, flags)
+
+
+@pytest.mark.parametrize("B,lo,hi,P", [(1, 0, 126, 129), (3, 120, 128, 130), (700, 0, 140, 143), (5000, 1, 248, 250),
+                                       (4097, 0, 999, 1001), (2000, 500, 998, 1000), (257, 0, 134, 136),
+                                       (65, 3000, 4100, 4111), (9000, 0, 126, 128)])
+def test_ragged_padlen_and_misaligned_outputs(gpu, oracle, variant, B, lo, hi, P):
+    """padlen that is not a multiple of 16 (the kernel's row-piece form: unaligned 16-byte stores, partial last piece of
+    every row in 8 / 4 / 2 / 1-byte stores) and outputs at every byte alignment; nothing outside the matrix is written."""
+    from bioseq_amd import capi
+    lib = capi.load()
+    chars, offs = nasty_batch(B * 3 + P, B, lo, hi)
+    for key, flags in (("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1)), ("SEB8", (1, 0, 1)), ("DNA5", (0, 1, 0))):
+        if hi + flags[0] + flags[1] > P:
+            continue
+        want = oracle.OracleTokenizer(key, *flags).tokenize_packed(chars, offs, P, "b", True)
+        for out_shift in (0, 1, 4, 8, 13, 16):
+            if P % 16 == 0 and out_shift in (0, 16):
+                continue  # the aligned form: covered above
+            got = dev_tokens(lib, capi, capi.make_desc(key, *flags), chars, offs, P, gpu, out_shift)
+            assert got.tobytes() == want.tobytes(), (key, flags, out_shift)
 
 
 def test_tables_that_do_not_fold_use_the_lds_lookup(gpu, variant):
