@@ -26,6 +26,40 @@ __device__ __forceinline__ void store16(void *dst, const uint4 &v) {
     }
 }
 
+// The same at ANY byte alignment (gfx950 splits an unaligned vector access in hardware), and the first `nbytes`
+// (wave-uniform, < 16) bytes of v as 8- / 4- / 2- / 1-byte stores from the lanes with `on` set: the row-piece forms of
+// the (B,P) chunk kernels (padlen not a multiple of a lane's 16 bytes, misaligned outputs).
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+template <bool NT>
+__device__ __forceinline__ void store16_unaligned(void *dst, const uint4 &v) {
+    const u32x4 x = {v.x, v.y, v.z, v.w};
+    if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<u32x4_unaligned *>(dst));
+    else *reinterpret_cast<u32x4_unaligned *>(dst) = x;
+}
+__device__ __forceinline__ void store_head_bytes(void *dst, const uint4 &v, uint32_t nbytes, bool on) {
+    uint8_t *d = static_cast<uint8_t *>(dst);
+    uint64_t w = (static_cast<uint64_t>(v.y) << 32) | v.x;
+    if (nbytes & 8u) {
+        if (on) *reinterpret_cast<u64_unaligned *>(d) = w;
+        w = (static_cast<uint64_t>(v.w) << 32) | v.z;
+        d += 8;
+    }
+    if (nbytes & 4u) {
+        if (on) *reinterpret_cast<u32_unaligned *>(d) = static_cast<uint32_t>(w);
+        w >>= 32;
+        d += 4;
+    }
+    if (nbytes & 2u) {
+        if (on) *reinterpret_cast<u16_unaligned *>(d) = static_cast<uint16_t>(w);
+        w >>= 16;
+        d += 2;
+    }
+    if ((nbytes & 1u) && on) *d = static_cast<uint8_t>(w);
+}
+
 // floor(n / d) for n < 2^31 with the constants of div_constants() (round-up method: exact below 2^31).
 // (host + device: bsq_selftest_index_math() runs the very same code on the CPU)
 __host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t shift, uint32_t pow2) {

@@ -1066,9 +1066,10 @@ struct TParams {
     const uint8_t *mask;
     int32_t C;
     uint64_t one_bits;
-    // index arithmetic without divisions: n / P for n < 2^31 is mulhi(n, magic) >> shift (pow2: n >> shift);
-    // step_q / step_r = (1024 / sizeof(T)) / P and % P: row / position advance between two stores of a lane
-    uint32_t magic, shift, pow2, step_q, step_r;
+    // index arithmetic in 16-byte PIECES (ppr = ceil(P / EPL) per row, the last one partial when P % EPL != 0),
+    // without divisions: n / ppr for n < 2^31 is mulhi(n, magic) >> shift (pow2: n >> shift);
+    // step_q / step_r = 64 / ppr and % ppr: row / piece advance between two stores of a lane
+    uint32_t ppr, magic, shift, pow2, step_q, step_r;
     uint32_t magic_c, shift_c, pow2_c;  // the same for / C (one-hot mode: row -> sequence, channel)
 };
 
@@ -1114,12 +1115,16 @@ struct ChunkState {  // one 4-KiB chunk in flight: the lane's four 16-byte store
     bool live[4];
     int32_t t0[4], L[4];
     uint32_t chan[4];
+    int64_t row[4];   // RG: row of the lane's piece
     int64_t start[4], stop[4];
     UBytes<EPL> cw[4], mw[4];
     bool slow[4];
 };
 
-template <typename T, bool NT, bool HOT, int NCH>
+// RG ("ragged"): any P and any element-aligned output.  Pieces are counted per row, so a lane's elements always lie in
+// one row; piece m of row r goes to out + (r * P + m * EPL) * sizeof(T) with an unaligned 16-byte store, the partial
+// last piece of a row (P % EPL elements) with 8 / 4 / 2 / 1-byte stores (see k_tokens_bp8, bsq_tokens8.hip).
+template <typename T, bool NT, bool HOT, int NCH, bool RG = false>
 __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     __shared__ __align__(16) uint8_t s_lut4[4][256];
     constexpr int SZ = static_cast<int>(sizeof(T));
@@ -1146,9 +1151,9 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     const int64_t k0 = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot0;
     if (k0 >= p.nchunks) return;
     const int64_t total_chars = p.offsets[p.B];
-    const uint32_t Pu = static_cast<uint32_t>(p.P);
+    const uint32_t Pu = static_cast<uint32_t>(p.P), PPR = p.ppr;
     const bool has_mask = HOT && p.mask != nullptr;
-    const bool small = nrows * p.P < (int64_t(1) << 31);  // 32-bit element indices: divide by reciprocal
+    const bool small = nrows * int64_t(PPR) < (int64_t(1) << 31);  // 32-bit piece indices: divide by reciprocal
 
     // stage A: (row, position) of the lane's four stores -- element e0 + u*EPS with e0 = lo/SZ + lane*EPL -- without a
     // per-lane division (the chunk's first element is wave-uniform, the lane's share adds < 1024 positions, the
@@ -1156,25 +1161,26 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     auto stage_a = [&](State &c, int64_t k) {
         c.valid = k < p.nchunks;
         if (!c.valid) return;
-        c.lo = k * kChunk;  // chunks are relative to `out` (16-byte aligned on this path)
-        const int64_t ec = c.lo / SZ;
+        c.lo = k * kChunk;  // !RG: chunks are relative to `out` (16-byte aligned)
+        const int64_t g0 = k * (kChunk / 16);  // first piece of the chunk
         uint32_t tc;
         if (small) {
-            const uint32_t q = fast_div(static_cast<uint32_t>(ec), p.magic, p.shift, p.pow2);
+            const uint32_t q = fast_div(static_cast<uint32_t>(g0), p.magic, p.shift, p.pow2);
             c.bc = q;
-            tc = static_cast<uint32_t>(ec) - q * Pu;
+            tc = static_cast<uint32_t>(g0) - q * PPR;
         } else {
-            c.bc = ec / p.P;
-            tc = static_cast<uint32_t>(ec - c.bc * p.P);
+            c.bc = g0 / PPR;
+            tc = static_cast<uint32_t>(g0 - c.bc * PPR);
         }
-        const uint32_t tl = tc + static_cast<uint32_t>(lane) * EPL;  // < P + 1024
+        const uint32_t tl = tc + static_cast<uint32_t>(lane);  // < ppr + 64
         const uint32_t ql = fast_div(tl, p.magic, p.shift, p.pow2);
         int64_t bu = c.bc + ql;
-        uint32_t tu = tl - ql * Pu;
+        uint32_t tu = tl - ql * PPR;  // piece of the row
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             int64_t b = bu;  // row of the flat matrix
-            c.t0[u] = static_cast<int32_t>(tu);
+            c.t0[u] = static_cast<int32_t>(tu * EPL);
+            c.row[u] = b;
             c.live[u] = b < nrows;
             b = c.live[u] ? b : nrows - 1;
             c.chan[u] = 0;
@@ -1191,8 +1197,8 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
             c.stop[u] = p.offsets[b + 1];
             bu += p.step_q;
             tu += p.step_r;
-            if (tu >= Pu) {
-                tu -= Pu;
+            if (tu >= PPR) {
+                tu -= PPR;
                 bu += 1;
             }
         }
@@ -1307,10 +1313,19 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
                     }
                 }
             }
+            uint4 o;
             if constexpr (!HOT && SZ == 1)  // 8-bit tokens: the packed words ARE the 16 output bytes
-                store16<NT>(p.out + c.lo + u * 1024 + lane * 16, uint4{packed[0], packed[1], packed[2], packed[3]});
+                o = uint4{packed[0], packed[1], packed[2], packed[3]};
             else
-                store16<NT>(p.out + c.lo + u * 1024 + lane * 16, *reinterpret_cast<const uint4 *>(vals));
+                o = *reinterpret_cast<const uint4 *>(vals);
+            if constexpr (!RG) {
+                store16<NT>(p.out + c.lo + u * 1024 + lane * 16, o);
+            } else {
+                uint8_t *dst = p.out + (c.row[u] * p.P + c.t0[u]) * SZ;
+                const uint32_t ne = Pu - static_cast<uint32_t>(c.t0[u]);  // elements of the row from this piece on
+                if (ne >= EPL) store16_unaligned<NT>(dst, o);
+                else store_head_bytes(dst, o, (Pu % EPL) * SZ, true);
+            }
         }
     };
 
@@ -2048,29 +2063,35 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     c.P = k.P;
     c.C = k.C;
     c.one_bits = k.one_bits;
+    constexpr uint32_t EPL = 16u / uint32_t(sizeof(T));
+    const bool ragged = k.P % EPL != 0 || reinterpret_cast<uintptr_t>(k.out) % 16 != 0;
     c.total = k.B * k.P * int64_t(sizeof(T)) * (HOT ? k.C : 1);
-    c.nchunks = (c.total + kChunk - 1) / kChunk;
+    c.ppr = uint32_t((k.P + EPL - 1) / EPL);
+    c.nchunks = (k.B * (HOT ? int64_t(k.C) : 1) * int64_t(c.ppr) + kChunk / 16 - 1) / (kChunk / 16);  // 256 pieces per wave
     c.bos = k.bos;
     c.bos_id = uint32_t(k.bos_id);
     c.fill_id = uint32_t(k.fill_id);
     c.at_len_id = k.eos ? uint32_t(k.eos_id) : c.fill_id;
     const int64_t room = k.P - k.bos - k.eos;
     c.room = int32_t(room < 0 ? 0 : room);
-    div_constants(uint32_t(k.P), &c.magic, &c.shift, &c.pow2);
+    div_constants(c.ppr, &c.magic, &c.shift, &c.pow2);
     div_constants(uint32_t(k.C > 0 ? k.C : 1), &c.magic_c, &c.shift_c, &c.pow2_c);
-    c.step_q = (1024u / uint32_t(sizeof(T))) / uint32_t(k.P);
-    c.step_r = (1024u / uint32_t(sizeof(T))) % uint32_t(k.P);
+    c.step_q = 64u / c.ppr;
+    c.step_r = 64u % c.ppr;
     // Chunks per wave: 1.  The software-pipelined 4-chunk form (knob "tokenize_nch" = 4) is 15-20 % SLOWER on cfg2 /
     // cfg5: the kernel is bound by its ~550 VALU instructions per chunk, not by memory latency, and four chunks
     // per wave cost occupancy (102 VGPRs).
-    const int nch = bsq_internal::tuning("tokenize_nch") == 4 ? 4 : 1;
+    const int nch = bsq_internal::tuning("tokenize_nch") == 4 && !ragged ? 4 : 1;
     const int64_t groups = ((c.nchunks + 7) / 8 + int64_t(4) * nch - 1) / (int64_t(4) * nch);
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
     const int padv = bsq_internal::tuning("tokenize_pad");  // unused dynamic LDS = occupancy cap (experiments)
     const size_t pad = padv > 0 ? size_t(padv) : 0;
     const bool nt = bsq_internal::nontemporal_stores();
-    if (nch == 4) {
+    if (ragged) {
+        if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 1, true>), grid, dim3(kThreads), pad, s, c);
+        else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 1, true>), grid, dim3(kThreads), pad, s, c);
+    } else if (nch == 4) {
         if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 4>), grid, dim3(kThreads), pad, s, c);
         else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 4>), grid, dim3(kThreads), pad, s, c);
     } else {
@@ -2239,8 +2260,10 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         bsq_internal::tokens_bp8_applicable(d, B, P, out) &&
         ((addr % 16 == 0 && P % 16 == 0) || bsq_internal::tuning("tokens8") != 2))  // knob 2: aligned shapes only (round-2 state)
         return bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, out, s);
-    if (batch_first && bsq_internal::tuning("tokenize_path") != 1 && addr % 16 == 0 &&
-        P % int64_t(16 / sz) == 0) {  // chunk kernel: every lane's 16 output bytes lie inside one row
+    // chunk kernel: a lane's 16 output bytes lie inside one row (its row-piece form when P % (16 / sz) != 0 or the output
+    // is not 16-byte aligned; knob "tokenize_path" 2: aligned shapes only, the rest falls to k_tokenize_rows as in round 1)
+    if (batch_first && bsq_internal::tuning("tokenize_path") != 1 && addr % sz == 0 &&
+        ((addr % 16 == 0 && P % int64_t(16 / sz) == 0) || bsq_internal::tuning("tokenize_path") != 2)) {
         switch (t) {
         case BSQ_I8: return launch_tokenize_chunks<int8_t, false>(k, s);
         case BSQ_I16: return launch_tokenize_chunks<int16_t, false>(k, s);
@@ -2339,7 +2362,8 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
         bsq_internal::workspace_release(ws, s);
         return wst;
     }
-    if (k.C <= 250 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && P % int64_t(16 / sz) == 0) {
+    if (k.C <= 250 && reinterpret_cast<uintptr_t>(out) % sz == 0 &&
+        ((reinterpret_cast<uintptr_t>(out) % 16 == 0 && P % int64_t(16 / sz) == 0) || bcl_path != 3)) {  // knob 3: aligned only
         switch (sz) {
         case 1: return launch_tokenize_chunks<uint8_t, true>(k, s);
         case 2: return launch_tokenize_chunks<uint16_t, true>(k, s);

@@ -92,9 +92,6 @@ struct CharStage {  // stage B: the lane's four 16-byte character vectors in fli
 // wave, but pieces are counted per ROW (ceil(P / 16) of them, the last one partial), so that a lane's bytes always lie
 // inside one row: piece m of row b goes to out + b * P + 16 m with an unaligned 16-byte store, the partial piece with
 // 8 / 4 / 2 / 1-byte stores.  With P % 16 == 0 and a 16-byte aligned output this is the same mapping as RG = false.
-typedef uint64_t u64u __attribute__((aligned(1)));
-typedef uint32_t u32u __attribute__((aligned(1)));
-typedef uint16_t u16u __attribute__((aligned(1)));
 
 template <bool NT, int LK, int ABL, bool RG = false>
 __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
@@ -310,32 +307,9 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
                 const int32_t t0 = b.j0[u] + p.bos;
                 uint8_t *dst = p.out + (b.bc + b.q[u]) * static_cast<int64_t>(P) + t0;
                 const uint32_t nb = P - static_cast<uint32_t>(t0);  // bytes of the row from this piece on
-                if (b.live[u] && nb >= 16) {
-                    const u32x4 x = {o.x, o.y, o.z, o.w};
-                    if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<u32x4u *>(dst));
-                    else *reinterpret_cast<u32x4u *>(dst) = x;
-                }
+                if (b.live[u] && nb >= 16) store16_unaligned<NT>(dst, o);
                 const uint32_t r = P & 15u;  // wave-uniform: the partial piece of every row holds r bytes
-                if (r != 0) {
-                    const bool part = b.live[u] && nb < 16;
-                    uint64_t lo64 = (static_cast<uint64_t>(o.y) << 32) | o.x;
-                    if (r & 8u) {
-                        if (part) *reinterpret_cast<u64u *>(dst) = lo64;
-                        lo64 = (static_cast<uint64_t>(o.w) << 32) | o.z;
-                        dst += 8;
-                    }
-                    if (r & 4u) {
-                        if (part) *reinterpret_cast<u32u *>(dst) = static_cast<uint32_t>(lo64);
-                        lo64 >>= 32;
-                        dst += 4;
-                    }
-                    if (r & 2u) {
-                        if (part) *reinterpret_cast<u16u *>(dst) = static_cast<uint16_t>(lo64);
-                        lo64 >>= 16;
-                        dst += 2;
-                    }
-                    if ((r & 1u) && part) *dst = static_cast<uint8_t>(lo64);
-                }
+                if (r != 0) store_head_bytes(dst, o, r, b.live[u] && nb < 16);
             }
         }
     };
