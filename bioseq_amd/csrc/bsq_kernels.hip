@@ -2150,15 +2150,16 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P) {
         //                 chunk-owner none -- 1000 x 256 DNA f32 6 vs 19 us, 1024 x 512 DNA int8 9 vs 16 us,
         //                 4096 x 512 DNA f32 17 vs 20 us -- so it also takes every output <= 8 MB and rows >= 24 B
         //                 up to 128 MB;
-        //  1 tiled      : the rest (tiny rows such as int8 DNA once the batch is not small).
+        //  1 tiled      : the rest (tiny rows such as int8 DNA once the batch is not small, 64-byte aligned position rows).
         const int64_t rowbytes = C * int64_t(sz), pitch = B * rowbytes, total = pitch * P;
         const bool pinned_columns = pitch % (8 * kChunk) == 0;
         const bool owner_big = rowbytes >= 48 && ((pinned_columns && B <= 131072) || B <= 16384);
         const bool owner_small = total <= (int64_t(8) << 20) || (rowbytes >= 24 && total <= (int64_t(128) << 20));
         if ((owner_big || owner_small) && total < (int64_t(4) << 30))
             path = 3;
-        else if (rowbytes >= 16 && total >= (int64_t(192) << 20))
-            path = 2;
+        else if ((rowbytes >= 16 && total >= (int64_t(192) << 20)) || (pitch % 64 != 0 && total >= (int64_t(32) << 20)))
+            path = 2;  // (second case: position rows that are not 64-byte aligned -- the tiles would share memory sectors or
+                       // fall to element stores: 250001 x 256 int8 DNA 187 -> 120 us, profiles/r02/path_unaligned.txt)
         else
             path = 1;
     }
@@ -2314,14 +2315,27 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
             hipLaunchKernelGGL((k_tokens_raw2<false, false>), vgrid, dim3(kThreads), 0, s, k);
         return check_launch("k_tokens_raw<value>");
     }
+    // Sequences per tile (knob "tokenize_tb": 0 automatic, 64 / 128 / 256).  A tile writes TB * sz-byte row segments;
+    // when the rows are not 64-byte aligned (B * sz % 64 != 0) neighbouring tiles share memory sectors, and longer
+    // segments share fewer of them: 65000 x 1024 int32 99 -> 82 us, int16 83 -> 55 us with 256 sequences
+    // (profiles/r02/tile_tb_lab.txt); aligned batches and small ones keep the short tiles (more workgroups).
+    const bool shared_sectors = (B * int64_t(sz)) % 64 != 0 && B >= 16384;
+    const int tbk = shared_sectors && bsq_internal::tuning("tokenize_tb") == 0 ? 256 : bsq_internal::tuning("tokenize_tb");
+#define BSQ_TILE(T, AUTO)                                                        \
+    switch (tbk ? tbk : AUTO) {                                                  \
+    case 64: return launch_tokenize_tile<T, 64>(k, s);                           \
+    case 128: return launch_tokenize_tile<T, 128>(k, s);                         \
+    default: return launch_tokenize_tile<T, 256>(k, s);                          \
+    }
     switch (t) {
     case BSQ_I8: return launch_tokenize_tile<int8_t, 256>(k, s);
-    case BSQ_I16: return launch_tokenize_tile<int16_t, 128>(k, s);
-    case BSQ_I32: return launch_tokenize_tile<int32_t, 64>(k, s);
-    case BSQ_U64: return launch_tokenize_tile<uint64_t, 64>(k, s);
-    case BSQ_F32: return launch_tokenize_tile<float, 64>(k, s);
-    case BSQ_F64: return launch_tokenize_tile<double, 64>(k, s);
+    case BSQ_I16: BSQ_TILE(int16_t, 128)
+    case BSQ_I32: BSQ_TILE(int32_t, 64)
+    case BSQ_U64: BSQ_TILE(uint64_t, 64)
+    case BSQ_F32: BSQ_TILE(float, 64)
+    case BSQ_F64: BSQ_TILE(double, 64)
     }
+#undef BSQ_TILE
     return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
 }
 

@@ -20,10 +20,10 @@ def run(budget=120.0, seed=1):
     while time.time() < t_end:
         key = KEYS[rng.integers(len(KEYS))]
         eos, bos, pad = (int(x) for x in rng.integers(0, 2, 3))
-        B = int(rng.choice([1, 2, 7, 63, 64, 65, 200, 255, 256, 257, 1000, 4096, 5000, 20000]))
+        B = int(rng.choice([1, 2, 7, 63, 64, 65, 200, 255, 256, 257, 1000, 1001, 4096, 5000, 20000, 20001, 33000]))
         P = int(rng.choice([1, 3, 15, 16, 17, 63, 64, 65, 100, 128, 255, 300, 512])) + eos + bos
-        if rng.random() < 0.25:  # multiples of 16 from 128 up: the (B,P) int8 kernel k_tokens_bp8 applies
-            P = int(rng.choice([128, 144, 160, 272, 512, 1024, 2048, 4112]))
+        if rng.random() < 0.35:  # 128 and up: the (B,P) int8 kernel k_tokens_bp8 applies (its row-piece form when P % 16 != 0)
+            P = int(rng.choice([128, 129, 135, 144, 160, 250, 272, 500, 512, 1000, 1001, 1024, 2048, 4111, 4112]))
         hi = P - eos - bos
         lo = int(rng.integers(0, hi + 1))
         if B * P > 6_000_000:
@@ -36,14 +36,15 @@ def run(budget=120.0, seed=1):
         mask = (rng.random(chars.size) < 0.7).astype(np.uint8) if use_mask else None
         path = int(rng.integers(0, 4))
         capi.check(lib.bsq_tuning_set(b"onehot_path", path))
-        capi.check(lib.bsq_tuning_set(b"tokenize_path", int(rng.integers(0, 2))))
-        knobs = (int(rng.integers(0, 4)), int(rng.choice([0, 0, 1, 2])), int(rng.integers(0, 3)), int(rng.integers(0, 2)))
+        capi.check(lib.bsq_tuning_set(b"tokenize_path", int(rng.integers(0, 3))))
+        capi.check(lib.bsq_tuning_set(b"tokenize_tb", int(rng.choice([0, 64, 128, 256]))))
+        knobs = (int(rng.integers(0, 4)), int(rng.choice([0, 0, 1, 2])), int(rng.integers(0, 3)), int(rng.integers(0, 3)))
         capi.check(lib.bsq_tuning_set(b"tile_order", knobs[0]))
         capi.check(lib.bsq_tuning_set(b"expand_mode", knobs[1]))
         capi.check(lib.bsq_tuning_set(b"tokens8_lookup", knobs[2]))
         capi.check(lib.bsq_tuning_set(b"tokens8", knobs[3]))
-        capi.check(lib.bsq_tuning_set(b"raw_mode", int(rng.integers(0, 4))))
-        capi.check(lib.bsq_tuning_set(b"bcl_path", int(rng.integers(0, 3))))
+        capi.check(lib.bsq_tuning_set(b"raw_mode", int(rng.integers(0, 5))))
+        capi.check(lib.bsq_tuning_set(b"bcl_path", int(rng.integers(0, 4))))
         tok, ora = bsq.Tokenizer(key, eos, bos, pad), O.OracleTokenizer(key, eos, bos, pad)
         shift = int(rng.integers(0, 4))  # misaligned device views of the inputs
         dch = torch.from_numpy(np.concatenate([np.zeros(shift, np.uint8), chars])).to(dev)[shift:]
@@ -71,7 +72,7 @@ def run(budget=120.0, seed=1):
         except AssertionError as ex:
             raise AssertionError("MISMATCH %s %r" % (ex, desc))
         n += 1
-    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"expand_mode", b"tokens8_lookup", b"tokens8", b"raw_mode", b"bcl_path"):
+    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"expand_mode", b"tokens8_lookup", b"tokens8", b"raw_mode", b"bcl_path", b"tokenize_tb"):
         capi.check(lib.bsq_tuning_set(name, 0))
     return n
 
