@@ -2131,7 +2131,7 @@ bsq_status launch_expand_bcl(const uint8_t *tokens, int64_t B, int64_t P, int32_
 extern "C" {
 
 // 0 generic, 1 tiled, 2 two-pass, 3 chunk-owner
-static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P) {
+static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool misaligned_out = false) {
     const int64_t ntiles = ((B + 63) / 64) * ((P + kTT - 1) / kTT);
     const bool tiled_ok = C <= 250 && 4 * (64 * C * int64_t(sz) + 16) + tile_fixed_bytes<64>() <= 60 * 1024 &&
                           ntiles < (int64_t(1) << 31) && B < (int64_t(1) << 31) - 256 && P <= kMaxTiledP;
@@ -2157,7 +2157,7 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P) {
         const bool owner_small = total <= (int64_t(8) << 20) || (rowbytes >= 24 && total <= (int64_t(128) << 20));
         if ((owner_big || owner_small) && total < (int64_t(4) << 30))
             path = 3;
-        else if ((rowbytes >= 16 && total >= (int64_t(192) << 20)) || (pitch % 64 != 0 && total >= (int64_t(32) << 20)))
+        else if ((rowbytes >= 16 && total >= (int64_t(192) << 20)) || ((pitch % 64 != 0 || misaligned_out) && total >= (int64_t(32) << 20)))
             path = 2;  // (second case: position rows that are not 64-byte aligned -- the tiles would share memory sectors or
                        // fall to element stores: 250001 x 256 int8 DNA 187 -> 120 us, profiles/r02/path_unaligned.txt)
         else
@@ -2190,7 +2190,7 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     const size_t sz = bsq_dtype_size(t);
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
     // Limits of the LDS kernels: 8-bit token ids, 32-bit tile arithmetic, row images must fit in LDS.
-    const int path = choose_onehot_path(k.C, sz, B, P);
+    const int path = choose_onehot_path(k.C, sz, B, P, reinterpret_cast<uintptr_t>(out) % 16 != 0);
     if (path == 0) return bsq_onehot_device_generic(d, chars, offsets, mask_or_null, B, P, t, out, hip_stream);
     k.one_bits = one_bits_of(t);
     const int64_t pitch = B * k.C * int64_t(sz);
