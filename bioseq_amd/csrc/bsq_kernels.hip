@@ -32,8 +32,8 @@
 //   k_tokens_raw<value>, k_tokenize_tile   (P,B) tokens (int8 / wider types): tiled transpose through LDS.
 //   k_*_generic        one thread per output element; any shape / alignment / alphabet (BYTES has ids > 255).
 //                      Fallback and in-library cross-check of the fast kernels.
-//   k_fill*, k_fill_pattern   write-bandwidth yardsticks and the store-pattern diagnostics.
-//   k_first_too_long   device-side length validation.     k_xcd_probe   which XCD each block ran on (diagnostic).
+//   k_first_too_long   device-side length validation.
+// (The write-bandwidth yardsticks, store-pattern diagnostics and probes of include/bsq_diag.h live in bsq_diag.hip.)
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -1502,83 +1502,6 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_generic(const GParams p) 
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_fill(uint4 *dst, size_t n16, uint32_t pattern) {
-    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
-    const uint4 v{pattern, pattern, pattern, pattern};
-    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n16; i += stride) dst[i] = v;
-}
-
-// Write-pattern experiments (fill_mode 1..4); mode 0 is k_fill above.
-//  1/3: one 16-byte store per thread, one block per 4 KiB (plain / nt)
-//  2/4: one block per 16 KiB, 4 stores per thread 4 KiB apart (plain / nt)
-template <int PER_THREAD, bool NT>
-__global__ __launch_bounds__(kThreads) void k_fill_blocks(uint4 *dst, size_t n16, uint32_t pattern) {
-    const uint4 v{pattern, pattern, pattern, pattern};
-    const size_t base = static_cast<size_t>(blockIdx.x) * (kThreads * PER_THREAD) + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k) {
-        const size_t i = base + static_cast<size_t>(k) * kThreads;
-        if (i < n16) store16<NT>(dst + i, v);
-    }
-}
-
-// Diagnostic: the WRITE PATTERN of the tiled one-hot kernel without any of its work.  The output is a
-// (rows, pitch) byte matrix; block (cb, rb) owns columns [cb*seg, (cb+1)*seg) of 4*rpw rows; each of its
-// 4 waves writes rpw rows (contiguous rows if !interleave), `seg` contiguous bytes per row.
-template <bool NT>
-__global__ __launch_bounds__(kThreads) void k_fill_pattern(uint8_t *dst, int64_t rows, int64_t pitch, int32_t seg,
-                                                           int32_t rpw, int32_t ncb, int32_t nrb, int32_t order,
-                                                           int32_t interleave, int32_t wait) {
-    int32_t cb, rb;
-    if (order >= 2) {  // permutations of the block -> column-chunk map (ncb must be a multiple of 64)
-        const uint32_t b = blockIdx.x % ncb;
-        rb = blockIdx.x / ncb;
-        uint32_t c = b;
-        if (order == 2) c = (b & ~7u) | ((b + (b >> 3)) & 7u);            // rotate the mod-8 class per group of 8
-        if (order == 3) c = b ^ 1u;                                        // swap neighbours
-        if (order == 4) c = (b & ~63u) | (__brev(b & 63u) >> 26);          // bit-reverse inside 64-chunk windows
-        if (order == 5) c = (b & ~7u) | ((b + 1u) & 7u);                   // constant rotation of the class
-        if (order == 6) c = (b & ~63u) | (((b & 7u) << 3) | ((b >> 3) & 7u));  // transpose 8x8 inside windows
-        cb = static_cast<int32_t>(c);
-    } else if (order == 0) {
-        cb = blockIdx.x % ncb;
-        rb = blockIdx.x / ncb;
-    } else {
-        rb = blockIdx.x % nrb;
-        cb = blockIdx.x / nrb;
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint4 v{1, 2, 3, 4};
-    if (interleave == 2) {  // row-wise: the 4 waves write 4 adjacent segments of the SAME row
-        for (int r = 0; r < rpw; ++r) {
-            const int64_t row = static_cast<int64_t>(rb) * rpw + r;
-            if (row >= rows) break;
-            uint8_t *g = dst + row * pitch + (static_cast<int64_t>(cb) * 4 + wave) * seg;
-            for (int32_t o = lane * 16; o < seg; o += 1024) store16<NT>(g + o, v);
-        }
-        return;
-    }
-    for (int r = 0; r < rpw; ++r) {
-        const int64_t row = static_cast<int64_t>(rb) * 4 * rpw + (interleave ? r * 4 + wave : wave * rpw + r);
-        if (row >= rows) break;
-        uint8_t *g = dst + row * pitch + static_cast<int64_t>(cb) * seg;
-        for (int32_t o = lane * 16; o < seg; o += 1024) store16<NT>(g + o, v);
-        // knob "pattern_wait" n > 0: at most n - 1 (0 / 1 / 2 / 4) stores of the wave in flight before its next row
-        if (wait == 1) __builtin_amdgcn_s_waitcnt(0x0F70);
-        else if (wait == 2) __builtin_amdgcn_s_waitcnt(0x0F71);
-        else if (wait == 3) __builtin_amdgcn_s_waitcnt(0x0F72);
-        else if (wait == 5) __builtin_amdgcn_s_waitcnt(0x0F74);
-    }
-}
-
-// Diagnostic: the XCD every block of a 1-D grid ran on (HW_REG_XCC_ID, 0..7).  The chunk kernels rely -- for
-// speed only -- on blocks b and b + 8 sharing an XCD; this records what the dispatcher actually did.
-__global__ __launch_bounds__(kThreads) void k_xcd_probe(int32_t *xcd) {
-    uint32_t id;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-    if (threadIdx.x == 0) xcd[blockIdx.x] = static_cast<int32_t>(id & 0xFu);
-}
-
 // first_bad[0]: first sequence longer than `room`; first_bad[1]: first entry i with offsets[i] > offsets[i + 1],
 // offsets[0] < 0 (reported as 0) or offsets[B] > nchars (reported as B) -- only checked when nchars >= 0.
 __global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offsets, int64_t B, int64_t room, int64_t nchars,
@@ -2445,148 +2368,6 @@ bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, 
     }
 #undef BSQ_GEN
     return check_launch("k_tokenize_generic");
-}
-
-bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip_stream) {
-    if (!dst || nbytes % 16 || reinterpret_cast<uintptr_t>(dst) % 16)
-        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "fill needs a 16-byte aligned pointer and size");
-    if (nbytes == 0) return BSQ_OK;
-    const size_t n16 = nbytes / 16;
-    const size_t blocks = (n16 + kThreads - 1) / kThreads;
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    uint4 *d4 = static_cast<uint4 *>(dst);
-    const int mode = bsq_internal::tuning("fill_mode");
-    if (blocks >= (size_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "fill too large");
-    switch (mode) {
-    case 1: hipLaunchKernelGGL((k_fill_blocks<1, false>), dim3(unsigned(blocks)), dim3(kThreads),
-                               size_t(bsq_internal::tuning("fill_pad")), s, d4, n16, pattern); break;
-    case 2: hipLaunchKernelGGL((k_fill_blocks<4, false>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;
-    case 3: hipLaunchKernelGGL((k_fill_blocks<1, true>), dim3(unsigned(blocks)), dim3(kThreads),
-                               size_t(bsq_internal::tuning("fill_pad")), s, d4, n16, pattern); break;
-    case 4: hipLaunchKernelGGL((k_fill_blocks<4, true>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;
-    default: {
-        const unsigned grid = unsigned(blocks > 256 * 16 ? 256 * 16 : blocks);
-        hipLaunchKernelGGL(k_fill, dim3(grid), dim3(kThreads), 0, s, d4, n16, pattern);
-    }
-    }
-    return check_launch("k_fill");
-}
-
-bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32_t seg, int32_t rows_per_wave,
-                                   int32_t order, int32_t interleave, int32_t nt, void *hip_stream) {
-    if (!dst || rows <= 0 || pitch <= 0 || seg <= 0 || seg % 16 || pitch % seg || rows_per_wave <= 0)
-        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bad fill pattern");
-    int32_t ncb = int32_t(pitch / seg);
-    int32_t nrb = int32_t((rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave));
-    if (interleave == 2) {
-        if (ncb % 4) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "row-wise pattern needs pitch % (4*seg) == 0");
-        ncb /= 4;
-        nrb = int32_t((rows + rows_per_wave - 1) / rows_per_wave);
-    }
-    const dim3 grid(unsigned(int64_t(ncb) * nrb));
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const size_t pad = size_t(bsq_internal::tuning("fill_pad"));  // unused dynamic LDS: caps the workgroups per CU
-    const int32_t wait = bsq_internal::tuning("pattern_wait");
-    if (nt)
-        hipLaunchKernelGGL((k_fill_pattern<true>), grid, dim3(kThreads), pad, s, static_cast<uint8_t *>(dst), rows, pitch,
-                           seg, rows_per_wave, ncb, nrb, order, interleave, wait);
-    else
-        hipLaunchKernelGGL((k_fill_pattern<false>), grid, dim3(kThreads), pad, s, static_cast<uint8_t *>(dst), rows, pitch,
-                           seg, rows_per_wave, ncb, nrb, order, interleave, wait);
-    return check_launch("k_fill_pattern");
-}
-
-// Host-side self-test of the kernels' division-free index arithmetic (the same inline functions the device runs):
-// fast_div against n / d for dividends below 2^31, div_by against the integer quotient / remainder below 2^52.
-// Returns 0, or a non-zero code that identifies the first failing case.
-int64_t bsq_selftest_index_math(void) {
-    uint64_t x = 0x9E3779B97F4A7C15ull;
-    auto next = [&x]() {  // splitmix64
-        x += 0x9E3779B97F4A7C15ull;
-        uint64_t z = x;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
-    };
-    for (int it = 0; it < 20000; ++it) {
-        uint32_t d;
-        switch (it % 5) {
-        case 0: d = uint32_t(it / 5 + 1); break;                                    // 1, 2, 3, ...
-        case 1: d = uint32_t(1) << (it / 5 % 31); break;                            // powers of two
-        case 2: d = (uint32_t(1) << (it / 5 % 30 + 1)) - 1; break;                  // 2^k - 1
-        case 3: d = (uint32_t(1) << (it / 5 % 29 + 1)) + 1; break;                  // 2^k + 1
-        default: d = uint32_t(next() % (uint64_t(1) << 30)) + 1; break;             // random <= 2^30
-        }
-        if (d > (uint32_t(1) << 30)) d = uint32_t(1) << 30;
-        uint32_t magic, shift, pow2;
-        div_constants(d, &magic, &shift, &pow2);
-        const double inv = 1.0 / double(d);
-        for (int j = 0; j < 64; ++j) {
-            uint32_t n;
-            const uint64_t qmax = ((uint64_t(1) << 31) - 1) / d;
-            switch (j % 4) {
-            case 0: n = uint32_t(next() & 0x7FFFFFFFu); break;
-            case 1: n = uint32_t((next() % (qmax + 1)) * d); break;                 // exact multiples
-            case 2: { const uint64_t m = (next() % (qmax + 1)) * d; n = uint32_t(m ? m - 1 : 0); break; }  // one below
-            default: n = uint32_t(0x7FFFFFFFu - uint32_t(j)); break;                // the top of the range
-            }
-            if (fast_div(n, magic, shift, pow2) != n / d) return 1000000 + it;
-            int64_t big = int64_t(next() >> 12);                                    // < 2^52
-            if (j % 8 == 3) big = (big / d) * int64_t(d);
-            if (j % 8 == 5) big = (int64_t(1) << 52) - 1 - j;
-            int64_t rem = -1;
-            const int64_t q = div_by(big, int64_t(d), inv, &rem);
-            if (q != big / int64_t(d) || rem != big % int64_t(d)) return 2000000 + it;
-            // div64: dividends up to 2^63 - 1, divisors up to 2^42 (a position row of 2^31 sequences x 2000 bytes)
-            const uint64_t d64 = (j % 3 == 0) ? uint64_t(d) : ((j % 3 == 1) ? uint64_t(d) * 2000u : (next() >> 22) + 1);
-            const Div64 dc = div64_constants(d64);
-            uint64_t n64 = next() >> 1;
-            if (j % 8 == 2) n64 = (n64 / d64) * d64;
-            if (j % 8 == 6) n64 = (n64 / d64) * d64 + d64 - 1;
-            if (j % 8 == 7) n64 = (uint64_t(1) << 63) - 1 - uint64_t(j);
-            if (div64(n64, dc) != n64 / d64) return 3000000 + it;
-        }
-    }
-    return 0;
-}
-
-bsq_status bsq_xcd_of_blocks_device(int32_t *xcd_dev, int32_t nblocks, void *hip_stream) {
-    if (!xcd_dev || nblocks <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer or nblocks <= 0");
-    hipLaunchKernelGGL(k_xcd_probe, dim3(unsigned(nblocks)), dim3(kThreads), 0, static_cast<hipStream_t>(hip_stream), xcd_dev);
-    return check_launch("k_xcd_probe");
-}
-
-int32_t bsq_xcd_round_robin(void) {
-    static int cached[16] = {};  // 0 unknown, 1 no, 2 yes
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
-        (void)hipGetLastError();
-        return -1;
-    }
-    if (cached[dev]) return cached[dev] - 1;
-    constexpr int n = 256;
-    int32_t *d = nullptr;
-    int32_t h[n];
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(int32_t));
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_xcd_probe, dim3(n), dim3(kThreads), 0, nullptr, d);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-        (void)hipFree(d);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return -1;
-    }
-    bool ok = true;
-    for (int b = 0; b + 8 < n; ++b) ok = ok && h[b] == h[b + 8];
-    uint32_t seen = 0;
-    for (int b = 0; b < 8; ++b) seen |= 1u << (h[b] & 15);
-    ok = ok && __builtin_popcount(seen) == 8;
-    cached[dev] = ok ? 2 : 1;
-    return ok ? 1 : 0;
 }
 
 bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos,
