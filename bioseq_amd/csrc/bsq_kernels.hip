@@ -179,9 +179,11 @@ __device__ __forceinline__ uint32_t load_clamped(global_u32_ptr base, uint32_t o
 }
 
 // `start` = offsets[b] - rule.off0 (window-relative), tpos = first of the four positions.
-template <bool MASK = true>
+// CHECK = false: the caller has hoisted the (workgroup-uniform) `nonempty` test out of its loop -- inside it, the
+// branch keeps the compiler from batching the span reads and the loads of several fetches.
+template <bool MASK = true, bool CHECK = true>
 __device__ __forceinline__ Raw4 fetch4(const TokenRule p, uint32_t start, int32_t tpos) {
-    if (!p.nonempty) return Raw4{0, 0, ~0u, ~0u, 0};  // wave-uniform: nothing to read
+    if (CHECK && !p.nonempty) return Raw4{0, 0, ~0u, ~0u, 0};  // wave-uniform: nothing to read
     const uint32_t j = start + static_cast<uint32_t>(tpos - p.bos);  // may be "-1" (BOS position of the first sequence)
     const uint32_t rel = j + p.mis;
     const uint32_t w0 = rel & ~3u;
@@ -304,24 +306,28 @@ __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, i
     const int g = tid & 15;  // 16 lanes x 4 characters cover the 64 positions of one sequence
     constexpr int NI = TB / 16;                  // sequences per thread
     constexpr int BATCH = NI < 4 ? NI : 4;       // fetches kept in flight (more costs occupancy: 129 VGPRs at 8)
+    auto run = [&](auto nonempty) {  // the window holds characters (workgroup-uniform): hoisted out of the fetches
 #pragma unroll 1
-    for (int i0 = 0; i0 < NI; i0 += BATCH) {
-        Raw4 raw[BATCH];
-        int32_t len[BATCH];
+        for (int i0 = 0; i0 < NI; i0 += BATCH) {
+            Raw4 raw[BATCH];
+            int32_t len[BATCH];
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int sb = (tid >> 4) + 16 * (i0 + k);
-            const SeqSpan sp = s_span[sb];
-            len[k] = sp.len;
-            raw[k] = fetch4(rule, sp.start, t0 + 4 * g);
-        }
+            for (int k = 0; k < BATCH; ++k) {
+                const int sb = (tid >> 4) + 16 * (i0 + k);
+                const SeqSpan sp = s_span[sb];
+                len[k] = sp.len;
+                raw[k] = decltype(nonempty)::value ? fetch4<true, false>(rule, sp.start, t0 + 4 * g) : Raw4{0, 0, ~0u, ~0u, 0};
+            }
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int sb = (tid >> 4) + 16 * (i0 + k);
-            const uint32_t w = finish4(rule, s_lut, raw[k], len[k], t0 + 4 * g);
-            *reinterpret_cast<uint32_t *>(s_tok + sb * kTokStride + 4 * g) = (b0 + sb < p.B) ? w : kNone * 0x01010101u;
+            for (int k = 0; k < BATCH; ++k) {
+                const int sb = (tid >> 4) + 16 * (i0 + k);
+                const uint32_t w = finish4(rule, s_lut, raw[k], len[k], t0 + 4 * g);
+                *reinterpret_cast<uint32_t *>(s_tok + sb * kTokStride + 4 * g) = (b0 + sb < p.B) ? w : kNone * 0x01010101u;
+            }
         }
-    }
+    };
+    if (rule.nonempty) run(std::true_type{});
+    else run(std::false_type{});
     __syncthreads();
 }
 
@@ -781,7 +787,11 @@ __host__ __device__ constexpr int raw_stride() {
 
 // RAW = false: the same kernel produces the final int8 (P,B) token matrix of batch_tokenize(batch_first=False)
 // (unmapped / unpadded positions are 0 instead of kNone).
-template <bool MASK, bool RAW = true, int TB = kRawTB, int TT = kTT>
+// HOIST: the (workgroup-uniform) "window holds characters" test is taken out of the fetches, so the compiler batches
+// the span reads and loads of the 8 fetches of a step (70 VGPRs instead of 42, 7 instead of 8 workgroups per CU):
+// 12-15 % faster while the grid is about one round of workgroups (latency), 2-5 % slower on large grids
+// (profiles/r02/ab_hoist.txt, ab_hoist2.txt) -- the launcher picks it for small (P,B) int8 token matrices.
+template <bool MASK, bool RAW = true, int TB = kRawTB, int TT = kTT, bool HOIST = false>
 __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     constexpr int STRIDE = raw_stride<TB>();
     constexpr int LPS = TT / 4;          // lanes per sequence (4 characters each)
@@ -818,28 +828,36 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     // of one wave are 4 apart.
     const int tg = tid / LPS;
     const int sb0 = 4 * (tg % (SPP / 4)) + tg / (SPP / 4);
+    auto run = [&](auto mode) {
+        constexpr int M = decltype(mode)::value;
 #pragma unroll 1
-    for (int i0 = 0; i0 < NI; i0 += BATCH) {
-        Raw4 raw[BATCH];
-        int32_t len[BATCH];
+        for (int i0 = 0; i0 < NI; i0 += BATCH) {
+            Raw4 raw[BATCH];
+            int32_t len[BATCH];
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int sb = sb0 + SPP * (i0 + k);
-            const SeqSpan sp = s_span[sb];
-            len[k] = sp.len;
-            raw[k] = fetch4<MASK>(rule, sp.start, tpos);
-        }
+            for (int k = 0; k < BATCH; ++k) {
+                const int sb = sb0 + SPP * (i0 + k);
+                const SeqSpan sp = s_span[sb];
+                len[k] = sp.len;
+                if constexpr (M == 0) raw[k] = Raw4{0, 0, ~0u, ~0u, 0};
+                else if constexpr (M == 1) raw[k] = fetch4<MASK, false>(rule, sp.start, tpos);
+                else raw[k] = fetch4<MASK, true>(rule, sp.start, tpos);
+            }
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int sb = sb0 + SPP * (i0 + k);
-            const uint32_t w = finish4<MASK>(rule, s_lut, raw[k], len[k], tpos);  // columns >= B are never read
-            uint8_t *col = s_t + (4 * g) * STRIDE + sb;
-            col[0] = static_cast<uint8_t>(w);
-            col[STRIDE] = static_cast<uint8_t>(w >> 8);
-            col[2 * STRIDE] = static_cast<uint8_t>(w >> 16);
-            col[3 * STRIDE] = static_cast<uint8_t>(w >> 24);
+            for (int k = 0; k < BATCH; ++k) {
+                const int sb = sb0 + SPP * (i0 + k);
+                const uint32_t w = finish4<MASK>(rule, s_lut, raw[k], len[k], tpos);  // columns >= B are never read
+                uint8_t *col = s_t + (4 * g) * STRIDE + sb;
+                col[0] = static_cast<uint8_t>(w);
+                col[STRIDE] = static_cast<uint8_t>(w >> 8);
+                col[2 * STRIDE] = static_cast<uint8_t>(w >> 16);
+                col[3 * STRIDE] = static_cast<uint8_t>(w >> 24);
+            }
         }
-    }
+    };
+    if constexpr (!HOIST) run(std::integral_constant<int, 2>{});  // the test inside every fetch
+    else if (rule.nonempty) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
     __syncthreads();
     uint8_t *out = static_cast<uint8_t *>(p.out);
     if (p.vw == 16) {
@@ -2230,7 +2248,9 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         }
         k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
         const dim3 vgrid(unsigned(tile_grid(k, k.ntt)));
-        if (rm < 2 || rm >= 4)
+        if ((rm < 2 || rm >= 4) && vgrid.x <= 2048u)  // about one round of workgroups: the latency form
+            hipLaunchKernelGGL((k_tokens_raw<false, false, kRawTB, kTT, true>), vgrid, dim3(kThreads), 0, s, k);
+        else if (rm < 2 || rm >= 4)
             hipLaunchKernelGGL((k_tokens_raw<false, false>), vgrid, dim3(kThreads), 0, s, k);
         else if (rm == 3 && k.foldable)
             hipLaunchKernelGGL((k_tokens_raw2<false, true>), vgrid, dim3(kThreads), 0, s, k);
