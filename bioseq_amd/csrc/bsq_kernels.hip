@@ -384,15 +384,22 @@ __global__ __launch_bounds__(kThreads) void k_onehot_tile(const KParams p) {
         const int32_t tl = wave * kRowsPerWave + r;
         const int64_t t = static_cast<int64_t>(t0) + tl;
         if (t >= p.P) break;  // wave-uniform
-        // 1. scatter the ones of this row into the wave's LDS image
+        // 1. scatter the ones of this row into the wave's LDS image.  All token reads first: the compiler cannot prove
+        // that the image does not alias the token tile, so a read placed after a write waits for it (four serial LDS
+        // round trips per row before round 2).  (Unpredicated writes with a spare slot for the lanes without a token
+        // were tried: one shared slot serialises those lanes, a slot per lane cost cfg4 int8 2 % -- ab_tile_scatter*.txt.)
         int32_t hot[kSeqPerLane];
+        uint32_t tks[kSeqPerLane];
+#pragma unroll
+        for (int q = 0; q < kSeqPerLane; ++q) tks[q] = s_tok[(lane + 64 * q) * kTokStride + tl];
 #pragma unroll
         for (int q = 0; q < kSeqPerLane; ++q) {
             const int32_t sb = lane + 64 * q;
-            const uint32_t tk = s_tok[sb * kTokStride + tl];
-            hot[q] = (tk != kNone) ? (sb * C + static_cast<int32_t>(tk)) * static_cast<int32_t>(sizeof(ST)) : -1;
-            if (hot[q] >= 0) *reinterpret_cast<ST *>(row + hot[q]) = one;
+            hot[q] = (tks[q] != kNone) ? (sb * C + static_cast<int32_t>(tks[q])) * static_cast<int32_t>(sizeof(ST)) : -1;
         }
+#pragma unroll
+        for (int q = 0; q < kSeqPerLane; ++q)
+            if (hot[q] >= 0) *reinterpret_cast<ST *>(row + hot[q]) = one;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // 2. stream the image to global memory
