@@ -1681,6 +1681,10 @@ bsq_status dispatch_onehot_tile(KParams &k, hipStream_t s) {
 // The gathered lines are re-used by the next positions from L2 (each XCD keeps to its own chunk
 // columns when the row pitch is a multiple of 32 KiB), so HBM sees the characters about once.
 // Any shape / pitch / alignment; best when a row (C*sizeof(T) bytes) is >= ~32 bytes.
+// (Tried in round 2: the rounds of 64 rows of a small-row chunk batched 2 / 4 at a time -- all offsets in flight, then all
+// characters -- to pay the two dependent round trips once: slower everywhere but cfg3 (1000 x 256 DNA f32 6 -> 7 us,
+// 8192 x 1024 AMINO20 f32 0.10 -> 0.11 ms, profiles/r02/ab_owner_rounds.txt): the extra registers cost the occupancy
+// this kernel lives on.)
 // ------------------------------------------------------------------------------------------
 struct CParams {
     int8_t lut[256];
