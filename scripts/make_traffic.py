@@ -17,7 +17,7 @@ def short(name):
         if k in name:
             return k
     return None
-for w in ("cfg3", "cfg2", "cfg5", "cfg4f", "cfg4b", "cfg5aug", "cfg3bcl"):
+for w in ("cfg3", "cfg2", "cfg5", "cfg4f", "cfg4b", "cfg5aug", "cfg3bcl", "cfg2sf", "cfg1oh"):
     src = os.path.join(ROOT, "gpurun_out", "%s_%s" % (tag, w))
     sj = os.path.join(src, "summary.json")
     if not os.path.exists(sj):
