@@ -60,6 +60,26 @@ __device__ __forceinline__ void store_head_bytes(void *dst, const uint4 &v, uint
     if ((nbytes & 1u) && on) *d = static_cast<uint8_t>(w);
 }
 
+// The same with a LANE-VARYING byte count (0 .. 15, a multiple of the element size SZ; no branches, up to four
+// predicated stores).
+template <int SZ>
+__device__ __forceinline__ void store_head_bytes_var(void *dst, const uint4 &v, uint32_t nbytes) {
+    uint8_t *d = static_cast<uint8_t *>(dst);
+    uint64_t w = (static_cast<uint64_t>(v.y) << 32) | v.x;
+    const bool c8 = (nbytes & 8u) != 0, c4 = SZ <= 4 && (nbytes & 4u) != 0, c2 = SZ <= 2 && (nbytes & 2u) != 0,
+               c1 = SZ <= 1 && (nbytes & 1u) != 0;
+    if (c8) *reinterpret_cast<u64_unaligned *>(d) = w;
+    w = c8 ? ((static_cast<uint64_t>(v.w) << 32) | v.z) : w;
+    d += c8 ? 8 : 0;
+    if (c4) *reinterpret_cast<u32_unaligned *>(d) = static_cast<uint32_t>(w);
+    w = c4 ? (w >> 32) : w;
+    d += c4 ? 4 : 0;
+    if (c2) *reinterpret_cast<u16_unaligned *>(d) = static_cast<uint16_t>(w);
+    w = c2 ? (w >> 16) : w;
+    d += c2 ? 2 : 0;
+    if (c1) *d = static_cast<uint8_t>(w);
+}
+
 // floor(n / d) for n < 2^31 with the constants of div_constants() (round-up method: exact below 2^31).
 // (host + device: bsq_selftest_index_math() runs the very same code on the CPU)
 __host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t shift, uint32_t pow2) {

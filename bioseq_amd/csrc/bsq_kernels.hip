@@ -1095,6 +1095,7 @@ struct TParams {
     // without divisions: n / ppr for n < 2^31 is mulhi(n, magic) >> shift (pow2: n >> shift);
     // step_q / step_r = 64 / ppr and % ppr: row / piece advance between two stores of a lane
     uint32_t ppr, magic, shift, pow2, step_q, step_r;
+    uint32_t a0e, pmod;  // RG: (out mod 16) / sizeof(T) and P mod EPL -- where in its 16-byte line a row starts
     uint32_t magic_c, shift_c, pow2_c;  // the same for / C (one-hot mode: row -> sequence, channel)
 };
 
@@ -1141,14 +1142,19 @@ struct ChunkState {  // one 4-KiB chunk in flight: the lane's four 16-byte store
     int32_t t0[4], L[4];
     uint32_t chan[4];
     int64_t row[4];   // RG: row of the lane's piece
+    int32_t cnt[4];   // RG: elements of the piece (EPL, or fewer for the head / tail piece of a row)
     int64_t start[4], stop[4];
     UBytes<EPL> cw[4], mw[4];
     bool slow[4];
 };
 
-// RG ("ragged"): any P and any element-aligned output.  Pieces are counted per row, so a lane's elements always lie in
-// one row; piece m of row r goes to out + (r * P + m * EPL) * sizeof(T) with an unaligned 16-byte store, the partial
-// last piece of a row (P % EPL elements) with 8 / 4 / 2 / 1-byte stores (see k_tokens_bp8, bsq_tokens8.hip).
+// RG ("ragged"): any P and any element-aligned output.  Pieces are counted per ROW, so a lane's elements always lie in
+// one row, and they are cut at the 16-byte lines of the OUTPUT: slot 0 of a row is its head (the h elements up to the
+// first 16-byte boundary, h = 0 .. EPL - 1 depending on where the row starts), slots 1 .. are whole aligned 16-byte
+// pieces, the last one the tail; ceil(P / EPL) + 1 slots per row, at most one of them empty.  Whole pieces are the same
+// aligned nt stores as in the plain form; heads and tails go out as 8 / 4 / 2 / 1-byte stores.  (A first version kept the
+// pieces row-relative and stored them with unaligned 16-byte stores: 4-byte aligned dwordx4 stores cost 45-55 % --
+// int32 65536 x 1001 63 us against 43 us aligned, profiles/r02/cliff_lab4.txt.)
 template <typename T, bool NT, bool HOT, int NCH, bool RG = false>
 __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     __shared__ __align__(16) uint8_t s_lut4[4][256];
@@ -1207,6 +1213,16 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
             c.t0[u] = static_cast<int32_t>(tu * EPL);
             c.row[u] = b;
             c.live[u] = b < nrows;
+            if constexpr (RG) {
+                // the row starts `sm` elements into a 16-byte line of the output: head = the elements up to the next line
+                const uint32_t sm = (p.a0e + (static_cast<uint32_t>(b) & (EPL - 1)) * p.pmod) & (EPL - 1);
+                const int32_t h = static_cast<int32_t>((EPL - sm) & (EPL - 1));
+                const int32_t t0 = tu == 0 ? 0 : h + static_cast<int32_t>(tu - 1) * EPL;
+                const int32_t left = static_cast<int32_t>(Pu) - t0;
+                c.t0[u] = t0;
+                c.cnt[u] = tu == 0 ? (h < left ? h : left) : (left > EPL ? EPL : left);
+                c.live[u] = c.live[u] && c.cnt[u] > 0;
+            }
             b = c.live[u] ? b : nrows - 1;
             c.chan[u] = 0;
             if constexpr (HOT) {  // row = sequence * C + channel
@@ -1347,9 +1363,10 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
                 store16<NT>(p.out + c.lo + u * 1024 + lane * 16, o);
             } else {
                 uint8_t *dst = p.out + (c.row[u] * p.P + c.t0[u]) * SZ;
-                const uint32_t ne = Pu - static_cast<uint32_t>(c.t0[u]);  // elements of the row from this piece on
-                if (ne >= EPL) store16_unaligned<NT>(dst, o);
-                else store_head_bytes(dst, o, (Pu % EPL) * SZ, true);
+                // (skipping the partial stores when no lane of the wave holds a head / tail -- a ballot -- measured 2-7 %
+                // slower: profiles/r02/cliff_lab5.txt vs cliff_lab6.txt)
+                if (c.cnt[u] == EPL) store16<NT>(dst, o);  // a whole piece: 16-byte aligned by construction
+                else store_head_bytes_var<SZ>(dst, o, static_cast<uint32_t>(c.cnt[u]) * SZ);
             }
         }
     };
@@ -2018,7 +2035,9 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     constexpr uint32_t EPL = 16u / uint32_t(sizeof(T));
     const bool ragged = k.P % EPL != 0 || reinterpret_cast<uintptr_t>(k.out) % 16 != 0;
     c.total = k.B * k.P * int64_t(sizeof(T)) * (HOT ? k.C : 1);
-    c.ppr = uint32_t((k.P + EPL - 1) / EPL);
+    c.ppr = uint32_t((k.P + EPL - 1) / EPL) + (ragged ? 1u : 0u);  // ragged: + the head slot
+    c.a0e = uint32_t(reinterpret_cast<uintptr_t>(k.out) % 16) / uint32_t(sizeof(T));
+    c.pmod = uint32_t(k.P % EPL);
     c.nchunks = (k.B * (HOT ? int64_t(k.C) : 1) * int64_t(c.ppr) + kChunk / 16 - 1) / (kChunk / 16);  // 256 pieces per wave
     c.bos = k.bos;
     c.bos_id = uint32_t(k.bos_id);
