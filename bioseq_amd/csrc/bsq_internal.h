@@ -24,7 +24,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokenize_nch  4: software-pipelined four chunks per wave in k_tokenize_chunks (experiments: slower than 1)
 //   tile_group    G > 1: XCD-aware tile order in groups of 8 x G sequence tiles (G = 16..64: +1 % on cfg4 int8; >= 128 loses
 //                 the L2 reuse: cfg4 f32 0.69 -> 0.90 ms at 512; profiles/r02/tile_lab3.txt)
-//   bcl_path      channels-first one-hot: 0 automatic (two-pass k_tokens_bp8<raw> + k_expand_bcl for unmasked outputs >= 256 MB),
+//   bcl_path      channels-first one-hot: 0 automatic (two-pass k_tokens_bp8<raw> + k_expand_bcl for outputs >= 256 MB),
 //                 1 never two-pass, 2 two-pass whenever it applies;  bcl_pad  occupancy cap of k_expand_bcl (0: 3 workgroups per CU)
 //   raw_mode      2 / 3: k_tokens_raw2 (4 x 4 byte transpose in registers via v_permlane32/16_swap; LDS / register
 //                 alphabet table) instead of k_tokens_raw; measured 7-15 % slower (profiles/r02/raw_lab.txt);
@@ -64,6 +64,6 @@ std::mutex &workspace_mutex();
 bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out);
 // raw = false: token VALUES (batch_tokenize); raw = true: ids with BSQ_NO_TOKEN (255) where a one-hot row is all zero
 bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
-                             void *out, hipStream_t stream, bool raw = false);
+                             void *out, hipStream_t stream, bool raw = false, const uint8_t *mask = nullptr);
 
 }  // namespace bsq_internal

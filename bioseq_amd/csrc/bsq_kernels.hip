@@ -181,7 +181,9 @@ __device__ __forceinline__ uint32_t load_clamped(global_u32_ptr base, uint32_t o
 // `start` = offsets[b] - rule.off0 (window-relative), tpos = first of the four positions.
 // CHECK = false: the caller has hoisted the (workgroup-uniform) `nonempty` test out of its loop -- inside it, the
 // branch keeps the compiler from batching the span reads and the loads of several fetches.
-template <bool MASK = true, bool CHECK = true>
+// MASK: 0 no mask; 1 test p.mask_al at run time (the tiled kernels serve both cases); 2 the caller knows there is one
+// (like CHECK, the wave-uniform test inside the fetch keeps the compiler from batching the loads of several fetches).
+template <int MASK = 1, bool CHECK = true>
 __device__ __forceinline__ Raw4 fetch4(const TokenRule p, uint32_t start, int32_t tpos) {
     if (CHECK && !p.nonempty) return Raw4{0, 0, ~0u, ~0u, 0};  // wave-uniform: nothing to read
     const uint32_t j = start + static_cast<uint32_t>(tpos - p.bos);  // may be "-1" (BOS position of the first sequence)
@@ -192,7 +194,7 @@ __device__ __forceinline__ Raw4 fetch4(const TokenRule p, uint32_t start, int32_
     r.a = load_clamped(p.chars_al, w0, p.last);
     r.b = load_clamped(p.chars_al, w0 + 4u, p.last);
     r.ma = r.mb = 0xFFFFFFFFu;
-    if (MASK && p.mask_al) {  // wave-uniform
+    if (MASK == 2 || (MASK == 1 && p.mask_al)) {  // wave-uniform
         const uint32_t relm = j + p.mis_m;
         const uint32_t m0 = relm & ~3u;
         r.ma = load_clamped(p.mask_al, m0, p.last_m);
@@ -205,14 +207,14 @@ __device__ __forceinline__ Raw4 fetch4(const TokenRule p, uint32_t start, int32_
 // Tokens of positions tpos..tpos+3 from the fetched words: four LUT lookups packed into one word, then
 // mask / PAD / EOS / BOS applied to the packed word.  Bytes fetched from outside [0, L) are garbage but
 // every such position is overwritten by the rules below.
-template <bool MASK = true>
+template <int MASK = 1>
 __device__ __forceinline__ uint32_t finish4(const TokenRule p, const uint8_t *s_lut, const Raw4 r, int32_t L,
                                             int32_t tpos) {
     const int32_t j0 = tpos - p.bos;
     const uint32_t cw = __builtin_amdgcn_alignbyte(r.b, r.a, r.sh & 3u);
     uint32_t w = static_cast<uint32_t>(s_lut[cw & 0xFFu]) | (static_cast<uint32_t>(s_lut[(cw >> 8) & 0xFFu]) << 8) |
                  (static_cast<uint32_t>(s_lut[(cw >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(s_lut[cw >> 24]) << 24);
-    if (MASK && p.mask_al) {
+    if (MASK == 2 || (MASK == 1 && p.mask_al)) {
         const uint32_t mw = __builtin_amdgcn_alignbyte(r.mb, r.ma, (r.sh >> 8) & 3u);
         uint32_t z = (mw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;  // exact zero-byte detection:
         z = ~(z | mw | 0x7F7F7F7Fu);                     // 0x80 in every byte of mw that is zero
@@ -316,7 +318,7 @@ __device__ __forceinline__ void build_token_tile(const KParams &p, int64_t b0, i
                 const int sb = (tid >> 4) + 16 * (i0 + k);
                 const SeqSpan sp = s_span[sb];
                 len[k] = sp.len;
-                raw[k] = decltype(nonempty)::value ? fetch4<true, false>(rule, sp.start, t0 + 4 * g) : Raw4{0, 0, ~0u, ~0u, 0};
+                raw[k] = decltype(nonempty)::value ? fetch4<1, false>(rule, sp.start, t0 + 4 * g) : Raw4{0, 0, ~0u, ~0u, 0};
             }
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
@@ -847,13 +849,13 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
                 const SeqSpan sp = s_span[sb];
                 len[k] = sp.len;
                 if constexpr (M == 0) raw[k] = Raw4{0, 0, ~0u, ~0u, 0};
-                else if constexpr (M == 1) raw[k] = fetch4<MASK, false>(rule, sp.start, tpos);
-                else raw[k] = fetch4<MASK, true>(rule, sp.start, tpos);
+                else if constexpr (M == 1) raw[k] = fetch4<MASK ? 2 : 0, false>(rule, sp.start, tpos);
+                else raw[k] = fetch4<MASK ? 2 : 0, true>(rule, sp.start, tpos);
             }
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 const int sb = sb0 + SPP * (i0 + k);
-                const uint32_t w = finish4<MASK>(rule, s_lut, raw[k], len[k], tpos);  // columns >= B are never read
+                const uint32_t w = finish4<MASK ? 2 : 0>(rule, s_lut, raw[k], len[k], tpos);  // columns >= B are never read
                 uint8_t *col = s_t + (4 * g) * STRIDE + sb;
                 col[0] = static_cast<uint8_t>(w);
                 col[STRIDE] = static_cast<uint8_t>(w >> 8);
@@ -976,7 +978,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw2(const KParams p) {
             const int sb = 4 * (wave + 4 * (i0 + k)) + sq;
             const SeqSpan sp = s_span[sb];
             len[k] = sp.len;
-            raw[k] = fetch4<false>(rule, sp.start, tpos);
+            raw[k] = fetch4<0>(rule, sp.start, tpos);
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
@@ -992,7 +994,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw2(const KParams p) {
                 }
                 w = rules4(rule, w, len[k], tpos);
             } else {
-                w = finish4<false>(rule, s_lut, raw[k], len[k], tpos);
+                w = finish4<0>(rule, s_lut, raw[k], len[k], tpos);
             }
             // 4 x 4 byte transpose over the lanes l, l + 16, l + 32, l + 48
             auto a = __builtin_amdgcn_permlane32_swap(w, w, false, false);
@@ -2325,18 +2327,18 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     k.one_bits = one_bits_of(t);
-    // Two-pass form (raw (B,P) ids, then k_expand_bcl) for large unmasked outputs; knob "bcl_path": 0 automatic,
+    // Two-pass form (raw (B,P) ids, then k_expand_bcl) for large outputs, masked or not; knob "bcl_path": 0 automatic,
     // 1 never, 2 whenever it applies.
     const int bcl_path = bsq_internal::tuning("bcl_path");
     const int64_t total_bytes = B * int64_t(k.C) * P * int64_t(sz);
-    if (!mask_or_null && bcl_path != 1 && (bcl_path == 2 || total_bytes >= (int64_t(256) << 20)) && k.C <= 250 &&
+    if (bcl_path != 1 && (bcl_path == 2 || total_bytes >= (int64_t(256) << 20)) && k.C <= 250 &&
         reinterpret_cast<uintptr_t>(out) % 16 == 0 && P % 16 == 0 && B * int64_t(k.C) * P < (int64_t(1) << 51) &&
         bsq_internal::tokens_bp8_applicable(d, B, P, out)) {
         std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());  // see bsq_onehot_device
         void *ws = nullptr;
         bsq_status wst = bsq_internal::workspace_acquire(size_t(B) * size_t(P), s, &ws);
         if (wst != BSQ_OK) return wst;
-        wst = bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, ws, s, true);
+        wst = bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, ws, s, true, mask_or_null);
         if (wst == BSQ_OK) {
             const uint8_t *tk = static_cast<const uint8_t *>(ws);
             switch (sz) {

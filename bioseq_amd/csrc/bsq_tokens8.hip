@@ -33,6 +33,7 @@ struct T8Params {
     int8_t lut[256];   // LK == 0 only
     uint32_t tab[8];   // LK == 1: token value of letter (c & 31), unmapped = 0 (the memset value of tokenize.h:427)
     const uint8_t *chars;
+    const uint8_t *mask;   // MASK: one byte per character, 0 = the position gets none_v (one-hot: an all-zero row)
     const int64_t *offsets;
     uint8_t *out;
     int64_t total;     // output bytes = B * P
@@ -83,6 +84,7 @@ struct CharStage {  // stage B: the lane's four 16-byte character vectors in fli
     int64_t lo, bc;
     uint32_t tc;
     u32x4u cw[4];
+    u32x4u mw[4];   // MASK: the mask bytes of the same characters
     int32_t j0[4], L[4];
     uint32_t q[4];  // RG: row of the lane's piece relative to bc
     bool live[4], slow[4];
@@ -93,7 +95,10 @@ struct CharStage {  // stage B: the lane's four 16-byte character vectors in fli
 // inside one row: piece m of row b goes to out + b * P + 16 m with an unaligned 16-byte store, the partial piece with
 // 8 / 4 / 2 / 1-byte stores.  With P % 16 == 0 and a 16-byte aligned output this is the same mapping as RG = false.
 
-template <bool NT, int LK, int ABL, bool RG = false>
+// MASK (raw-id mode of the channels-first one-hot only): p.mask holds one byte per character; a character whose mask byte
+// is 0 gives none_v (tokenize.h:346-348: the masked position's one-hot row stays zero).  Four more 16-byte loads per
+// lane, one zero-byte test per word.
+template <bool NT, int LK, int ABL, bool RG = false, bool MASK = false>
 __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
     __shared__ __align__(16) uint4 s_rule[4][2][18];
     __shared__ __align__(16) uint8_t s_lut4[LK == 0 ? 4 : 1][256];
@@ -237,9 +242,17 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
             const uint8_t *cbase = p.chars + (off0 + lo_b);  // wave-uniform, inside the buffer
 #pragma unroll
             for (int u = 0; u < 4; ++u) b.cw[u] = *reinterpret_cast<const u32x4u *>(cbase + uoff[u]);
+            if constexpr (MASK) {
+                const uint8_t *mbase = p.mask + (off0 + lo_b);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b.mw[u] = *reinterpret_cast<const u32x4u *>(mbase + uoff[u]);
+            }
         } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) b.cw[u] = u32x4u{0x41434447u, 0x61636474u, 0x4B4C4D4Eu, 0x50515253u};
+            for (int u = 0; u < 4; ++u) {
+                b.cw[u] = u32x4u{0x41434447u, 0x61636474u, 0x4B4C4D4Eu, 0x50515253u};
+                if constexpr (MASK) b.mw[u] = u32x4u{~0u, ~0u, ~0u, ~0u};
+            }
         }
         return b;
     };
@@ -254,12 +267,16 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
                 const uint32_t tl = b.tc + static_cast<uint32_t>(u * 64 + lane);
                 const int64_t row = b.bc + div_p(tl);
                 const int64_t start = p.offsets[row];
-                uint32_t w[4] = {0, 0, 0, 0};
+                uint32_t w[4] = {0, 0, 0, 0}, mk[4] = {~0u, ~0u, ~0u, ~0u};
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i)
-                    if (b.j0[u] + i >= 0 && b.j0[u] + i < b.L[u])
+                    if (b.j0[u] + i >= 0 && b.j0[u] + i < b.L[u]) {
                         w[i >> 2] |= static_cast<uint32_t>(p.chars[start + b.j0[u] + i]) << (8 * (i & 3));
+                        if constexpr (MASK)
+                            if (p.mask[start + b.j0[u] + i] == 0) mk[i >> 2] &= ~(0xFFu << (8 * (i & 3)));
+                    }
                 b.cw[u] = u32x4u{w[0], w[1], w[2], w[3]};
+                if constexpr (MASK) b.mw[u] = u32x4u{mk[0], mk[1], mk[2], mk[3]};
             }
         }
 #pragma unroll
@@ -295,6 +312,16 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
                            (static_cast<uint32_t>(lut[(x >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(lut[x >> 24]) << 24);
                 }
             }
+            if constexpr (MASK) {  // masked characters -> none_v (before the position rules: those overwrite what lies behind L)
+                const uint32_t mi[4] = {b.mw[u].x, b.mw[u].y, b.mw[u].z, b.mw[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t z = (mi[q] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;  // exact zero-byte detection
+                    z = ~(z | mi[q] | 0x7F7F7F7Fu);                     // 0x80 in every byte of mi that is zero
+                    const uint32_t zm = (z >> 7) * 0xFFu;
+                    w[q] = (w[q] & ~zm) | ((p.none_v * 0x01010101u) & zm);
+                }
+            }
             uint4 o;
             o.x = (w[0] & keep.x) | cst.x;
             o.y = (w[1] & keep.y) | cst.y;
@@ -328,7 +355,9 @@ void launch_variant(const T8Params &c, dim3 grid, size_t pad, hipStream_t s) {
     case 4: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 4>), grid, dim3(kThreads), pad, s, c); break;
     case 5: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 5>), grid, dim3(kThreads), pad, s, c); break;
     default:
-        if (c.P % 16 != 0 || reinterpret_cast<uintptr_t>(c.out) % 16 != 0)
+        if (c.mask)  // raw ids for the masked channels-first one-hot (aligned shapes only: see launch_tokens_bp8)
+            hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0, false, true>), grid, dim3(kThreads), pad, s, c);
+        else if (c.P % 16 != 0 || reinterpret_cast<uintptr_t>(c.out) % 16 != 0)
             hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0, true>), grid, dim3(kThreads), pad, s, c);
         else
             hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0>), grid, dim3(kThreads), pad, s, c);
@@ -366,8 +395,11 @@ bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
 }
 
 bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
-                             void *out, hipStream_t s, bool raw) {
+                             void *out, hipStream_t s, bool raw, const uint8_t *mask) {
+    if (mask && (!raw || P % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0))
+        return set_error(BSQ_ERR_INVALID_ARG, "k_tokens_bp8: a mask needs raw-id mode and an aligned shape");
     T8Params c;
+    c.mask = mask;
     for (int i = 0; i < 256; ++i) c.lut[i] = d->lut[i];
     c.none_v = raw ? 0xFFu : 0u;  // raw: ids with BSQ_NO_TOKEN where the one-hot row is all zero (plain stores: re-read at once)
     const bool foldable = fold_table(d->lut, c.tab, c.none_v);

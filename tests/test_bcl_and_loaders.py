@@ -78,7 +78,8 @@ def test_dataset_batches_match_per_item_reference_semantics(gpu, bsq, oracle, tm
 def test_bcl_two_pass_form_equals_single_pass_and_oracle(gpu, bsq, oracle, key, flags):
     """The two-pass channels-first path (raw (B,P) ids from k_tokens_bp8 + k_expand_bcl; automatic for outputs >= 256 MB,
     forced here with the knob `bcl_path`) against the single-pass kernel and the transposed oracle: every element type,
-    padlens of 128 and more that are multiples of 16, dirty input (every kind of unmapped byte -> all-zero column)."""
+    padlens of 128 and more that are multiples of 16, dirty input (every kind of unmapped byte -> all-zero column), with
+    and without a mask."""
     import torch
     from bioseq_amd import capi, synth
     lib = capi.load()
@@ -86,14 +87,17 @@ def test_bcl_two_pass_form_equals_single_pass_and_oracle(gpu, bsq, oracle, key, 
     for B, P in ((300, 128), (77, 272), (5, 1024), (1, 144)):
         chars, offs = synth.synth_packed(B * 3 + P, B, 0, P - 2, synth.DIRTY)
         dch, dof = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+        mask = (np.random.default_rng(B + P).random(chars.size) < 0.7).astype(np.uint8)
+        dm = torch.from_numpy(mask).to(gpu)
         for d in "bhifd":
-            exp = np.ascontiguousarray(ora.onehot_packed(chars, offs, P, d).transpose(1, 2, 0))
-            got = {}
-            for path in (1, 2):
-                capi.check(lib.bsq_tuning_set(b"bcl_path", path))
-                try:
-                    got[path] = tok.onehot_packed(dch, dof, P, d, layout="bcl").cpu().numpy()
-                finally:
-                    capi.check(lib.bsq_tuning_set(b"bcl_path", 0))
-            assert got[2].tobytes() == exp.tobytes(), (B, P, d)
-            assert got[1].tobytes() == exp.tobytes(), (B, P, d)
+            for m, mdev in ((None, None), (mask, dm)):  # masked: k_tokens_bp8<.., MASK> in raw-id mode
+                exp = np.ascontiguousarray(ora.onehot_packed(chars, offs, P, d, mask=m).transpose(1, 2, 0))
+                got = {}
+                for path in (1, 2):
+                    capi.check(lib.bsq_tuning_set(b"bcl_path", path))
+                    try:
+                        got[path] = tok.onehot_packed(dch, dof, P, d, mask=mdev, layout="bcl").cpu().numpy()
+                    finally:
+                        capi.check(lib.bsq_tuning_set(b"bcl_path", 0))
+                assert got[2].tobytes() == exp.tobytes(), (B, P, d, m is not None)
+                assert got[1].tobytes() == exp.tobytes(), (B, P, d, m is not None)
