@@ -40,7 +40,9 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokens8_lookup  0 automatic, 1 LDS byte table, 2 register table (v_perm_b32)
 //   tokens8_pad   unused dynamic LDS of k_tokens_bp8;  tokens8_abl  ablation experiments (diagnostic)
 //   onehot_tb     0: automatic, else force 64 / 128 / 256 sequences per tile of k_onehot_tile
-//   tile_order    0: automatic (XCD-aware), 1: position-tile index fastest, 2: XCD-aware, 3: sequence-tile index fastest
+//   tile_order    0: automatic (XCD-aware), 1: position-tile index fastest, 2: XCD-aware, 3: sequence-tile index fastest,
+//                 4: every XCD walks its own contiguous range of sequence tiles (automatic for (P,B) tokens of 2- / 4-byte
+//                 elements whose rows are not 64-byte aligned)
 //   expand_mode   0 / 1: k_expand_chunks, 2: k_expand_small (dword token loads; an experiment that lost), 9: the same
 //                 without token loads (ablation)
 //   fill_mode, fill_pad   access pattern / occupancy of bsq_fill_device (write-bandwidth yardsticks)

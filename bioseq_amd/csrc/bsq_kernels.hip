@@ -71,7 +71,8 @@ struct KParams {
     int32_t fill_id;  // token of positions >= L+bos+eos: pad id, or kNone without padchar
     int32_t ntb;      // number of sequence tiles
     int32_t aligned;  // 1: every output row segment is 16-byte aligned -> vector stores
-    int32_t vw;       // k_tokens_raw: bytes per store that the alignment of its output rows allows (16, 8, 4 or 1)
+    int32_t vw;       // k_tokens_raw: bytes per store that the alignment of its output rows allows (16, 8, 4 or 1);
+                      // k_tokenize_tile: 2 = rows only element-aligned, segments cut at the output's 16-byte lines
     int32_t ntt;      // number of position tiles
     int32_t order;    // 0: sequence-tile index fastest over blockIdx, 1: position-tile index fastest, 2: XCD-aware
     int32_t group;    // order 2: sequence tiles per XCD and group (see tile_of_block)
@@ -96,6 +97,15 @@ __device__ __forceinline__ void tile_of_block(const KParams &p, int32_t &tb, int
         tt = static_cast<int32_t>(r / (8u * G));
         const uint32_t q = r % (8u * G);
         tb = static_cast<int32_t>((g * G + (q >> 3)) * 8u + (q & 7u));
+    } else if (p.order == 4) {
+        // every XCD walks its own contiguous range of sequence tiles (position tile by position tile): the row segments
+        // of neighbouring sequence tiles are written through the SAME L2, close in time -- when the rows are not
+        // 64-byte aligned, the memory sectors that two tiles share are merged there instead of being written twice,
+        // partially, from two XCDs.
+        const uint32_t per = (static_cast<uint32_t>(p.ntb) + 7u) / 8u;
+        const uint32_t xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        tb = static_cast<int32_t>(xcd * per + i % per);
+        tt = static_cast<int32_t>(i / per);
     } else if (p.order == 0) {
         tb = static_cast<int32_t>(blockIdx.x % static_cast<uint32_t>(p.ntb));
         tt = static_cast<int32_t>(blockIdx.x / static_cast<uint32_t>(p.ntb));
@@ -472,6 +482,40 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_tile(const KParams p) {
     constexpr int EPC = 16 / static_cast<int>(sizeof(T));  // elements per 16-byte chunk
     constexpr int CPR = TB / EPC;                          // chunks per row segment
     T *out = static_cast<T *>(p.out);
+    if (p.vw == 2) {
+        // Rows that are only element-aligned (odd batch sizes, offset outputs): the row segment of the tile is cut at the
+        // 16-byte lines of the OUTPUT -- slot 0 = the head (the 0 .. EPC-1 elements up to the first line), then whole
+        // aligned pieces (nt stores as in the aligned case), the last one the tail; heads and tails as element stores.
+        const int64_t nb64 = p.B - b0;
+        const int32_t nb = nb64 < TB ? static_cast<int32_t>(nb64) : TB;  // sequences of the tile
+        const uint32_t a0e = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p.out) & 15u) / static_cast<uint32_t>(sizeof(T));
+        for (int f = tid; f < kTT * (CPR + 1); f += kThreads) {
+            const int32_t tl = f / (CPR + 1), slot = f % (CPR + 1);
+            const int64_t t = static_cast<int64_t>(t0) + tl;
+            if (t >= p.P) continue;
+            const int64_t e0 = t * p.B + b0;  // element index of the segment's first element
+            const int32_t h = static_cast<int32_t>((EPC - ((a0e + static_cast<uint32_t>(e0)) & (EPC - 1))) & (EPC - 1));
+            const int32_t sb0 = slot == 0 ? 0 : h + (slot - 1) * EPC;
+            const int32_t left = nb - sb0;
+            const int32_t cnt = slot == 0 ? (h < left ? h : left) : (left > EPC ? EPC : left);
+            if (cnt <= 0) continue;
+            alignas(16) T vals[EPC];
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) {
+                const int32_t sb = sb0 + i < TB ? sb0 + i : TB - 1;
+                vals[i] = token_value<T>(s_tok[sb * kTokStride + tl]);
+            }
+            T *dst = out + e0 + sb0;
+            if (cnt == EPC) {
+                store16<true>(dst, *reinterpret_cast<const uint4 *>(vals));
+            } else {
+#pragma unroll
+                for (int i = 0; i < EPC - 1; ++i)
+                    if (i < cnt) dst[i] = vals[i];
+            }
+        }
+        return;
+    }
     for (int f = tid; f < kTT * CPR; f += kThreads) {
         const int32_t tl = f / CPR, q = f % CPR;
         const int64_t t = static_cast<int64_t>(t0) + tl;
@@ -1570,6 +1614,7 @@ __global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offs
 // Blocks of a tiled launch (see tile_of_block).
 int64_t tile_grid(const KParams &k, int64_t ntt) {
     const int64_t unit = 8 * int64_t(k.group);
+    if (k.order == 4) return (int64_t(k.ntb) + 7) / 8 * 8 * ntt;
     return (k.order == 2 ? (int64_t(k.ntb) + unit - 1) / unit * unit : int64_t(k.ntb)) * ntt;
 }
 
@@ -1610,7 +1655,7 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     // XCD-aware placement fetches the characters once instead of ~3 times on the 1M x 160 DNA batch (FETCH_SIZE 234 ->
     // 78 MB; k_tokens_raw 97 -> 66 us, k_onehot_tile 258 -> 233 us: profiles/r02/order_lab.txt).
     const int order_knob = bsq_internal::tuning("tile_order");
-    k.order = order_knob == 1 ? 1 : (order_knob == 3 ? 0 : 2);
+    k.order = order_knob == 1 ? 1 : (order_knob == 3 ? 0 : (order_knob == 4 ? 4 : 2));
     const int group_knob = bsq_internal::tuning("tile_group");
     k.group = group_knob > 0 && group_knob <= 4096 ? group_knob : 1;
     if (k.order == 2 && (B / 64 + 8 * int64_t(k.group)) * int64_t(k.ntt) >= (int64_t(1) << 31)) k.order = 0;  // keep the rounded-up grid in 32 bits
@@ -2017,7 +2062,7 @@ bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
     // automatic tile order: sequence-tile index fastest.  This kernel writes TB * sizeof(T) = 256..512-byte row segments;
     // with the XCD-aware order their neighbours in a row are written far apart in time and the (P,B) int32 / f32 matrix of
     // the cfg2 batch takes 62 us instead of 48 (profiles/r02/tokens_dtypes.txt); its character re-reads are small beside that.
-    if (bsq_internal::tuning("tile_order") == 0) k.order = 0;
+    if (bsq_internal::tuning("tile_order") == 0 && k.order != 4) k.order = 0;  // (4: chosen by the caller for unaligned rows)
     k.ntb = int32_t((k.B + TB - 1) / TB);
     const int64_t ntt = (k.P + kTT - 1) / kTT;
     const size_t smem = tile_fixed_bytes<TB>();
@@ -2267,6 +2312,7 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         return check_launch("k_tokenize_rows");
     }
     k.aligned = (addr % 16 == 0) && ((B * int64_t(sz)) % 16 == 0);
+    k.vw = (!k.aligned && addr % sz == 0 && bsq_internal::tuning("tokenize_path") != 2) ? 2 : 1;  // k_tokenize_tile: 2 = line-aligned slots
     if (t == BSQ_I8 && bsq_internal::tuning("tokenize_path") != 1) {  // int8 (P,B): the raw-token kernel in value mode
         const uint64_t al = uint64_t(addr) | uint64_t(B);  // every row starts at out + t * B
         k.vw = al % 16 == 0 ? 16 : (al % 8 == 0 ? 8 : (al % 4 == 0 ? 4 : 1));
@@ -2297,8 +2343,12 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     // when the rows are not 64-byte aligned (B * sz % 64 != 0) neighbouring tiles share memory sectors, and longer
     // segments share fewer of them: 65000 x 1024 int32 99 -> 82 us, int16 83 -> 55 us with 256 sequences
     // (profiles/r02/tile_tb_lab.txt); aligned batches and small ones keep the short tiles (more workgroups).
-    const bool shared_sectors = (B * int64_t(sz)) % 64 != 0 && B >= 16384;
+    // With such rows the 2- / 4-byte types also take tile order 4 (every XCD walks its own contiguous range of sequence
+    // tiles, so the sectors two tiles share are merged in ONE L2): int16 55 -> 42 us, int32 78 -> 69 us on 65000 x 1024
+    // (profiles/r02/tile_tb_lab2.txt).  8-byte elements gain from neither (151-161 us whatever the tile).
+    const bool shared_sectors = (B * int64_t(sz)) % 64 != 0 && B >= 16384 && sz < 8;
     const int tbk = shared_sectors && bsq_internal::tuning("tokenize_tb") == 0 ? 256 : bsq_internal::tuning("tokenize_tb");
+    if (shared_sectors && bsq_internal::tuning("tile_order") == 0) k.order = 4;
 #define BSQ_TILE(T, AUTO)                                                        \
     switch (tbk ? tbk : AUTO) {                                                  \
     case 64: return launch_tokenize_tile<T, 64>(k, s);                           \

@@ -26,8 +26,8 @@ for key, B, P in (("AMINO20", 65536, 1024), ("AMINO20", 65000, 1024), ("AMINO20"
         dt = ctypes.c_int(0); capi.check(lib.bsq_dtype_from_destchar(dc.encode(), ctypes.byref(dt)))
         fn = lambda: capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 0, dt, buf.data_ptr(), None))
         row = []
-        for order in (0, 2):
-            for tb in (64, 128, 256):
+        for order in (0, 4):
+            for tb in (64, 256):
                 capi.check(lib.bsq_tuning_set(b"tile_order", order)); capi.check(lib.bsq_tuning_set(b"tokenize_tb", tb))
                 row.append("o%d tb%d %.0f" % (order, tb, timeit(fn) * 1e3))
         print("%-7s B=%6d P=%4d %s | %s us" % (key, B, P, dc, " | ".join(row)), flush=True)

@@ -93,3 +93,38 @@ def test_two_pass_onehot_with_either_scratch_tile(gpu, oracle, raw_mode):
             assert out.cpu().numpy().tobytes() == want.tobytes(), key
     finally:
         capi.check(lib.bsq_tuning_set(b"onehot_path", 0))
+
+
+@pytest.mark.parametrize("dc", list("hilfd"))
+@pytest.mark.parametrize("B,P", [(1, 5), (7, 64), (65, 100), (1001, 33), (4099, 70), (20001, 24), (4096, 64)])
+def test_wider_types_any_batch_size_any_alignment(gpu, oracle, dc, B, P):
+    """(P,B) token matrices of 2- / 4- / 8-byte elements (k_tokenize_tile) when the rows are only element-aligned -- odd
+    batch sizes, outputs offset by a few elements: segments cut at the output's 16-byte lines -- and in the round-1 form
+    (knob tokenize_path = 2); every sequences-per-tile setting; nothing outside the matrix is written."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    chars, offs = nasty_batch(B * 5 + P, B, 0, P - 2)
+    dch = torch.from_numpy(np.concatenate([chars, np.zeros(1, np.uint8)])).to(gpu)
+    dof = torch.from_numpy(offs).to(gpu)
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(dc.encode(), ctypes.byref(dt)))
+    sz = lib.bsq_dtype_size(dt)
+    try:
+        for key, flags in (("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1))):
+            want = oracle.OracleTokenizer(key, *flags).tokenize_packed(chars, offs, P, dc, False)
+            desc = capi.make_desc(key, *flags)
+            for path, tb, shift in ((0, 0, 0), (0, 0, 1), (0, 64, 3), (0, 256, 1), (2, 0, 1), (0, 128, 2)):
+                capi.check(lib.bsq_tuning_set(b"tokenize_path", path))
+                capi.check(lib.bsq_tuning_set(b"tokenize_tb", tb))
+                buf = torch.full(((P * B + 24) * sz,), 0x5A, dtype=torch.uint8, device=gpu)
+                lo = shift * sz
+                capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 0, dt,
+                                                   buf.data_ptr() + lo, None))
+                torch.cuda.synchronize()
+                host = buf.cpu().numpy()
+                assert (host[:lo] == 0x5A).all() and (host[lo + P * B * sz:] == 0x5A).all(), "wrote outside the matrix"
+                assert host[lo:lo + P * B * sz].tobytes() == want.tobytes(), (key, flags, dc, path, tb, shift)
+    finally:
+        capi.check(lib.bsq_tuning_set(b"tokenize_path", 0))
+        capi.check(lib.bsq_tuning_set(b"tokenize_tb", 0))
