@@ -42,7 +42,8 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   onehot_tb     0: automatic, else force 64 / 128 / 256 sequences per tile of k_onehot_tile
 //   tile_order    0: automatic (XCD-aware), 1: position-tile index fastest, 2: XCD-aware, 3: sequence-tile index fastest,
 //                 4: every XCD walks its own contiguous range of sequence tiles (automatic for (P,B) tokens of 2- / 4-byte
-//                 elements whose rows are not 64-byte aligned)
+//                 elements whose rows are not 64-byte aligned), 5: as 4 with the position tiles of a sequence tile back to
+//                 back (automatic for the (P,B) int8 token matrix)
 //   expand_mode   0 / 1: k_expand_chunks, 2: k_expand_small (dword token loads; an experiment that lost), 9: the same
 //                 without token loads (ablation)
 //   fill_mode, fill_pad   access pattern / occupancy of bsq_fill_device (write-bandwidth yardsticks)

@@ -97,6 +97,12 @@ __device__ __forceinline__ void tile_of_block(const KParams &p, int32_t &tb, int
         tt = static_cast<int32_t>(r / (8u * G));
         const uint32_t q = r % (8u * G);
         tb = static_cast<int32_t>((g * G + (q >> 3)) * 8u + (q & 7u));
+    } else if (p.order == 5) {
+        // as 4, but all position tiles of a sequence tile back to back (the character lines they share stay in that L2)
+        const uint32_t per = (static_cast<uint32_t>(p.ntb) + 7u) / 8u;
+        const uint32_t xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        tb = static_cast<int32_t>(xcd * per + i / static_cast<uint32_t>(p.ntt));
+        tt = static_cast<int32_t>(i % static_cast<uint32_t>(p.ntt));
     } else if (p.order == 4) {
         // every XCD walks its own contiguous range of sequence tiles (position tile by position tile): the row segments
         // of neighbouring sequence tiles are written through the SAME L2, close in time -- when the rows are not
@@ -1614,7 +1620,7 @@ __global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offs
 // Blocks of a tiled launch (see tile_of_block).
 int64_t tile_grid(const KParams &k, int64_t ntt) {
     const int64_t unit = 8 * int64_t(k.group);
-    if (k.order == 4) return (int64_t(k.ntb) + 7) / 8 * 8 * ntt;
+    if (k.order == 4 || k.order == 5) return (int64_t(k.ntb) + 7) / 8 * 8 * ntt;
     return (k.order == 2 ? (int64_t(k.ntb) + unit - 1) / unit * unit : int64_t(k.ntb)) * ntt;
 }
 
@@ -1655,7 +1661,7 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     // XCD-aware placement fetches the characters once instead of ~3 times on the 1M x 160 DNA batch (FETCH_SIZE 234 ->
     // 78 MB; k_tokens_raw 97 -> 66 us, k_onehot_tile 258 -> 233 us: profiles/r02/order_lab.txt).
     const int order_knob = bsq_internal::tuning("tile_order");
-    k.order = order_knob == 1 ? 1 : (order_knob == 3 ? 0 : (order_knob == 4 ? 4 : 2));
+    k.order = order_knob == 1 ? 1 : (order_knob == 3 ? 0 : (order_knob == 4 ? 4 : (order_knob == 5 ? 5 : 2)));
     const int group_knob = bsq_internal::tuning("tile_group");
     k.group = group_knob > 0 && group_knob <= 4096 ? group_knob : 1;
     if (k.order == 2 && (B / 64 + 8 * int64_t(k.group)) * int64_t(k.ntt) >= (int64_t(1) << 31)) k.order = 0;  // keep the rounded-up grid in 32 bits
@@ -2316,6 +2322,10 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     if (t == BSQ_I8 && bsq_internal::tuning("tokenize_path") != 1) {  // int8 (P,B): the raw-token kernel in value mode
         const uint64_t al = uint64_t(addr) | uint64_t(B);  // every row starts at out + t * B
         k.vw = al % 16 == 0 ? 16 : (al % 8 == 0 ? 8 : (al % 4 == 0 ? 4 : 1));
+        // tile order 5 (XCD-contiguous ranges of sequence tiles, their position tiles back to back): the 256-byte row
+        // segments of neighbouring tiles meet in one L2 -- cfg5 43.0 -> 41.3 us, 100000 x 256 DNA 13.8 -> 12.7,
+        // 65000 x 1001 29.1 -> 27.3, cfg2 24.7 -> 24.0 (profiles/r02/seqfirst_orders2.txt)
+        if (bsq_internal::tuning("tile_order") == 0) k.order = 5;
         const int rm = bsq_internal::tuning("raw_mode");
         // knob "raw_mode": 0 automatic, 1 the 256 x 64 tile, 4 the wide 1024 x 16 tile, 2 / 3 the round-2 experiments
         const bool wide_ok = P <= (int64_t(1) << 20);  // 1024 sequences x padlen in 32-bit window offsets

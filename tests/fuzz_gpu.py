@@ -38,7 +38,7 @@ def run(budget=120.0, seed=1):
         capi.check(lib.bsq_tuning_set(b"onehot_path", path))
         capi.check(lib.bsq_tuning_set(b"tokenize_path", int(rng.integers(0, 3))))
         capi.check(lib.bsq_tuning_set(b"tokenize_tb", int(rng.choice([0, 64, 128, 256]))))
-        knobs = (int(rng.integers(0, 5)), int(rng.choice([0, 0, 1, 2])), int(rng.integers(0, 3)), int(rng.integers(0, 3)))
+        knobs = (int(rng.integers(0, 6)), int(rng.choice([0, 0, 1, 2])), int(rng.integers(0, 3)), int(rng.integers(0, 3)))
         capi.check(lib.bsq_tuning_set(b"tile_order", knobs[0]))
         capi.check(lib.bsq_tuning_set(b"expand_mode", knobs[1]))
         capi.check(lib.bsq_tuning_set(b"tokens8_lookup", knobs[2]))
