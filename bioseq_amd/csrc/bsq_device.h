@@ -14,7 +14,7 @@ constexpr int kChunk = 4096;       // the unit of the streaming kernels: one nat
 // nontemporal store: four scalar ones only stay `nt` if the compiler happens to merge them unchanged (it dropped
 // the flag for the 8-byte element types, which cost the f64 token matrix 40 % of its bandwidth).
 // (Write-through `sc1` stores were tried in round 2: a pure 64-128 MiB store stream runs 15-20 % faster with them,
-// every kernel that also reads runs the same or slower, multi-GB outputs much slower: profiles/r02/store_kinds.txt.)
+// every kernel that also reads runs the same or slower, multi-GB outputs much slower: profiles/r02/store_kinds_bench.txt, tokens8_lab4.txt.)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ void store16(void *dst, const uint4 &v) {
