@@ -2169,8 +2169,8 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool m
         //  2 two-pass   : the fastest streamer once the output is large -- 7.3-7.4 TB/s at 3 workgroups per CU
         //                 when rows are >= 64 B, 6-7 TB/s for smaller rows, any pitch; needs rows >= 16 B and an
         //                 output that amortises the token pass and the second launch;
-        //  3 chunk-owner: one launch, no scratch: ahead below ~4 GiB of output (2.7 GB: 0.383 vs 0.390 ms, 5.4 GB:
-        //                 0.757 vs 0.733) when a row is >= 48 B and its
+        //  3 chunk-owner: one launch, no scratch: ahead below ~1.5 GiB of output (round 1 measured it ahead up to 2.7 GB:
+        //                 0.383 vs 0.390 ms; 5.4 GB: 0.757 vs 0.733) when a row is >= 48 B and its
         //                 per-position gather set stays L2-resident, i.e. the pitch is a multiple of 32 KiB (each
         //                 XCD keeps to its own chunk columns) and B <= 128k, or B <= 16k whatever the pitch;
         //                 Small batches (profiles/r02/path_small.txt): the tile kernel has a ~15 us floor, the
@@ -2182,7 +2182,9 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool m
         const bool pinned_columns = pitch % (8 * kChunk) == 0;
         const bool owner_big = rowbytes >= 48 && ((pinned_columns && B <= 131072) || B <= 16384);
         const bool owner_small = total <= (int64_t(8) << 20) || (rowbytes >= 24 && total <= (int64_t(128) << 20));
-        if ((owner_big || owner_small) && total < (int64_t(4) << 30))
+        // (end of round 2: two-pass is 3-4 % ahead from 2 GB on -- 32768 x 1024 AMINO20 f32 0.376 vs 0.389 ms --, level at
+        // 1.3 GB and behind below: profiles/r02/sweep_shapes_final.txt)
+        if ((owner_big || owner_small) && total < (int64_t(3) << 29))
             path = 3;
         else if ((rowbytes >= 16 && total >= (int64_t(192) << 20)) || ((pitch % 64 != 0 || misaligned_out) && total >= (int64_t(32) << 20)))
             path = 2;  // (second case: position rows that are not 64-byte aligned -- the tiles would share memory sectors or
