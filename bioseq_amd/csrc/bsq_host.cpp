@@ -338,7 +338,8 @@ Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
                   {"tokens8_lookup", "BSQ_TOKENS8_LOOKUP", 0, false},
                   {"tokens8_pad", "BSQ_TOKENS8_PAD", 0, false},
                   {"pattern_wait", "BSQ_PATTERN_WAIT", 0, false},
-                  {"tokenize_tb", "BSQ_TOKENIZE_TB", 0, false}};
+                  {"tokenize_tb", "BSQ_TOKENIZE_TB", 0, false},
+                  {"wide_index", "BSQ_WIDE_INDEX", 0, false}};
 std::mutex g_knob_mu;
 Knob *find_knob(const char *name) {
     for (Knob &k : g_knobs)

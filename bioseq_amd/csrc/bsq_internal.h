@@ -48,6 +48,8 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //                 without token loads (ablation)
 //   fill_mode, fill_pad   access pattern / occupancy of bsq_fill_device (write-bandwidth yardsticks)
 //   tokenize_tb           sequences per tile of k_tokenize_tile ((P,B) tokens of 2- / 4- / 8-byte elements): 64 / 128 / 256
+//   wide_index            1: the (B,P) chunk kernels take their 64-bit index arithmetic whatever the size (tests: the path
+//                         otherwise needs more than 2^31 16-byte pieces of output)
 //   pattern_wait          bsq_fill_pattern_device: n > 0 = s_waitcnt vmcnt(n - 1) after every row of a wave
 //   host_copy_threads     worker threads of the pipelined device -> host result copy (0: 8)
 int tuning(const char *name);

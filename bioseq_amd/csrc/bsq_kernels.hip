@@ -1151,6 +1151,7 @@ struct TParams {
     // step_q / step_r = 64 / ppr and % ppr: row / piece advance between two stores of a lane
     uint32_t ppr, magic, shift, pow2, step_q, step_r;
     uint32_t a0e, pmod;  // RG: (out mod 16) / sizeof(T) and P mod EPL -- where in its 16-byte line a row starts
+    int32_t wide_index;  // knob "wide_index": the 64-bit index arithmetic whatever the size (tests)
     uint32_t magic_c, shift_c, pow2_c;  // the same for / C (one-hot mode: row -> sequence, channel)
 };
 
@@ -1239,7 +1240,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
     const int64_t total_chars = p.offsets[p.B];
     const uint32_t Pu = static_cast<uint32_t>(p.P), PPR = p.ppr;
     const bool has_mask = HOT && p.mask != nullptr;
-    const bool small = nrows * int64_t(PPR) < (int64_t(1) << 31);  // 32-bit piece indices: divide by reciprocal
+    const bool small = nrows * int64_t(PPR) < (int64_t(1) << 31) && !p.wide_index;  // 32-bit piece indices: divide by reciprocal
 
     // stage A: (row, position) of the lane's four stores -- element e0 + u*EPS with e0 = lo/SZ + lane*EPL -- without a
     // per-lane division (the chunk's first element is wave-uniform, the lane's share adds < 1024 positions, the
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
             c.chan[u] = 0;
             if constexpr (HOT) {  // row = sequence * C + channel
                 int64_t seq;
-                if (nrows < (int64_t(1) << 31))  // wave-uniform
+                if (nrows < (int64_t(1) << 31) && !p.wide_index)  // wave-uniform
                     seq = fast_div(static_cast<uint32_t>(b), p.magic_c, p.shift_c, p.pow2_c);
                 else
                     seq = b / p.C;
@@ -1314,7 +1315,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_chunks(const TParams p) {
         }
         int64_t seq0 = c.bc;
         if constexpr (HOT)
-            seq0 = (nrows < (int64_t(1) << 31)) ? int64_t(fast_div(static_cast<uint32_t>(c.bc), p.magic_c, p.shift_c, p.pow2_c))
+            seq0 = (nrows < (int64_t(1) << 31) && !p.wide_index) ? int64_t(fast_div(static_cast<uint32_t>(c.bc), p.magic_c, p.shift_c, p.pow2_c))
                                                 : c.bc / p.C;
         const int64_t off0 = p.offsets[seq0];
         const int64_t lo_b64 = -off0, hi_b64 = total_chars - off0 - EPL;  // valid range of a vector's first byte, relative to off0
@@ -2094,6 +2095,7 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     c.ppr = uint32_t((k.P + EPL - 1) / EPL) + (ragged ? 1u : 0u);  // ragged: + the head slot
     c.a0e = uint32_t(reinterpret_cast<uintptr_t>(k.out) % 16) / uint32_t(sizeof(T));
     c.pmod = uint32_t(k.P % EPL);
+    c.wide_index = bsq_internal::tuning("wide_index");
     c.nchunks = (k.B * (HOT ? int64_t(k.C) : 1) * int64_t(c.ppr) + kChunk / 16 - 1) / (kChunk / 16);  // 256 pieces per wave
     c.bos = k.bos;
     c.bos_id = uint32_t(k.bos_id);

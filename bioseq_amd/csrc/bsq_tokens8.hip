@@ -45,6 +45,8 @@ struct T8Params {
     int32_t bos, room;
     uint32_t bos_id, at_len_v, fill_v;  // token VALUES at position 0, bos + L and beyond (0 where the reference leaves the memset)
     int32_t abl;       // ablation experiments (diagnostic builds of the kernel only)
+    int32_t wide_index;  // knob "wide_index": take the 64-bit chunk arithmetic whatever the size (tests: that path otherwise
+                         // needs > 32 GB of output)
     uint32_t none_v;   // value of an unmapped character: 0 (token VALUES, tokenize.h:427) or 0xFF (raw ids for the one-hot expansion)
 };
 
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    const bool small = p.nchunks < (int64_t(1) << 23);  // piece indices below 2^31
+    const bool small = p.nchunks < (int64_t(1) << 23) && !p.wide_index;  // piece indices below 2^31
     const uint32_t P = p.P, PPR = p.ppr;
     auto div_p = [&](uint32_t n) { return fast_div(n, p.magic, p.shift, p.pow2); };
     constexpr bool kLoadOffsets = ABL != 3 && ABL != 5;
@@ -421,6 +423,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
     c.fill_v = fill;
     c.at_len_v = d->eos ? uint32_t(bsq_eos_id(d)) : fill;
     c.abl = tuning("tokens8_abl");
+    c.wide_index = tuning("wide_index");
     int lk = tuning("tokens8_lookup");  // 0 automatic (registers when the table folds), 1 LDS byte table, 2 registers
     if (lk == 0) lk = foldable ? 2 : 1;
     if (lk == 2 && !foldable) lk = 1;

@@ -88,3 +88,41 @@ def test_channels_first_onehot_any_padlen_any_alignment(gpu, oracle, dc, B, lo, 
                 host = buf.cpu().numpy()
                 assert (host[:lo_b] == 0x5A).all() and (host[lo_b + n:] == 0x5A).all(), "wrote outside the tensor"
                 assert host[lo_b:lo_b + n].tobytes() == want.tobytes(), (key, flags, dc, use_mask, shift)
+
+
+@pytest.mark.parametrize("dc", list("bhilfd"))
+def test_wide_index_arithmetic_gives_the_same_results(gpu, oracle, dc):
+    """The 64-bit index paths of the (B,P) chunk kernels (more than 2^31 16-byte pieces: > 32 GB of output) forced with the
+    knob `wide_index` on small shapes, aligned and ragged, tokens and channels-first one-hot."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(dc.encode(), ctypes.byref(dt)))
+    sz = lib.bsq_dtype_size(dt)
+    capi.check(lib.bsq_tuning_set(b"wide_index", 1))
+    try:
+        for B, P in ((700, 144), (300, 250), (1000, 129), (64, 1024)):
+            chars, offs = nasty_batch(B + P, B, 0, P - 2)
+            dch = torch.from_numpy(np.concatenate([chars, np.zeros(1, np.uint8)])).to(gpu)
+            dof = torch.from_numpy(offs).to(gpu)
+            for key, flags in TOKS:
+                ora = oracle.OracleTokenizer(key, *flags)
+                desc = capi.make_desc(key, *flags)
+                for knob in ((0, 1) if dc == "b" else (0,)):
+                    capi.check(lib.bsq_tuning_set(b"tokens8", knob))
+                    got = run_tokens(lib, capi, desc, dch, dof, B, P, dc, gpu, 0)
+                    capi.check(lib.bsq_tuning_set(b"tokens8", 0))
+                    assert got.tobytes() == ora.tokenize_packed(chars, offs, P, dc, True).tobytes(), (key, B, P, knob)
+                C = ora.alphabet_size()
+                out = torch.full((B * C * P * sz,), 0x5A, dtype=torch.uint8, device=gpu)
+                for path in (1, 2):
+                    capi.check(lib.bsq_tuning_set(b"bcl_path", path))
+                    capi.check(lib.bsq_onehot_bcl_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), None, B, P, dt,
+                                                         out.data_ptr(), None))
+                    torch.cuda.synchronize()
+                    want = np.ascontiguousarray(ora.onehot_packed(chars, offs, P, dc).transpose(1, 2, 0))
+                    assert out.cpu().numpy().tobytes() == want.tobytes(), (key, B, P, "bcl", path)
+    finally:
+        for k in (b"wide_index", b"tokens8", b"bcl_path"):
+            capi.check(lib.bsq_tuning_set(k, 0))
