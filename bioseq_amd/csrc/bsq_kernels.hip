@@ -365,11 +365,11 @@ __host__ __device__ constexpr int tile_fixed_bytes() {
     return tile_off_bytes<TB>() + 256 + TB * kTokStride;
 }
 
-// amdgpu_waves_per_eu(5): 94 instead of 127 VGPRs, so that the 5 workgroups per CU that the LDS allows also fit the
+// amdgpu_waves_per_eu(5) for the 256-sequence tile (the smaller ones would spill a few registers): 94 instead of 127 VGPRs, so that the 5 workgroups per CU that the LDS allows also fit the
 // register file (4 before): 65536 x 256 int8 DNA 31 -> 28 us, 8192 x 512 int8 AMINO20 22 -> 19 us, cfg4 int8 -1..3 %
 // (profiles/r02/ab_tile_occ5.txt).
 template <typename ST, int TB, bool NT>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void k_onehot_tile(const KParams p) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TB == 256 ? 5 : 4))) void k_onehot_tile(const KParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     SeqSpan *s_span = reinterpret_cast<SeqSpan *>(smem);
     uint8_t *s_lut = smem + tile_off_bytes<TB>();
