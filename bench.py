@@ -117,6 +117,23 @@ def cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, cap_threads=Non
                                         % (B1, int(o1[-1]), nbytes1 / 1e9)}}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>`
+    as a child process and relay its output (rank 0's JSON line goes to stdout as it is).  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,10 +154,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched HIP or imported
+        # torch yet, and the ranks are CHILD processes (never an exec): torch.distributed.run starts one rank per GPU,
+        # rank 0 prints the one JSON line, which is relayed unchanged; exit code = the launcher's.
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
         args.gpus = world
 
     import ctypes

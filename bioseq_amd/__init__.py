@@ -59,8 +59,11 @@ def onehot_encode(tokenizer, seqbatch, padlen=-1, destchar='B', batch_first=Fals
     """
     on_device = to_pytorch and _is_hip_device(device)
     single = isinstance(seqbatch, (str, bytes))
-    if single:
-        encoded = tokenizer.onehot_encode(seqbatch, padlen, destchar)
+    if single:  # one sequence: (max(L, padlen) + bos + eos, C), tokenize.h:188-216
+        if on_device:
+            encoded = tokenizer.onehot_encode(seqbatch, padlen, destchar, device=device)
+        else:
+            encoded = tokenizer.onehot_encode(seqbatch, padlen, destchar)
     else:
         encoded = tokenizer.batch_onehot_encode(seqbatch, padlen, destchar, device=device if on_device else None)
         if batch_first:  # 'seq batch base -> batch seq base', a strided view like the reference's einops.rearrange

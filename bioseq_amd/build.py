@@ -43,11 +43,31 @@ def hipcc():
 
 
 def build_lib(force=False):
-    deps = [os.path.join(CSRC, f) for f in LIB_DEPS] + [os.path.join(INCLUDE, "bsq.h")]
-    if force or _newer(LIB, deps):
-        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
-              "-pthread", "-I" + INCLUDE, "-I" + CSRC, "-o", LIB] + os.environ.get("BSQ_EXTRA_HIPCC_FLAGS", "").split() +
-             [os.path.join(CSRC, f) for f in LIB_SRCS])
+    """One object per source under csrc/_obj/ (compiled in parallel, rebuilt only when the source or a header
+    changed), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    headers = [os.path.join(CSRC, f) for f in LIB_DEPS if f.endswith(".h")] + [os.path.join(INCLUDE, "bsq.h"), os.path.join(INCLUDE, "bsq_diag.h")]
+    extra = os.environ.get("BSQ_EXTRA_HIPCC_FLAGS", "").split()
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    stamp = os.path.join(objdir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(extra):
+        force = True
+    jobs, objs = [], []
+    for f in LIB_SRCS:
+        src, obj = os.path.join(CSRC, f), os.path.join(objdir, f + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + headers):
+            lang = ["-x", "hip"] if f.endswith(".hip") else []
+            jobs.append([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-pthread",
+                         "-I" + INCLUDE, "-I" + CSRC] + extra + lang + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("BSQ_BUILD_JOBS", "4")))) as ex:
+            list(ex.map(_run, jobs))
+        with open(stamp, "w") as fh:
+            fh.write(" ".join(extra))
+    if jobs or not os.path.exists(LIB):
+        _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
     return LIB
 
 

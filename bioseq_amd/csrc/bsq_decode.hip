@@ -149,10 +149,10 @@ __global__ __launch_bounds__(kThreads) void k_argmax_tokens(const LT *logits, in
         for (int32_t c = 1; c < C; ++c) {
             if constexpr (sizeof(LT) == 8) {
                 const double v = static_cast<double>(a[c]);
-                if (v > bestd) bestd = v, arg = c;
+                if (v > bestd || (v != v && bestd == bestd)) bestd = v, arg = c;  // NaN is the maximum, first one wins (torch.argmax)
             } else {
                 const float v = static_cast<float>(a[c]);
-                if (v > best) best = v, arg = c;
+                if (v > best || (v != v && best == best)) best = v, arg = c;
             }
         }
         tokens[r] = static_cast<OT>(arg);
@@ -212,25 +212,30 @@ bsq_status bsq_decode_sizes_device(const bsq_desc *d, const void *tokens, int32_
     *first_bad = -1;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     if ((nrows + 3) / 4 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "too many rows");
-    std::lock_guard<std::mutex> turn(bsq_internal::workspace_mutex());  // the flag lives in the stream's shared scratch
-    void *ws = nullptr;
-    st = bsq_internal::workspace_acquire(sizeof(unsigned long long), s, &ws);
-    if (st != BSQ_OK) return st;
-    p.first_bad = static_cast<unsigned long long *>(ws);
-    p.row_len = row_offsets;
-    hipError_t e = hipMemsetAsync(ws, 0xFF, sizeof(unsigned long long), s);
-    if (e == hipSuccess && nrows == 0) e = hipMemsetAsync(row_offsets, 0, sizeof(int64_t), s);
-    if (e == hipSuccess && nrows > 0) {
-        hipLaunchKernelGGL(k_decode_sizes, dim3(unsigned((nrows + 3) / 4)), dim3(kThreads), 0, s, p);
-        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, s, row_offsets, nrows);
-        e = hipGetLastError();
-    }
     unsigned long long bad = ~0ull;
     int64_t tot = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&bad, ws, sizeof(bad), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(&tot, row_offsets + nrows, sizeof(tot), hipMemcpyDeviceToHost, s);
+    hipError_t e;
+    {
+        // the flag lives in the stream's shared scratch: the lock is held until the last operation that touches it is
+        // ENQUEUED (bsq_internal.h), never across the synchronisation -- stream order protects it from later users
+        std::lock_guard<std::mutex> turn(bsq_internal::workspace_mutex());
+        void *ws = nullptr;
+        st = bsq_internal::workspace_acquire(sizeof(unsigned long long), s, &ws);
+        if (st != BSQ_OK) return st;
+        p.first_bad = static_cast<unsigned long long *>(ws);
+        p.row_len = row_offsets;
+        e = hipMemsetAsync(ws, 0xFF, sizeof(unsigned long long), s);
+        if (e == hipSuccess && nrows == 0) e = hipMemsetAsync(row_offsets, 0, sizeof(int64_t), s);
+        if (e == hipSuccess && nrows > 0) {
+            hipLaunchKernelGGL(k_decode_sizes, dim3(unsigned((nrows + 3) / 4)), dim3(kThreads), 0, s, p);
+            hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, s, row_offsets, nrows);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, ws, sizeof(bad), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&tot, row_offsets + nrows, sizeof(tot), hipMemcpyDeviceToHost, s);
+        bsq_internal::workspace_release(ws, s);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    bsq_internal::workspace_release(ws, s);
     if (e != hipSuccess) return bsq_internal::set_hip_error("bsq_decode_sizes_device", e);
     *total = tot;
     if (bad != ~0ull) {

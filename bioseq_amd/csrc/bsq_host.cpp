@@ -389,13 +389,17 @@ void keep_pool_memory(int dev) {
 }
 }  // namespace
 
+constexpr size_t kWsCacheCap = size_t(2) << 30;
+
 bsq_status workspace_acquire(size_t nbytes, hipStream_t stream, void **ptr) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return set_hip_error("hipGetDevice", e);
     keep_pool_memory(dev);
     if (nbytes == 0) nbytes = 16;
-    if (capturing(stream) || tuning("workspace_cache") == 1) {
+    // Scratch above kWsCacheCap is never kept: one huge call would otherwise pin its bytes (invisible to the caller's
+    // allocator) per (device, stream) slot until bsq_release_staging().  cfg3 needs 64 MiB, cfg4 160 MiB.
+    if (capturing(stream) || nbytes > kWsCacheCap || tuning("workspace_cache") == 1) {
         e = hipMallocAsync(ptr, nbytes, stream);
         if (e != hipSuccess) return set_hip_error("hipMallocAsync(workspace)", e);
         return BSQ_OK;
@@ -448,6 +452,9 @@ std::mutex &workspace_mutex() {
 }
 
 void workspace_drop_cache() {
+    // workspace_mutex() first: a caller that sits between workspace_acquire() and its last launch holds it, and its
+    // scratch must not be freed under it
+    std::lock_guard<std::mutex> turn(workspace_mutex());
     std::lock_guard<std::mutex> lock(g_ws_mu);
     int prev = 0;
     (void)hipGetDevice(&prev);

@@ -17,8 +17,11 @@ Files written next to this script:
     facade.npz/json  outputs of bioseq.onehot_encode / f_encode and the tokenizer-dict key lists
     blosum_normrows.npy
     flatfile_small.fa/.ff  a small FASTA/FASTQ text and the FlatFile the reference writes from it
+    augment_law.json  (position x new residue) counts of the reference's augment_seq on a mixed sequence
+    decode.json.gz, decode_tokens.npz, single.json.gz   row f-4: decode_tokens strings and single-sequence one-hot digests
 """
 import argparse
+import gzip
 import hashlib
 import itertools
 import json
@@ -212,6 +215,15 @@ def facade():
                              to_pytorch=True)
     A["onehot_encode_torch_bf"] = t.numpy().copy()
     J["onehot_encode_torch_bf"] = dict(dtype=str(t.dtype), contiguous=bool(t.is_contiguous()))
+    A["onehot_encode_numpy_sf"] = bioseq.onehot_encode(bioseq.beos_tokenizers["AMINO20"], ["MKV", b"ACDEFGHIKL", bytearray(b"WY")],
+                                                       padlen=12, destchar="h")
+    A["onehot_encode_numpy_bf"] = bioseq.onehot_encode(bioseq.pos_tokenizers["SEB8"], ["MKV", "ACDEFGHIKL", ""], padlen=10,
+                                                       destchar="d", batch_first=True)
+    t = bioseq.f_encode(["ACGT", "NNNN", "acg"], key="DNA5", eos=True, padchar=True, padlen=6, destchar="i", to_pytorch=True)
+    A["f_encode_torch_sf_i32"] = t.numpy().copy()
+    J["f_encode_torch_sf_i32"] = dict(dtype=str(t.dtype), contiguous=bool(t.is_contiguous()))
+    t = bioseq.f_encode("ACGTTGCA", key="DNA", bos=True, padlen=10, destchar="f", to_pytorch=True)
+    A["f_encode_single_torch"] = t.numpy().copy()
     # single-sequence path: str -> 'B' is uint8 there, shape (max(L,padlen)+bos+eos, C)
     A["single_str_default"] = bioseq.f_encode("ACGT", key="DNA")
     A["single_pbeos_p8"] = bioseq.pbeos_tokenizers["DNA"].onehot_encode("ACGT", 8, "f")
@@ -221,6 +233,91 @@ def facade():
         json.dump(J, f, indent=1, sort_keys=True)
     from bioseq import blosum
     np.save(os.path.join(HERE, "blosum_normrows.npy"), blosum.normrows.astype("<f8"))
+
+
+DEC_KEYS = ["DNA", "AMINO20", "SEB8", "DNA5", "BYTES", "KETO", "DAYHOFF"]
+SINGLE_KEYS = ["DNA", "AMINO20", "SEB8", "PURPYR"]
+
+
+def decode_and_single():
+    """Row f-4 pinned to the reference.
+
+    decode.json.gz / decode_tokens.npz: seeded token matrices (stored) and what the REFERENCE's `decode_tokens`
+    (src/tokenize.h:131-183) returns for them as 2-D arrays of every item size (1/2/4/8, signed and unsigned -- all must
+    agree, asserted here), as 1-D rows, through a transposed view and through a column-strided view.
+    single.json.gz: the reference's single-sequence `onehot_encode` (src/tokenize.h:188-216, src/tokenize.cpp:24-51) for
+    str / bytes / bytearray x padlen {0, L, L+5} x the case-masked dtype characters (+ the per-type default), as
+    dtype / shape / sha256 of the returned array.  Only letters the alphabet maps are used: an unmapped byte makes the
+    reference write before the row (tokenize.h:203-206)."""
+    rng = np.random.default_rng(20260301)
+    arrays, dec = {}, []
+    n = 0
+    for key in DEC_KEYS:
+        for eos, bos, pad in COMBOS:
+            tok = cbioseq.Tokenizer(key, eos, bos, pad)
+            ids = sorted(k for k in tok.token_decoder().keys() if 0 <= k < 128)
+            ids += [i for i, on in ((tok.bos(), bos), (tok.eos(), eos), (tok.pad(), pad)) if on]
+            for shape in ((1, 1), (3, 64), (5, 65), (7, 200), (70, 33)):
+                toks = rng.choice(np.array(ids, dtype=np.int64), size=shape)
+                want = tok.decode_tokens(toks)
+                for dt in (np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64):
+                    if toks.max() <= np.iinfo(dt).max:
+                        assert tok.decode_tokens(toks.astype(dt)) == want, (key, dt)
+                rows = [tok.decode_tokens(toks[r].astype(np.int32)) for r in range(shape[0])]
+                assert rows == want
+                name = "T%d" % n
+                n += 1
+                arrays[name] = toks.astype(np.int16 if toks.max() > 127 else np.int8)
+                dec.append(dict(name=name, key=key, eos=eos, bos=bos, padchar=pad,
+                                decoded=want,
+                                transposed=tok.decode_tokens(toks.astype(np.int16).T),
+                                strided=tok.decode_tokens(toks.astype(np.int32)[:, ::2])))
+    np.savez_compressed(os.path.join(HERE, "decode_tokens.npz"), **arrays)
+    with gzip.GzipFile(os.path.join(HERE, "decode.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(dec, separators=(",", ":")).encode())
+
+    single = []
+    for key in SINGLE_KEYS:
+        plain = cbioseq.Tokenizer(key)
+        letters = "".join(sorted(chr(b) for t, members in plain.token_decoder().items() if t >= 0 for b in members
+                                 if chr(b).isalpha()))
+        seqs = ["", letters[0], "".join(rng.choice(list(letters), size=37)), "".join(rng.choice(list(letters), size=130))]
+        for eos, bos, pad in COMBOS:
+            tok = cbioseq.Tokenizer(key, eos, bos, pad)
+            for si, seq in enumerate(seqs):
+                for padlen in (0, len(seq), len(seq) + 5):
+                    for kind, obj in (("str", seq), ("bytes", seq.encode()), ("bytearray", bytearray(seq.encode()))):
+                        dts = ["", "B", "H", "I", "F", "D", "b", "h", "i", "f", "d"] if kind == "str" else ["", "f", "H"]
+                        for dt in dts:
+                            a = tok.onehot_encode(obj, padlen, dt) if dt else tok.onehot_encode(obj, padlen)
+                            single.append([key, eos, bos, pad, si, padlen, kind, dt, str(a.dtype), list(a.shape),
+                                           int(a.sum()), sha(a)[:24]])
+        single.append(dict(key=key, seqs=seqs))
+    with gzip.GzipFile(os.path.join(HERE, "single.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(single, separators=(",", ":")).encode())
+
+
+AUG_SEQ = "AWHKCLGPSTYV"
+AUG_N = 200000
+
+
+def augment_law():
+    """augment_law.json: the REFERENCE's `augment_seq` (bioseq/blosum.py:63-87) run AUG_N times on one heterogeneous
+    sequence, chain_len 1, as a (position x new residue) count table -- data only.  The mutated position is NOT uniform:
+    the reject-until-changed loop makes it proportional to 1 - normrows[r, r] (W: almost never, A: often)."""
+    import time
+    from bioseq import blosum
+    letters = "".join(blosum.aa_array)
+    counts = np.zeros((len(AUG_SEQ), len(letters)), dtype=np.int64)
+    t0 = time.time()
+    for _ in range(AUG_N):
+        out = blosum.augment_seq(AUG_SEQ, 1)
+        (pos,) = [i for i, (a, b) in enumerate(zip(AUG_SEQ, out)) if a != b]  # exactly one residue changes
+        counts[pos, letters.index(out[pos])] += 1
+    with open(os.path.join(HERE, "augment_law.json"), "w") as f:
+        json.dump(dict(seq=AUG_SEQ, n=AUG_N, chain_len=1, letters=letters, counts=counts.tolist(),
+                       generator="bioseq.blosum.augment_seq, module rng default_rng(72) as imported", seconds=round(time.time() - t0)),
+                  f, separators=(",", ":"))
 
 
 def flatfile_fixture():
@@ -237,11 +334,15 @@ def flatfile_fixture():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--augment-law", action="store_true", help="re-run the reference's augment_seq 200 000 times (about a minute)")
     a = ap.parse_args()
     alphabets()
     small_cases()
     facade()
     flatfile_fixture()
+    decode_and_single()
     kats(a.full)
+    if a.augment_law or not os.path.exists(os.path.join(HERE, "augment_law.json")):
+        augment_law()
     print("golden fixtures written to", HERE)
 

@@ -186,3 +186,126 @@ def test_cfg5_full_size_augment_then_tokenize(gpu, bsq, oracle, chain_len, frac)
     got = tok.tokenize_packed(dch, dof, P, "B", True).cpu().numpy()
     exp = oracle.OracleTokenizer(c["key"], c["eos"], c["bos"], c["padchar"]).tokenize_packed(mutated, offs, P, "B", True, 8)
     assert got.tobytes() == exp.tobytes()
+
+
+# ---------------------------------------------------------------- the joint law on a MIXED sequence
+
+def _law_fixture(golden_dir):
+    import json
+    with open(os.path.join(golden_dir, "augment_law.json")) as f:
+        J = json.load(f)
+    assert J["letters"] == LETTERS and J["chain_len"] == 1
+    return J["seq"], J["n"], np.array(J["counts"], dtype=np.float64)
+
+
+def _expected_law(seq, normrows):
+    """P(position i, new residue k) of the reference's reject-until-changed loop (blosum.py:75-83): every iteration
+    draws i uniformly and k from normrows[r_i]; it stops when k != r_i.  So P(i, k) = normrows[r_i, k] / Z for
+    k != r_i, Z = sum_i (1 - normrows[r_i, r_i]): the POSITION is proportional to 1 - p_self(residue)."""
+    rows = [LETTERS.index(c) for c in seq]
+    P = np.array([normrows[r] for r in rows])
+    for i, r in enumerate(rows):
+        P[i, r] = 0.0
+    return P / P.sum()
+
+
+def _chi2_p(counts, probs):
+    from scipy import stats
+    n = counts.sum()
+    exp = n * probs
+    keep = exp > 0
+    assert counts[~keep].sum() == 0
+    small = keep & (exp < 5)                      # pool thin cells
+    c = np.append(counts[keep & ~small], counts[small].sum())
+    e = np.append(exp[keep & ~small], exp[small].sum())
+    if e[-1] == 0:
+        c, e = c[:-1], e[:-1]
+    return stats.chi2.sf((((c - e) ** 2) / e).sum(), len(c) - 1)
+
+
+def test_reference_run_follows_the_stated_law(golden_dir):
+    """CPU: the fixture (200 000 runs of the REFERENCE's augment_seq) against the closed form the kernel implements --
+    position ~ (1 - p_self), new residue ~ row without its own entry.  Pins our reading of blosum.py:63-87."""
+    from bioseq_amd import blosum
+    seq, n, counts = _law_fixture(golden_dir)
+    assert counts.sum() == n
+    law = _expected_law(seq, blosum.normrows)
+    assert _chi2_p(counts.sum(axis=1), law.sum(axis=1)) > 1e-6            # positions
+    assert _chi2_p(counts.ravel(), law.ravel()) > 1e-6                    # joint
+    w, a = seq.index("W"), seq.index("A")
+    assert counts[w].sum() * 40 < counts[a].sum()                         # W (p_self 0.99) almost never, A often
+
+
+def _kernel_table(gpu, seq, n, seed, chain_len=1):
+    import torch
+    from bioseq_amd import blosum
+    L = len(seq)
+    chars = np.tile(np.frombuffer(seq.encode(), dtype=np.uint8), n)
+    offs = np.arange(0, n * L + 1, L, dtype=np.int64)
+    got = blosum.augment_packed(torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu), chain_len, 1.0, seed).cpu().numpy()
+    diff = (got != chars).reshape(n, L)
+    return got.reshape(n, L), diff
+
+
+@pytest.mark.gpu
+def test_position_law_on_a_mixed_sequence(gpu, golden_dir):
+    """200 000 copies of a fixed heterogeneous sequence, chain 1, frac 1: the histogram of the MUTATED POSITION against
+    (1 - normrows[r, r]) / sum, per position the new residue against the row without its own entry, and a two-sample
+    chi-square between the kernel's (position x residue) table and the reference's own run (augment_law.json)."""
+    from scipy import stats
+    from bioseq_amd import blosum
+    seq, n, ref_counts = _law_fixture(golden_dir)
+    got, diff = _kernel_table(gpu, seq, n, seed=20260303)
+    assert (diff.sum(axis=1) == 1).all()                    # exactly one residue changes, never to itself
+    pos = diff.argmax(axis=1)
+    new = got[np.arange(n), pos]
+    lut = np.full(256, -1)
+    for k, ch in enumerate(LETTERS):
+        lut[ord(ch)] = k
+    assert (lut[new] >= 0).all()
+    table = np.zeros((len(seq), 20))
+    np.add.at(table, (pos, lut[new]), 1)
+    law = _expected_law(seq, blosum.normrows)
+    p_pos = _chi2_p(table.sum(axis=1), law.sum(axis=1))
+    assert p_pos > 1e-6, ("position histogram", table.sum(axis=1), n * law.sum(axis=1))
+    for i in range(len(seq)):
+        if table[i].sum() >= 1000:
+            assert _chi2_p(table[i], law[i] / law[i].sum()) > 1e-6, (i, seq[i])
+    assert _chi2_p(table.ravel(), law.ravel()) > 1e-6
+    # two-sample test against the reference's run (equal sample sizes): sum (k1 - k2)^2 / (k1 + k2)
+    k1, k2 = table.ravel(), ref_counts.ravel()
+    thin = (k1 + k2) < 20
+    a = np.append(k1[~thin], k1[thin].sum())
+    b = np.append(k2[~thin], k2[thin].sum())
+    stat = (((a - b) ** 2) / (a + b)).sum()
+    assert stats.chi2.sf(stat, len(a) - 1) > 1e-6, stat
+    # an unknown residue (X row: p_self = 0) and lower case in the mix: accepted at once wherever they are drawn
+    seq2 = "WWWWxWWWWWWa"
+    got2, diff2 = _kernel_table(gpu, seq2, 50000, seed=5)
+    pos2 = diff2.argmax(axis=1)
+    law2 = np.array([1.0 - (blosum.normrows[17, 17] if c == "W" else 0.0) for c in seq2])
+    assert _chi2_p(np.bincount(pos2, minlength=len(seq2)).astype(np.float64), law2 / law2.sum()) > 1e-6
+
+
+@pytest.mark.gpu
+def test_chain_of_mutations_follows_the_law_step_by_step(gpu):
+    """chain_len 2: the second mutation sees the sequence the first one left (the weights move with it).  Checked through
+    the marginal the closed form gives for the number of changed positions: P(both mutations hit the same position)."""
+    from bioseq_amd import blosum
+    seq, n = "AWHKCLGPSTYV", 100000
+    got, diff = _kernel_table(gpu, seq, n, seed=77, chain_len=2)
+    nd = diff.sum(axis=1)
+    assert nd.max() <= 2
+    law1 = _expected_law(seq, blosum.normrows)
+    # P(second hits the same position i | first was (i, k)) = (1 - p_self(k)) / Z', Z' = Z - (1 - p_self(r_i)) + (1 - p_self(k))
+    rows = [LETTERS.index(c) for c in seq]
+    w = np.array([1.0 - blosum.normrows[r, r] for r in rows])
+    p_same = 0.0
+    for i in range(len(seq)):
+        for k in range(20):
+            if law1[i, k] > 0:
+                wk = 1.0 - blosum.normrows[k, k]
+                p_same += law1[i, k] * wk / (w.sum() - w[i] + wk)
+    same = float((nd <= 1).sum())                # same position twice: one visible change (or none: mutated back)
+    sd = np.sqrt(n * p_same * (1 - p_same))
+    assert abs(same - n * p_same) < 6 * sd, (same, n * p_same)
