@@ -58,7 +58,9 @@ def build_lib(force=False):
         src, obj = os.path.join(CSRC, f), os.path.join(objdir, f + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
-            lang = ["-x", "hip"] if f.endswith(".hip") else []
+            # gfx950 hands the first 14 kernel-argument dwords to a wave in SGPRs (no s_load round trip before its first
+            # vector load): the fast token kernel's signature is laid out for it (bsq_tokens8.hip)
+            lang = ["-x", "hip", "-mllvm", "-amdgpu-kernarg-preload-count=14"] if f.endswith(".hip") else []
             jobs.append([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-pthread",
                          "-I" + INCLUDE, "-I" + CSRC] + extra + lang + ["-c", src, "-o", obj])
     if jobs:

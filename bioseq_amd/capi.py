@@ -76,6 +76,7 @@ def load():
         "bsq_onehot_device_generic": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
         "bsq_fill_device": (i32, [vp, sz, ctypes.c_uint32, vp]),
         "bsq_fill_pattern_device": (i32, [vp, i64, i64, i32, i32, i32, i32, i32, vp]),
+        "bsq_copy_mix_device": (i32, [vp, sz, vp, sz, i32, i32, vp]),
         "bsq_xcd_of_blocks_device": (i32, [vp, i32, vp]),
         "bsq_selftest_index_math": (i64, []),
         "bsq_raw_tokens_device": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, vp]),

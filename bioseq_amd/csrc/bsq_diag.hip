@@ -90,6 +90,42 @@ __global__ __launch_bounds__(kThreads) void k_fill_pattern(uint8_t *dst, int64_t
     }
 }
 
+// Diagnostic: a read + write stream of the (B,P) int8 token kernel's SHAPE with none of its work -- the yardstick the
+// token kernels of cfg2 / cfg5 are quoted against next to the plain fill.  Wave k writes the aligned 4-KiB chunk k of
+// dst (class k % 8 pinned to its XCD as in k_tokens_bp8) and reads its share of src (ceil(nsrc16 / nchunks) 16-byte
+// pieces, coalesced).  mode 0: loads, then stores of the loaded data (one dependent step); mode 1: an 8-byte load of
+// src first, whose (zeroed) value is added to the load addresses: two dependent steps, like offsets -> characters;
+// mode 2: the stores do not wait for the loads (their data only reaches a never-taken store at the end).
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void k_copy_mix(uint4 *dst, int64_t nchunks, const uint4 *src, int64_t nsrc16,
+                                                       int32_t per_chunk, int32_t mode) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave);
+    if (k >= nchunks) return;
+    int64_t base = k * per_chunk;
+    if (mode == 1) {
+        const uint64_t dep = reinterpret_cast<const uint64_t *>(src)[(k * 2) % (nsrc16 * 2)];
+        base += dep == 0x123456789ABCDEF1ull ? 1 : 0;  // practically always 0, but the addresses now wait for the load
+    }
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * 64 + lane;
+        v[u] = (u * 64 + lane < per_chunk && i < nsrc16) ? src[i] : uint4{1, 2, 3, 4};
+    }
+    uint4 *d = dst + k * (kChunk / 16) + lane;
+    if (mode == 2) {
+        const uint4 c{5, 6, 7, 8};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) store16<NT>(d + u * 64, c);
+        const uint32_t x = v[0].x & v[1].y & v[2].z & v[3].w;
+        if (x == 0x9E3779B9u) store16<NT>(d, v[0]);  // keeps the loads alive
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) store16<NT>(d + u * 64, uint4{v[u].x | v[(u + 1) & 3].x, v[u].y, v[u].z, v[u].w});
+}
+
 // Diagnostic: the XCD every block of a 1-D grid ran on (HW_REG_XCC_ID, 0..7).  The chunk kernels rely -- for
 // speed only -- on blocks b and b + 8 sharing an XCD; this records what the dispatcher actually did.
 __global__ __launch_bounds__(kThreads) void k_xcd_probe(int32_t *xcd) {
@@ -149,6 +185,29 @@ bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32
         hipLaunchKernelGGL((k_fill_pattern<false>), grid, dim3(kThreads), pad, s, static_cast<uint8_t *>(dst), rows, pitch,
                            seg, rows_per_wave, ncb, nrb, order, interleave, wait);
     return check_launch("k_fill_pattern");
+}
+
+bsq_status bsq_copy_mix_device(void *dst, size_t dst_bytes, const void *src, size_t src_bytes, int32_t mode, int32_t nt,
+                               void *hip_stream) {
+    if (!dst || !src || dst_bytes % kChunk || src_bytes % 16 || src_bytes < 16 || reinterpret_cast<uintptr_t>(dst) % 16 ||
+        reinterpret_cast<uintptr_t>(src) % 16)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "copy mix: dst a multiple of 4 KiB, src of 16 bytes, both 16-byte aligned");
+    if (dst_bytes == 0) return BSQ_OK;
+    const int64_t nchunks = int64_t(dst_bytes / kChunk), nsrc16 = int64_t(src_bytes / 16);
+    const int64_t per_chunk = (nsrc16 + nchunks - 1) / nchunks;
+    if (per_chunk > 256) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "copy mix: src must not exceed dst");
+    const int64_t groups = ((nchunks + 7) / 8 + 3) / 4;
+    if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "copy mix too large");
+    const dim3 grid(unsigned(groups * 8));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const size_t pad = size_t(bsq_internal::tuning("fill_pad"));
+    if (nt)
+        hipLaunchKernelGGL((k_copy_mix<true>), grid, dim3(kThreads), pad, s, static_cast<uint4 *>(dst), nchunks,
+                           static_cast<const uint4 *>(src), nsrc16, int32_t(per_chunk), mode);
+    else
+        hipLaunchKernelGGL((k_copy_mix<false>), grid, dim3(kThreads), pad, s, static_cast<uint4 *>(dst), nchunks,
+                           static_cast<const uint4 *>(src), nsrc16, int32_t(per_chunk), mode);
+    return check_launch("k_copy_mix");
 }
 
 // Host-side self-test of the kernels' division-free index arithmetic (the same inline functions the device runs):

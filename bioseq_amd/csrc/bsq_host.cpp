@@ -335,6 +335,7 @@ Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
                   {"chunk_math", "BSQ_CHUNK_MATH", 0, false},
                   {"tokens8", "BSQ_TOKENS8", 0, false},
                   {"tokens8_abl", "BSQ_TOKENS8_ABL", 0, false},
+                  {"tokens8_fast", "BSQ_TOKENS8_FAST", 0, false},
                   {"tokens8_lookup", "BSQ_TOKENS8_LOOKUP", 0, false},
                   {"tokens8_pad", "BSQ_TOKENS8_PAD", 0, false},
                   {"pattern_wait", "BSQ_PATTERN_WAIT", 0, false},

@@ -348,6 +348,166 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
     stage_c(b);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_tokens_bp8_fast: the aligned, unmasked, register-table case of k_tokens_bp8 (cfg2, cfg5 and every other foldable
+// alphabet with padlen % 16 == 0 and < 2^23 chunks) with the wave's CRITICAL PATH cut down.  Same lane mapping, same
+// loads and stores, same results; what changed (round 3, profiles/r03/mix_lab1.txt: a plain read + write stream of this
+// shape with two dependent load steps takes 15.7 / 30.3 us on cfg2 / cfg5, k_tokens_bp8 17.0-17.4 / 31.8-33):
+//   * the scalars the first loads depend on are KERNEL ARGUMENTS IN SGPRs at wave start (14 dwords, gfx950 kernarg
+//     preload: -mllvm -amdgpu-kernarg-preload-count=14 in build.py) instead of five serialised rounds of s_load +
+//     s_waitcnt out of a 400-byte by-value struct;
+//   * the offsets loads are issued FIRST; the per-wave rule table (18 lanes x ~30 VALU + 2 ds_write_b128), the register
+//     alphabet table (one s_load_dwordx8) and offsets[B] are produced while they are in flight;
+//   * one division constant pair for every row width (powers of two as magic = 2^(32-s), shift 0: no branch per divide).
+struct T8Tab {
+    uint32_t t[8];
+};
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
+                                                              uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
+                                                              uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
+                                                              T8Tab tab) {
+    __shared__ __align__(16) uint4 s_rule[4][2][18];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t wave_s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(wave));
+    const uint32_t k0 = (blockIdx.x & 7u) + 8u * ((blockIdx.x >> 3) * 4u + wave_s);  // class = blockIdx % 8 (XCD-pinned)
+    if (k0 >= nchunks) return;
+    auto div_p = [&](uint32_t n) { return __umulhi(n, magic) >> shift; };
+    const uint32_t bos = packed & 1u, none_v = (packed & 2u) ? 0xFFu : 0u;
+    const uint32_t bos_id = (packed >> 8) & 0xFFu, at_len_v = (packed >> 16) & 0xFFu, fill_v = packed >> 24;
+
+    // ---- rows of the chunk; their offsets go out first ----
+    const uint32_t g0 = k0 * (kChunk / 16);  // first piece (nchunks < 2^23)
+    const uint32_t bc = div_p(g0);
+    const uint32_t tc = g0 - bc * PPR;
+    const uint32_t nr = div_p(tc + (kChunk / 16 - 1));  // rows bc .. bc + nr intersect the chunk (nr <= 32: P >= 128)
+    int64_t o0 = 0, o1 = 0;
+    if (static_cast<uint32_t>(lane) <= nr) {
+        const uint32_t i0 = bc + lane, i1 = i0 + 1;
+        o0 = offsets[i0 < B ? i0 : B];
+        o1 = offsets[i1 < B ? i1 : B];
+    }
+    int64_t total_chars = offsets[B];  // scalar load, in flight beside them
+    uint32_t T[8];  // the register alphabet table: fetched HERE, beside the offsets (the compiler would sink the s_load to its use,
+                    // behind the character loads)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) T[i] = tab.t[i];
+    asm volatile("" : "+s"(T[0]), "+s"(T[1]), "+s"(T[2]), "+s"(T[3]), "+s"(T[4]), "+s"(T[5]), "+s"(T[6]), "+s"(T[7]), "+s"(total_chars));
+
+    // ---- per-wave rule table, built while the offsets are in flight ----
+    {
+        const uint32_t fill_w = fill_v * 0x01010101u, at_w = at_len_v * 0x01010101u;
+        if (lane < 18) {  // entry `lane`: n = lane - 1 bytes kept, byte n (if any) = token at bos + L, the rest fill
+            const int n = lane - 1;
+            uint32_t keep[4], cst[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nv = n - 4 * q;
+                const int nvc = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+                const uint32_t kq = nvc == 4 ? 0xFFFFFFFFu : ((1u << (8 * nvc)) - 1u);
+                const uint32_t at = (nv >= 0 && nv < 4) ? (0xFFu << (8 * nv)) : 0u;
+                keep[q] = kq;
+                cst[q] = (fill_w & ~kq & ~at) | (at_w & at);
+            }
+            s_rule[wave][0][lane] = uint4{keep[0], keep[1], keep[2], keep[3]};
+            s_rule[wave][1][lane] = uint4{cst[0], cst[1], cst[2], cst[3]};
+        }
+        // wave-private: LDS operations of one wave execute in order, only the compiler must not reorder them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the characters: 4 unconditional unaligned 16-byte loads, all in flight together (see k_tokens_bp8) ----
+    const int64_t off0 = (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(static_cast<int32_t>(o0 >> 32))) << 32) |
+                         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int32_t>(o0)));
+    const uint32_t rel = static_cast<uint32_t>(o0) - static_cast<uint32_t>(off0);
+    const uint32_t len = static_cast<uint32_t>(o1) - static_cast<uint32_t>(o0);
+    const int32_t Lr = static_cast<int32_t>(len > static_cast<uint32_t>(room) ? static_cast<uint32_t>(room) : len);
+    const int64_t lo_b64 = -off0, hi_b64 = total_chars - off0 - 16;  // valid range of a vector's first byte, relative to off0
+    const bool can_vec = hi_b64 >= lo_b64;                           // wave-uniform (the buffer holds >= 16 bytes)
+    const int32_t lo_b = lo_b64 < INT32_MIN ? INT32_MIN : static_cast<int32_t>(lo_b64);
+    const int32_t hi_b = hi_b64 > INT32_MAX ? INT32_MAX : (hi_b64 < lo_b ? lo_b : static_cast<int32_t>(hi_b64));
+    const uint32_t span = static_cast<uint32_t>(hi_b) - static_cast<uint32_t>(lo_b);
+    const uint32_t rows_left = B - bc > 64u ? 64u : B - bc;
+    uint32_t uoff[4], qrow[4], rs[4];
+    int32_t j0[4], L[4];
+    bool live[4], slow[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // all eight cross-lane reads in flight together
+        const uint32_t tl = tc + static_cast<uint32_t>(u * 64 + lane);
+        const uint32_t q = div_p(tl);
+        qrow[u] = q;
+        j0[u] = static_cast<int32_t>((tl - q * PPR) << 4) - static_cast<int32_t>(bos);  // >= -1
+        rs[u] = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(q << 2), static_cast<int>(rel)));
+        L[u] = __builtin_amdgcn_ds_bpermute(static_cast<int>(q << 2), Lr);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        live[u] = qrow[u] < rows_left;
+        const bool need = live[u] && j0[u] < L[u];
+        const uint32_t d = rs[u] + static_cast<uint32_t>(j0[u]) - static_cast<uint32_t>(lo_b);  // offset from the lowest valid address
+        const bool fast = can_vec && need && d <= span;
+        slow[u] = need && !fast;
+        uoff[u] = fast ? d : 0u;
+    }
+    u32x4u cw[4];
+    if (can_vec) {
+        const uint8_t *cbase = chars + (off0 + lo_b);  // wave-uniform, inside the buffer
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cw[u] = *reinterpret_cast<const u32x4u *>(cbase + uoff[u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cw[u] = u32x4u{0x41434447u, 0x61636474u, 0x4B4C4D4Eu, 0x50515253u};
+    }
+    // rule entries of the four stores: LDS reads that run beside the character loads
+    uint4 keep[4], cst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int32_t dd = L[u] - j0[u];
+        const int32_t idx = (dd < -1 ? -1 : (dd > 16 ? 16 : dd)) + 1;
+        keep[u] = s_rule[wave][0][idx];
+        cst[u] = s_rule[wave][1][idx];
+    }
+    if (__builtin_amdgcn_ballot_w64(slow[0] | slow[1] | slow[2] | slow[3]) != 0) {  // first / last bytes of the buffer: never read outside it
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (slow[u]) {
+                const int64_t start = offsets[bc + qrow[u]];
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+                for (int i = 0; i < 16; ++i)
+                    if (j0[u] + i >= 0 && j0[u] + i < L[u])
+                        w[i >> 2] |= static_cast<uint32_t>(chars[start + j0[u] + i]) << (8 * (i & 3));
+                cw[u] = u32x4u{w[0], w[1], w[2], w[3]};
+            }
+        }
+    }
+    uint8_t *dst = out + static_cast<int64_t>(k0) * kChunk + lane * 16;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t in[4] = {cw[u].x, cw[u].y, cw[u].z, cw[u].w};
+        uint32_t w[4], bad = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            w[q] = lookup4_perm(in[q], T);
+            bad |= (in[q] ^ 0x40404040u) & 0xC0C0C0C0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {  // some lane holds a non-letter: exact masks (rare)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t m = nonletter_mask(in[q]);
+                w[q] = (w[q] & ~m) | (m & (none_v * 0x01010101u));
+            }
+        }
+        uint4 o;
+        o.x = (w[0] & keep[u].x) | cst[u].x;
+        o.y = (w[1] & keep[u].y) | cst[u].y;
+        o.z = (w[2] & keep[u].z) | cst[u].z;
+        o.w = (w[3] & keep[u].w) | cst[u].w;
+        if (j0[u] < 0) o.x = (o.x & ~0xFFu) | bos_id;  // position 0 with BOS
+        if (live[u]) store16<NT>(dst + u * 1024, o);
+    }
+}
+
 template <bool NT, int LK>
 void launch_variant(const T8Params &c, dim3 grid, size_t pad, hipStream_t s) {
     switch (c.abl) {
@@ -433,6 +593,27 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
     const int padv = tuning("tokens8_pad");  // unused dynamic LDS = occupancy cap (experiments)
     const size_t pad = padv > 0 ? size_t(padv) : 0;
     const bool nt = nontemporal_stores() && !raw;
+    // the fast form: register table, aligned rows, no mask, 32-bit piece indices (knob tokens8_fast = 1: never)
+    if (lk == 2 && !mask && c.abl == 0 && P % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && !c.wide_index &&
+        c.nchunks < (int64_t(1) << 23) && B < (int64_t(1) << 31) && tuning("tokens8_fast") != 1) {
+        uint32_t magic = c.magic, shift = c.shift;
+        if (c.pow2) {  // d = 2^s, s >= 3: mulhi(n, 2^(32 - s)) == n >> s
+            magic = uint32_t(1) << (32 - c.shift);
+            shift = 0;
+        }
+        const uint32_t packed = uint32_t(c.bos != 0) | (raw ? 2u : 0u) | (c.bos_id << 8) | ((c.at_len_v & 0xFFu) << 16) | ((c.fill_v & 0xFFu) << 24);
+        T8Tab tab;
+        for (int i = 0; i < 8; ++i) tab.t[i] = c.tab[i];
+        if (nt)
+            hipLaunchKernelGGL((k_tokens_bp8_fast<true>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks),
+                               uint32_t(B), c.ppr, magic, shift, c.room, packed, tab);
+        else
+            hipLaunchKernelGGL((k_tokens_bp8_fast<false>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks),
+                               uint32_t(B), c.ppr, magic, shift, c.room, packed, tab);
+        const hipError_t ef = hipGetLastError();
+        if (ef != hipSuccess) return set_hip_error("k_tokens_bp8_fast", ef);
+        return BSQ_OK;
+    }
 #define BSQ_T8(NTV, LKV) launch_variant<NTV, LKV>(c, grid, pad, s)
     if (lk == 2) { if (nt) BSQ_T8(true, 1); else BSQ_T8(false, 1); }
     else { if (nt) BSQ_T8(true, 0); else BSQ_T8(false, 0); }

@@ -30,16 +30,20 @@ def nasty_batch(seed, n, lo, hi):
     return chars, offs
 
 
-@pytest.fixture(params=[(0, 0), (0, 1), (0, 2), (1, 0)], ids=["auto", "lds-table", "register-table", "round1-kernel"])
+@pytest.fixture(params=[(0, 0, 0), (0, 1, 0), (0, 2, 0), (0, 2, 1), (1, 0, 0)],
+                ids=["auto", "lds-table", "register-table", "register-table-round2-form", "round1-kernel"])
 def variant(request):
+    """auto / register-table take k_tokens_bp8_fast (round 3) on aligned shapes; tokens8_fast = 1 keeps the round-2 form."""
     from bioseq_amd import capi
     lib = capi.load()
-    off, lookup = request.param
+    off, lookup, nofast = request.param
     capi.check(lib.bsq_tuning_set(b"tokens8", off))
     capi.check(lib.bsq_tuning_set(b"tokens8_lookup", lookup))
-    yield request.param
+    capi.check(lib.bsq_tuning_set(b"tokens8_fast", nofast))
+    yield request.param[:2]
     capi.check(lib.bsq_tuning_set(b"tokens8", 0))
     capi.check(lib.bsq_tuning_set(b"tokens8_lookup", 0))
+    capi.check(lib.bsq_tuning_set(b"tokens8_fast", 0))
 
 
 def dev_tokens(lib, capi, desc, chars, offs, P, gpu, out_shift=0):
