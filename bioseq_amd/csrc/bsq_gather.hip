@@ -1,0 +1,122 @@
+// Index-list batches out of a packed store that lives in HBM (SURVEY.md section 8 row f-3 under a shuffling sampler).
+//
+// The reference's FlatFileDataset.__getitem__ (/root/reference/bioseq/loaders.py:76-104) fetches ONE sequence per call from
+// the memory-mapped file, tokenises it on the host and lets the DataLoader stack the results; a shuffled epoch therefore
+// touches the host for every sample.  Here the whole FlatFile is uploaded once (FlatFile.to_device) and a batch of
+// arbitrary, repeated or empty sequence indices is rebuilt ON THE DEVICE as a packed batch (chars, offsets) that the
+// encode kernels consume as they are: three small launches, no host round trip, no H2D copy.
+//   k_gather_lengths  out_offsets[i + 1] <- length of sequence index[i]   (bad indices: length 0, position recorded)
+//   k_gather_scan     in-place inclusive prefix sum -> out_offsets[i + 1] = end of output sequence i  (one workgroup;
+//                     a batch is 10^3 .. 10^6 sequences: 8 MB at most, microseconds)
+//   k_gather_chars    16 lanes per output sequence copy its characters with unaligned 16-byte loads / stores
+// gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "bsq.h"
+#include "bsq_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+typedef uint32_t g_u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+
+__global__ __launch_bounds__(kThreads) void k_gather_lengths(const int64_t *offsets, int64_t n_store, const int64_t *index,
+                                                             int64_t n, int64_t *out_offsets, unsigned long long *first_bad) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (i == 0) out_offsets[0] = 0;
+    if (i >= n) return;
+    const int64_t j = index[i];
+    int64_t len = 0;
+    if (j >= 0 && j < n_store) {
+        len = offsets[j + 1] - offsets[j];
+        if (len < 0) len = 0;
+    } else {
+        atomicMin(first_bad, static_cast<unsigned long long>(i));
+    }
+    out_offsets[i + 1] = len;
+}
+
+// in-place inclusive prefix sum of v[0 .. n) by ONE workgroup of 1024 threads (pieces of 1024 with a running carry)
+__global__ __launch_bounds__(1024) void k_gather_scan(int64_t *v, int64_t n) {
+    __shared__ int64_t s_wave[16];
+    __shared__ int64_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        int64_t x = i < n ? v[i] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t o = __shfl_up(x, d, 64);
+            if (lane >= d) x += o;
+        }
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();
+        int64_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (i < n) v[i] = x + before;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = x + before;
+        __syncthreads();
+    }
+}
+
+// 16 lanes per output sequence.  capacity: bytes of out_chars; a batch that does not fit is cut there (never a write
+// past the buffer) and recorded in first_bad as position n + i.
+__global__ __launch_bounds__(kThreads) void k_gather_chars(const uint8_t *chars, const int64_t *offsets, int64_t n_store,
+                                                           const int64_t *index, int64_t n, const int64_t *out_offsets,
+                                                           uint8_t *out_chars, int64_t capacity, unsigned long long *first_bad) {
+    const int sub = threadIdx.x & 15;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * (kThreads / 16) + (threadIdx.x >> 4);
+    if (i >= n) return;
+    const int64_t j = index[i];
+    if (j < 0 || j >= n_store) return;
+    const int64_t src0 = offsets[j], d0 = out_offsets[i];
+    int64_t len = out_offsets[i + 1] - d0;
+    if (d0 + len > capacity) {
+        if (sub == 0) atomicMin(first_bad, static_cast<unsigned long long>(n + i));
+        len = capacity > d0 ? capacity - d0 : 0;
+    }
+    const uint8_t *src = chars + src0;
+    uint8_t *dst = out_chars + d0;
+    const int64_t body = len & ~int64_t(15);
+    for (int64_t p = sub * 16; p < body; p += 256)
+        *reinterpret_cast<g_u32x4u *>(dst + p) = *reinterpret_cast<const g_u32x4u *>(src + p);
+    if (sub < (len & 15)) dst[body + sub] = src[body + sub];
+}
+
+}  // namespace
+
+extern "C" {
+
+bsq_status bsq_gather_packed_device(const uint8_t *chars, const int64_t *offsets, int64_t n_store, const int64_t *index,
+                                    int64_t n, uint8_t *out_chars, int64_t out_capacity, int64_t *out_offsets,
+                                    int64_t *status_dev, void *hip_stream) {
+    if (!offsets || !out_offsets || !status_dev || n_store < 0 || n < 0 || out_capacity < 0 || (n > 0 && !index))
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_gather_packed_device: null pointer or negative size");
+    if ((n + kThreads - 1) / kThreads >= (int64_t(1) << 31) || (n + 15) / 16 >= (int64_t(1) << 31))
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "index list too long");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    hipError_t e = hipMemsetAsync(status_dev, 0xFF, sizeof(int64_t), s);  // -1 = every index valid, everything fitted
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipMemsetAsync(gather status)", e);
+    unsigned long long *bad = reinterpret_cast<unsigned long long *>(status_dev);
+    if (n == 0) {
+        e = hipMemsetAsync(out_offsets, 0, sizeof(int64_t), s);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("hipMemsetAsync(gather offsets)", e);
+        return BSQ_OK;
+    }
+    hipLaunchKernelGGL(k_gather_lengths, dim3(unsigned((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, offsets, n_store,
+                       index, n, out_offsets, bad);
+    hipLaunchKernelGGL(k_gather_scan, dim3(1), dim3(1024), 0, s, out_offsets + 1, n);
+    if (chars && out_chars && out_capacity > 0)
+        hipLaunchKernelGGL(k_gather_chars, dim3(unsigned((n + 15) / 16)), dim3(kThreads), 0, s, chars, offsets, n_store, index, n,
+                           out_offsets, out_chars, out_capacity, bad);
+    e = hipGetLastError();
+    if (e != hipSuccess) return bsq_internal::set_hip_error("k_gather_*", e);
+    return BSQ_OK;
+}
+
+}  // extern "C"

@@ -24,6 +24,10 @@
 #include "bsq_internal.h"
 
 namespace {
+std::atomic<uint64_t> g_upload_bytes{0};  // bytes this library copied host -> device (bsq_host_upload_bytes)
+}  // namespace
+
+namespace {
 
 thread_local std::string t_last_error;
 
@@ -132,6 +136,7 @@ bsq_status upload(InSlot &s, const uint8_t *chars, const int64_t *offsets, const
     bsq_status st = grow_device(&s.d_in, &s.d_in_cap, need);
     if (st != BSQ_OK) return st;
     char *base = static_cast<char *>(s.d_in);
+    g_upload_bytes.fetch_add(uint64_t(B + 1) * 8 + uint64_t(total) * (mask ? 2 : 1), std::memory_order_relaxed);
     hipError_t e = hipMemcpyAsync(base, offsets, size_t(B + 1) * 8, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess && total) e = hipMemcpyAsync(base + off_bytes, chars, total, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess && mask && total)
@@ -502,6 +507,7 @@ bsq_status bsq_tuning_set(const char *name, int32_t value) {
                                                  : bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "unknown tuning knob");
 }
 int32_t bsq_tuning_get(const char *name) { return bsq_internal::tuning(name); }
+uint64_t bsq_host_upload_bytes(void) { return g_upload_bytes.load(std::memory_order_relaxed); }
 
 int32_t bsq_device_count(void) {
     int n = 0;

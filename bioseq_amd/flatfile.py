@@ -162,6 +162,44 @@ class FlatFile:
         c0, c1 = int(self._offsets[start]), int(self._offsets[stop])
         return chars[c0:c1], o - o[0]
 
+    def gather_device(self, indices, device="cuda", validate=True):
+        """Packed batch (chars, offsets) of the sequences `indices` -- any order, repeats allowed -- rebuilt ON THE
+        DEVICE from the uploaded store (`bsq_gather_packed_device`): what a shuffling sampler needs, with no host gather
+        and no upload of characters.  `indices`: an int64 tensor already on `device` (nothing crosses PCIe at all) or a
+        host list / array (range-checked here, 8 bytes per index uploaded).  The returned `chars` tensor is
+        n * (longest sequence) bytes long; only its first offsets[-1] bytes belong to the batch."""
+        import ctypes
+        import torch
+        from . import capi
+        lib = capi.load()
+        dev = torch.device(device)
+        chars, offs = self.to_device(dev)
+        on_device = isinstance(indices, torch.Tensor) and indices.is_cuda
+        if on_device:
+            idx = indices.to(torch.int64).contiguous()
+            if idx.device != chars.device:
+                raise ValueError("indices live on %s, the store on %s" % (idx.device, chars.device))
+        else:
+            host = np.ascontiguousarray(np.asarray(indices, dtype=np.int64).ravel())
+            if host.size and (host.min() < 0 or host.max() >= self._n):
+                raise IndexError("Accessing sequence out of range")
+            idx = torch.from_numpy(host).to(dev)
+        n = idx.numel()
+        longest = int(np.diff(self._offsets).max()) if self._n else 0
+        capacity = n * longest
+        out_chars = torch.empty(max(capacity, 1), dtype=torch.uint8, device=dev)
+        out_offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        status = torch.empty(1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), self._n, idx.data_ptr(), n,
+                                                    out_chars.data_ptr(), capacity, out_offs.data_ptr(), status.data_ptr(), stream))
+        if on_device and validate:  # the only synchronising step, and only for index tensors nobody has checked
+            bad = int(status.item())
+            if bad >= 0:
+                raise IndexError("Accessing sequence out of range (position %d of the index list)" % (bad % max(n, 1)))
+        return out_chars, out_offs
+
     def batch_tokenize(self, tokenizer, start=0, stop=None, padlen=None, destchar="B", batch_first=True, device=None):
         """`tokenizer.batch_tokenize(ff.access(start, stop), ...)` without materialising the sequences
         (cf. FF2NP, bioseq/loaders.py:11-26).  padlen defaults to maxseqlen + bos + eos."""

@@ -64,15 +64,8 @@ class FlatFileDataset(torch.utils.data.Dataset):
             chars, offs = self.ff.packed_device(start, stop, self.device)
             if self.augment:
                 chars = chars.clone()  # never mutate the resident store
-        else:  # arbitrary index set: gather on the host side of the mapped file, one upload
-            hc, ho = self.ff.packed(0, None)
-            lens = (ho[1:] - ho[:-1])[indices]
-            offs_np = np.zeros(len(indices) + 1, dtype=np.int64)
-            np.cumsum(lens, out=offs_np[1:])
-            buf = np.empty(int(offs_np[-1]), dtype=np.uint8)
-            for k, i in enumerate(indices):
-                buf[offs_np[k]:offs_np[k + 1]] = hc[ho[i]:ho[i + 1]]
-            chars, offs = torch.from_numpy(buf).to(self.device), torch.from_numpy(offs_np).to(self.device)
+        else:  # arbitrary index set (a shuffling sampler): rebuilt on the device from the resident store, no host gather
+            chars, offs = self.ff.gather_device(indices, self.device)
         if self.augment:
             self._calls += 1
             blosum.augment_packed(chars, offs, self.augment, self.augment_frac, self._seed + self._calls)
@@ -81,7 +74,8 @@ class FlatFileDataset(torch.utils.data.Dataset):
     def _encode(self, chars, offs):
         if self.cnn:
             return self.tokenizer.onehot_packed(chars, offs, self.max_seq_len, "f", layout="bcl")
-        return self.tokenizer.tokenize_packed(chars, offs, self.max_seq_len, "B", True).to(torch.long)
+        # int64 rows written by the kernel itself ('q'), not int8 + a .to(torch.long) pass over the matrix
+        return self.tokenizer.tokenize_packed(chars, offs, self.max_seq_len, "q", True)
 
     def get_batch(self, start, stop):
         """Sequences [start, stop) as one encoded batch on the device."""
@@ -99,11 +93,28 @@ class FlatFileDataset(torch.utils.data.Dataset):
     def __getitems__(self, indices):
         """One encoded batch ON THE DEVICE for the whole index list -- a single stacked tensor, not a list of samples:
         use `DataLoader(ds, batch_size=..., collate_fn=lambda batch: batch, num_workers=0)` (the default collate would
-        re-stack it with a copy, and device tensors cannot cross worker processes)."""
+        re-stack it with a copy, and device tensors cannot cross worker processes).  A list of host integers costs one
+        upload of 8 bytes per index; an int64 tensor on the device (see `batches`) costs none."""
+        if isinstance(indices, torch.Tensor) and indices.is_cuda:
+            return self._encode(*self._packed_device(0, 0, indices))
         idx = [self._index(i) for i in indices]
         if idx and idx == list(range(idx[0], idx[0] + len(idx))):
             return self.get_batch(idx[0], idx[-1] + 1)
         return self._encode(*self._packed_device(0, 0, idx))
+
+    def batches(self, batch_size, shuffle=True, drop_last=False, generator=None):
+        """One epoch of encoded batches with the sampler ON THE DEVICE: a `torch.randperm` drawn on `self.device` (or the
+        identity), cut into index tensors that never leave HBM.  Nothing is copied host -> device per batch: the store is
+        resident (FlatFile.to_device), the indices are device tensors, the batch is gathered, augmented and encoded there.
+        Yields (B, P) int64 tokens or (B, C, P) float32 one-hots, like `__getitems__`."""
+        n = len(self)
+        order = (torch.randperm(n, device=self.device, generator=generator) if shuffle
+                 else torch.arange(n, device=self.device))
+        for first in range(0, n, batch_size):
+            idx = order[first:first + batch_size]
+            if drop_last and idx.numel() < batch_size:
+                return
+            yield self._encode(*self._packed_device(0, 0, idx)) if shuffle else self.get_batch(first, min(n, first + batch_size))
 
     def __getitem__(self, index):
         if isinstance(index, slice):

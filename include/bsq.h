@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSQ_ABI_VERSION 2
+#define BSQ_ABI_VERSION 3
 
 typedef int32_t bsq_status;
 enum {
@@ -175,6 +175,20 @@ bsq_status bsq_argmax_tokens_device(const void *logits, int32_t logit_kind, int6
 bsq_status bsq_blosum62_normrows(double *out21x20);
 bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len, double frac,
                               uint64_t seed, void *hip_stream);
+
+/* ---- index-list batches from a packed store resident in HBM: replaces the per-item fetch of FlatFileDataset.__getitem__
+ * (bioseq/loaders.py:76-104: ff.access(i) on the host for every sample) under a shuffling sampler.  Rebuilds the packed
+ * batch of sequences index[0 .. n) of the store (chars, offsets: n_store sequences) on the device:
+ *     out_offsets[0] = 0, out_offsets[i + 1] - out_offsets[i] = length of sequence index[i];
+ *     out_chars[out_offsets[i] .. out_offsets[i + 1]) = its characters
+ * -- ready for bsq_tokenize_device / bsq_onehot_device / bsq_onehot_bcl_device / bsq_augment_device.  Indices may
+ * repeat, in any order; empty sequences are fine.  Stream-ordered, never synchronises: errors are left in *status_dev
+ * (device int64): -1 = ok, i in [0, n) = index[i] was out of range (it contributes an empty sequence), n + i = output
+ * sequence i did not fit into out_capacity bytes (the batch is cut there, nothing is written past the buffer).
+ * out_capacity = n * (longest sequence of the store) always suffices.  out_chars may be NULL to get the offsets only. */
+bsq_status bsq_gather_packed_device(const uint8_t *chars, const int64_t *offsets, int64_t n_store, const int64_t *index,
+                                    int64_t n, uint8_t *out_chars, int64_t out_capacity, int64_t *out_offsets,
+                                    int64_t *status_dev, void *hip_stream);
 
 /* ---- host entry points: packed batch in HOST memory (pageable or pinned).  The library stages
  * it through its own pinned + device buffers on the current HIP device, runs the device entry

@@ -18,6 +18,10 @@ extern "C" {
 bsq_status bsq_tuning_set(const char *name, int32_t value);
 int32_t bsq_tuning_get(const char *name);
 
+/* Bytes the *_host entry points have copied host -> device since the library was loaded (the device entry points copy
+ * nothing).  The loader tests assert that a shuffled epoch over a resident FlatFile leaves it unchanged. */
+uint64_t bsq_host_upload_bytes(void);
+
 /* Streaming fill of nbytes (multiple of 16, 16-byte aligned) with a 32-bit pattern: the
  * write-bandwidth yardstick bench.py reports next to the encode kernels. */
 bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip_stream);

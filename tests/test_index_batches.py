@@ -1,0 +1,158 @@
+"""SURVEY.md section 8 row f-3 under a SHUFFLING sampler (missing #5 / item 6): batches of arbitrary
+sequence indices -- repeats, empty sequences, any order -- rebuilt on the device from the resident FlatFile
+(bsq_gather_packed_device) and encoded there.  Reference behaviour: FlatFileDataset.__getitem__ tokenises ff.access(i) per
+item on the host (bioseq/loaders.py:76-104); expected values are the CPU oracle's encode of the same sequences in the
+same order.  A shuffled epoch must not copy anything host -> device per batch."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from bioseq_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make_store(tmp_path, seed=17, n=3000, lo=0, hi=300, letters=None):
+    from bioseq_amd.flatfile import FlatFile, write_flatfile
+    chars, offs = synth.synth_packed(seed, n, lo, hi, letters or synth.AA)
+    seqs = synth.unpack(chars, offs)
+    return FlatFile(write_flatfile(seqs, str(tmp_path / "store.ff"))), seqs
+
+
+def test_gather_c_abi_rebuilds_the_packed_batch(gpu, tmp_path):
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    ff, seqs = make_store(tmp_path, n=2000, lo=0, hi=200, letters=synth.DIRTY)
+    chars, offs = ff.to_device(gpu)
+    rng = np.random.default_rng(3)
+    empties = [i for i, s in enumerate(seqs) if len(s) == 0]
+    assert empties
+    for n in (0, 1, 5, 64, 1000, 5000):
+        idx = rng.integers(0, len(seqs), size=n)
+        if n >= 5:
+            idx[:2] = idx[2]                    # repeats
+            idx[3] = empties[0]                 # an empty sequence
+            idx[4] = len(seqs) - 1              # the last one (ends at the end of the store)
+        want = b"".join(bytes(seqs[i]) for i in idx)
+        want_offs = np.concatenate([[0], np.cumsum([len(seqs[i]) for i in idx])]).astype(np.int64)
+        d_idx = torch.from_numpy(idx.astype(np.int64)).to(gpu)
+        cap = max(1, n * 200)
+        out_c = torch.full((cap + 32,), 0xEE, dtype=torch.uint8, device=gpu)
+        out_o = torch.empty(n + 1, dtype=torch.int64, device=gpu)
+        st = torch.empty(1, dtype=torch.int64, device=gpu)
+        capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), len(seqs), d_idx.data_ptr(), n,
+                                                out_c.data_ptr(), cap, out_o.data_ptr(), st.data_ptr(), None))
+        assert int(st.item()) == -1
+        assert (out_o.cpu().numpy() == want_offs).all()
+        host = out_c.cpu().numpy()
+        assert host[:len(want)].tobytes() == want
+        assert (host[cap:] == 0xEE).all()                                  # nothing behind the capacity
+    # bad indices and a capacity that is too small are reported in the status word, never written out of bounds
+    idx = torch.tensor([3, len(seqs), 5, -1], dtype=torch.int64, device=gpu)
+    out_c = torch.full((1024,), 0xEE, dtype=torch.uint8, device=gpu)
+    out_o = torch.empty(5, dtype=torch.int64, device=gpu)
+    st = torch.empty(1, dtype=torch.int64, device=gpu)
+    capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), len(seqs), idx.data_ptr(), 4, out_c.data_ptr(), 1024,
+                                            out_o.data_ptr(), st.data_ptr(), None))
+    assert int(st.item()) == 1
+    o = out_o.cpu().numpy()
+    assert o[2] - o[1] == 0 and o[4] - o[3] == 0                           # invalid entries contribute empty sequences
+    long_ones = [i for i, s in enumerate(seqs) if len(s) > 100][:3]
+    idx = torch.tensor(long_ones, dtype=torch.int64, device=gpu)
+    out_c = torch.full((300,), 0xEE, dtype=torch.uint8, device=gpu)
+    capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), len(seqs), idx.data_ptr(), 3, out_c.data_ptr(), 150,
+                                            out_o.data_ptr(), st.data_ptr(), None))
+    assert int(st.item()) == 3 + 1                                         # output sequence 1 did not fit
+    assert (out_c.cpu().numpy()[150:] == 0xEE).all()
+
+
+@pytest.mark.parametrize("cnn", [False, True])
+def test_shuffled_batches_equal_the_oracle_on_the_permuted_sequences(gpu, bsq, oracle, tmp_path, cnn):
+    import torch
+    from bioseq_amd.loaders import FlatFileDataset
+    ff, seqs = make_store(tmp_path, n=1500, lo=0, hi=180)
+    tok, ora = bsq.pbeos_tokenizers["PROTEIN"], oracle.OracleTokenizer("PROTEIN", 1, 1, 1)
+    ds = FlatFileDataset(ff, tok, cnn=cnn, device=gpu)
+    P = ds.max_seq_len
+
+    def expect(idx):
+        pick = [seqs[i] for i in idx]
+        if cnn:
+            return np.ascontiguousarray(ora.batch_onehot_encode(pick, padlen=P, destchar="f").transpose(1, 2, 0))
+        return ora.batch_tokenize(pick, padlen=P, batch_first=True).astype(np.int64)
+
+    rng = np.random.default_rng(11)
+    for n in (1, 7, 257, 1500, 4000):                       # 4000 > len(ds): indices repeat
+        idx = rng.integers(0, 1500, size=n).tolist()
+        got = ds.__getitems__(idx)                           # host index list: validated here, 8 bytes per index uploaded
+        assert got.is_cuda and got.dtype == (torch.float32 if cnn else torch.int64)
+        assert got.cpu().numpy().tobytes() == expect(idx).tobytes()
+        got = ds.__getitems__(torch.tensor(idx, device=gpu))  # device index tensor
+        assert got.cpu().numpy().tobytes() == expect(idx).tobytes()
+    assert ds.__getitems__([-1, 0, -1500]).cpu().numpy().tobytes() == expect([1499, 0, 0]).tobytes()   # Python indexing
+    with pytest.raises(IndexError):
+        ds.__getitems__([0, 1500])
+    with pytest.raises(IndexError):
+        ff.gather_device(torch.tensor([0, 1500], device=gpu), gpu)           # device indices are checked on the device
+    # a shuffled DataLoader epoch (host sampler): every sequence once, each batch equal to the oracle on its indices
+    g = torch.Generator().manual_seed(5)
+    sampler = torch.utils.data.BatchSampler(torch.utils.data.RandomSampler(ds, generator=g), batch_size=256, drop_last=False)
+    batches = list(sampler)
+    dl = torch.utils.data.DataLoader(ds, batch_sampler=batches, collate_fn=lambda x: x)
+    seen = []
+    for idx, got in zip(batches, dl):
+        assert got.cpu().numpy().tobytes() == expect(idx).tobytes()
+        seen += idx
+    assert sorted(seen) == list(range(1500))
+
+
+def test_a_shuffled_epoch_copies_nothing_host_to_device(gpu, bsq, oracle, tmp_path, monkeypatch):
+    """The device-side sampler (`FlatFileDataset.batches`): permutation drawn on the device, index tensors never leave HBM,
+    batches gathered + augmented + encoded there.  Counters: the library's own host -> device byte count
+    (bsq_host_upload_bytes) and every torch host -> device path (Tensor.to / .cuda / torch.tensor(device=) / from_numpy)."""
+    import torch
+    from bioseq_amd import capi
+    from bioseq_amd.loaders import AugmentedSeqDataset, FlatFileDataset
+    lib = capi.load()
+    ff, seqs = make_store(tmp_path, n=2048, lo=1, hi=120)
+    tok, ora = bsq.Tokenizer("SEB8", 1, 1, 1), oracle.OracleTokenizer("SEB8", 1, 1, 1)
+    ds = FlatFileDataset(ff, tok, device=gpu)
+    aug = AugmentedSeqDataset(ff, tok, device=gpu)
+    ds.get_batch(0, 4), aug.get_batch(0, 4)                  # upload the store, build the tables: untimed set-up
+    torch.cuda.synchronize()
+    uploads = []
+    real_to, real_cuda = torch.Tensor.to, torch.Tensor.cuda
+
+    def to(self, *a, **k):
+        out = real_to(self, *a, **k)
+        if not self.is_cuda and out.is_cuda:
+            uploads.append(("to", self.numel() * self.element_size()))
+        return out
+
+    def cuda(self, *a, **k):
+        if not self.is_cuda:
+            uploads.append(("cuda", self.numel() * self.element_size()))
+        return real_cuda(self, *a, **k)
+    monkeypatch.setattr(torch.Tensor, "to", to)
+    monkeypatch.setattr(torch.Tensor, "cuda", cuda)
+    before = lib.bsq_host_upload_bytes()
+    g = torch.Generator(device=gpu).manual_seed(99)
+    total, order = 0, []
+    for batch in ds.batches(200, shuffle=True, generator=g):
+        assert batch.is_cuda and batch.dtype == torch.int64
+        total += batch.shape[0]
+        order.append(batch)
+    for batch in aug.batches(200, shuffle=True):
+        assert batch.is_cuda
+    torch.cuda.synchronize()
+    assert lib.bsq_host_upload_bytes() == before, "the library copied host -> device during the epoch"
+    assert uploads == [], uploads
+    monkeypatch.undo()
+    assert total == 2048
+    # the epoch is a permutation of the oracle's rows (same generator -> same order)
+    g = torch.Generator(device=gpu).manual_seed(99)
+    perm = torch.randperm(2048, device=gpu, generator=g).cpu().numpy()
+    exp = ora.batch_tokenize([seqs[i] for i in perm], padlen=ds.max_seq_len, batch_first=True).astype(np.int64)
+    assert torch.cat(order).cpu().numpy().tobytes() == exp.tobytes()
