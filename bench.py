@@ -117,6 +117,64 @@ def cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, cap_threads=Non
                                         % (B1, int(o1[-1]), nbytes1 / 1e9)}}
 
 
+def e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev):
+    """PCIe-inclusive timings of the DROP-IN surface (bioseq.Tokenizer's Python API) on the same batch -- reported beside the
+    kernel numbers, never part of `value`: list[bytes] -> device tensor (every call synchronised, and 20 calls back to back),
+    list[bytes] -> numpy (the reference's default return type: includes the D2H copy of the result), packed batch resident
+    in HBM -> device tensor including the allocation of the result.  Median of 10 (numpy return: of 5)."""
+    import torch
+    import bioseq_amd
+    from bioseq_amd import synth
+    P = cfg["padlen"]
+    tok = bioseq_amd.Tokenizer(cfg["key"], bool(cfg["eos"]), bool(cfg["bos"]), bool(cfg["padchar"]))
+    seqs = synth.unpack(chars, offsets)
+    nthreads = min(8, os.cpu_count() or 1)
+    d_chars, d_offs = torch.from_numpy(chars).to(dev), torch.from_numpy(offsets).to(dev)
+
+    def call(device, nt=nthreads):
+        if op == "onehot":
+            return tok.batch_onehot_encode(seqs, padlen=P, destchar=destchar, nthreads=nt, device=device)
+        return tok.batch_tokenize(seqs, padlen=P, destchar=destchar, batch_first=batch_first, nthreads=nt, device=device)
+
+    def packed():
+        if op == "onehot":
+            return tok.onehot_packed(d_chars, d_offs, P, destchar)
+        return tok.tokenize_packed(d_chars, d_offs, P, destchar, batch_first)
+
+    def median_ms(fn, n):
+        r = fn()
+        del r
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+            del r
+        return float(np.median(ts) * 1e3)
+
+    def pipelined_ms(fn, n=20):
+        r = fn()
+        del r
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+            del r
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    out = {"nthreads": nthreads, "sequences": len(seqs), "host_cpus": os.cpu_count(),
+           "list_to_device_sync_ms": median_ms(lambda: call(dev), 10),
+           "list_to_device_sync_default_nthreads_ms": median_ms(lambda: (tok.batch_onehot_encode(seqs, padlen=P, destchar=destchar, device=dev) if op == "onehot" else tok.batch_tokenize(seqs, padlen=P, destchar=destchar, batch_first=batch_first, device=dev)), 10),
+           "list_to_device_pipelined20_ms": float(np.median([pipelined_ms(lambda: call(dev)) for _ in range(3)])),
+           "packed_resident_to_device_incl_alloc_ms": median_ms(packed, 10),
+           "list_to_numpy_ms": median_ms(lambda: call(None), 5),
+           "note": "PCIe-inclusive, synthetic list of %d bytes objects; never part of `value`" % len(seqs)}
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher around it: start
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>`
@@ -141,6 +199,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)  # the first ~10 launches after idle run 3-8 % slow (clock ramp)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive timings of the Python surface (N = 1 only)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 1 s sustained loop (N = 1 only)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap the CPU baseline's thread count")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="weak: every rank encodes a batch of the workload's size (default); strong: ONE batch of that "
@@ -258,20 +318,46 @@ def main():
         if not os.environ.get("BSQ_BENCH_SKIP_SANITY"):
             assert ones == expect, ("one-hot sanity failed", ones, expect)
 
-    # write-bandwidth yardstick: a plain fill (one 1-KiB store per wave, one aligned 4-KiB chunk per workgroup,
-    # blocks in address order) over the same output buffer.  Measured BEFORE the warm-up steps: its launches
-    # also lift the clocks out of idle, so that a small --warmup does not time the clock ramp.
+    # write-bandwidth yardstick: a plain fill (one 1-KiB store per wave, one aligned 4-KiB chunk per workgroup, blocks in
+    # address order) over the same output buffer, in its BEST-KNOWN configuration: 3 resident workgroups per CU (unused
+    # LDS as the cap; profiles/r01/fill_occupancy.txt: 6.84 TB/s uncapped, 7.38 at 3 per CU), and uncapped for reference.
+    # Measured BEFORE the warm-up steps: its launches also lift the clocks out of idle.
     capi.check(lib.bsq_tuning_set(b"fill_mode", 1))
     fill_bytes = (out_bytes // 16) * 16
-    for _ in range(10):
-        capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh))
-    fa, fb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fa.record(stream)
-    for _ in range(5):
-        capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh))
-    fb.record(stream)
+
+    def timed_loop(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(n):
+            fn()
+        b.record(stream)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n  # ms
+
+    fill_gbps = {}
+    for name, pad in (("uncapped", 0), ("3_workgroups_per_cu", 53000)):
+        capi.check(lib.bsq_tuning_set(b"fill_pad", pad))
+        fill_gbps[name] = fill_bytes / (timed_loop(lambda: capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh)), 5, 10) * 1e-3) / 1e9
+    capi.check(lib.bsq_tuning_set(b"fill_pad", 0))
+    fill_best = max(fill_gbps.values())
+    # read + write yardstick of the token workloads: the kernel's stream shape (one wave = one aligned 4-KiB chunk of the
+    # output + its share of the characters, two dependent load steps like offsets -> characters) with none of its work
+    mix_gbps = None
+    if op in ("tokenize", "augment+tokenize") and batch_first and sz == 1 and out_bytes % 4096 == 0 and total >= 16:
+        src_bytes = (total // 16) * 16
+        mix_ms = timed_loop(lambda: capi.check(lib.bsq_copy_mix_device(out.data_ptr(), out_bytes, d_chars.data_ptr(), src_bytes, 1, 1, sh)), 20, 10)
+        mix_gbps = (src_bytes + out_bytes) / (mix_ms * 1e-3) / 1e9
+    # what one event pair around ONE tiny launch reads: the floor under every per-step event time below
+    tiny = torch.empty(4096, dtype=torch.uint8, device=dev)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in pairs:
+        a.record(stream)
+        capi.check(lib.bsq_fill_device(tiny.data_ptr(), 4096, 0, sh))
+        b.record(stream)
     torch.cuda.synchronize()
-    fill_gbps = fill_bytes * 5 / (fa.elapsed_time(fb) * 1e-3) / 1e9
+    event_floor_ms = float(np.median([a.elapsed_time(b) for a, b in pairs]))
 
     for _ in range(args.warmup):
         step()
@@ -302,6 +388,24 @@ def main():
     kern_avg_ms = float(np.mean(kern_ms))
     if os.environ.get("BSQ_BENCH_DUMP"):  # per-step device times, for variance hunting
         print("per-step ms:", " ".join("%.3f" % v for v in kern_ms), file=sys.stderr)
+
+    # Sustained: the same step looped for at least one second of wall clock (clocks, thermals), untimed for `value`.
+    sustained = None
+    if world == 1 and not args.no_sustained:
+        n_sus = max(args.steps, int(1.05 / max(loop_ms * 1e-3, 1e-6)))
+        sa, sb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        sa.record(stream)
+        for _ in range(n_sus):
+            step()
+        sb.record(stream)
+        torch.cuda.synchronize()
+        sus_wall = time.perf_counter() - w0
+        sus_ms = sa.elapsed_time(sb) / n_sus
+        sustained = {"steps": n_sus, "wall_s": sus_wall, "ms_per_step": sus_wall / n_sus * 1e3, "kernel_avg_ms": sus_ms,
+                     "frac": algo_bytes / (sus_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "frac_wall": algo_bytes / (sus_wall / n_sus) / 1e9 / HBM_PEAK_GBPS}
 
     gather_info = None
     if world > 1 and args.gather > 0:
@@ -409,11 +513,20 @@ def main():
                          "kernel_avg_ms_per_step_events": kern_avg_ms,  # second, untimed pass: one event pair per step
                          "frac_per_step_events": algo_bytes / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "kernel_min_ms": float(np.min(kern_ms)), "kernel_median_ms": float(np.median(kern_ms)),
-                         "fill_yardstick_gbps": fill_gbps,
-                         "frac_of_fill": (out_bytes / (loop_ms * 1e-3) / 1e9) / fill_gbps},
+                         "event_pair_floor_ms": event_floor_ms,  # one event pair around one 4-KiB fill: what per-step events add
+                         "traffic_source": ("profiles/traffic.json (separate rocprofv3 --pmc passes of this workload, committed; "
+                                            "not measured in this run)") if traffic is not None else None,
+                         "fill_yardstick_gbps": fill_best, "fill_yardsticks_gbps": fill_gbps,
+                         "frac_of_fill": (out_bytes / (loop_ms * 1e-3) / 1e9) / fill_best,
+                         "copy_mix_yardstick_gbps": mix_gbps,
+                         "frac_of_copy_mix": (achieved / mix_gbps) if mix_gbps else None},
         }
+        if sustained is not None:
+            res["sustained"] = sustained
         if gather_info is not None:
             res["gather"] = gather_info
+        if world == 1 and not args.no_e2e and op in ("onehot", "tokenize"):
+            res["e2e"] = e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, args.cpu_threads or None)
         print(json.dumps(res), flush=True)

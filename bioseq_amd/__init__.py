@@ -32,7 +32,7 @@ except ImportError as _e:  # fail loudly: the HIP extension IS the product
 from .cbioseq import Threading, Tokenizer, get_num_threads, set_num_threads  # noqa: F401
 from . import synth  # noqa: F401
 from . import blosum, sharding  # noqa: F401
-from .flatfile import FlatFile  # noqa: F401  (bioseq.FlatFile, /root/reference/src/fxstats.cpp:166-200)
+from .flatfile import FlatFile, getstats  # noqa: F401  (bioseq.FlatFile / getstats, /root/reference/src/fxstats.cpp:166-219)
 
 __version__ = "0.1.0"
 
@@ -161,4 +161,4 @@ __all__ = ["onehot_encode", "cbioseq", "f_encode", "Tokenizer", "make_embedding"
            "pos_tokenizers", "default_tokenizers", "total_tokenizer_dict", "get_tokenizer_dict", "DNATokenizer",
            "AmineTokenizer", "Reduced6Tokenizer", "Reduced8Tokenizer", "Reduced10Tokenizer", "Reduced14Tokenizer",
            "DayhoffTokenizer", "LIATokenizer", "LIBTokenizer", "torchify", "set_num_threads", "get_num_threads",
-           "Threading", "device_count", "synth", "blosum", "sharding", "FlatFile", "loaders"]
+           "Threading", "device_count", "synth", "blosum", "sharding", "FlatFile", "getstats", "loaders"]

@@ -21,7 +21,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libbsq_hip.so")
 EXT = os.path.join(HERE, "cbioseq" + sysconfig.get_config_var("EXT_SUFFIX"))
 
-LIB_SRCS = ["bsq_kernels.hip", "bsq_tokens8.hip", "bsq_decode.hip", "bsq_augment.hip", "bsq_gather.hip", "bsq_diag.hip", "bsq_host.cpp", "bsq_alphabet.cpp"]
+LIB_SRCS = ["bsq_kernels.hip", "bsq_tokens8.hip", "bsq_decode.hip", "bsq_augment.hip", "bsq_gather.hip", "bsq_diag.hip", "bsq_host.cpp", "bsq_alphabet.cpp", "bsq_fastx.cpp"]
 LIB_DEPS = LIB_SRCS + ["bsq_internal.h", "bsq_device.h"]
 EXT_SRCS = ["cbioseq_module.cpp"]
 
@@ -69,7 +69,7 @@ def build_lib(force=False):
         with open(stamp, "w") as fh:
             fh.write(" ".join(extra))
     if jobs or not os.path.exists(LIB):
-        _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
+        _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-lz"])
     return LIB
 
 

@@ -25,6 +25,11 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <pthread.h>
+
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <vector>
 
 #include "bsq.h"
@@ -52,6 +57,98 @@ int default_threads() {
     if (t > 0) return t;
     const unsigned hc = std::thread::hardware_concurrency();
     return hc ? int(hc) : 1;
+}
+
+// Persistent host workers for the two parallel phases of a list-of-objects call (item scan, pinned pack): creating and
+// joining 2 x nthreads std::threads per call cost 0.2-0.4 ms of a 2.7 ms call (profiles/r02/e2e_python_api.txt: 32 threads
+// were SLOWER than 8).  parallel_for(n, fn) runs fn(t) for t in [0, n) -- t = 0 on the caller -- and returns when all are
+// done.  Workers only ever touch raw bytes (never the interpreter), the caller keeps the GIL meanwhile, so the items stay
+// alive.  One job at a time (g_pack_mu / the GIL serialise the callers).
+class WorkerPool {
+  public:
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+    void parallel_for(int n, const std::function<void(int)> &fn) {
+        if (n <= 1) {
+            if (n == 1) fn(0);
+            return;
+        }
+        std::unique_lock<std::mutex> job_lock(job_mu_);  // one job at a time
+        grow(n - 1);
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            fn_ = &fn;
+            next_ = 1;
+            limit_ = n;
+            pending_ = n - 1;
+            ++generation_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> l(mu_);
+        done_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void grow(int want) {
+        std::lock_guard<std::mutex> l(mu_);
+        while (int(threads_.size()) < want && threads_.size() < 256) threads_.emplace_back([this] { run(); });
+    }
+    void run() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> l(mu_);
+        for (;;) {
+            cv_.wait(l, [&] { return stop_ || (generation_ != seen && next_ < limit_); });
+            if (stop_) return;
+            while (next_ < limit_) {
+                const int t = next_++;
+                const std::function<void(int)> *fn = fn_;
+                l.unlock();
+                (*fn)(t);
+                l.lock();
+                if (--pending_ == 0) done_.notify_all();
+            }
+            seen = generation_;
+        }
+    }
+    std::mutex mu_, job_mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int next_ = 0, limit_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+// Leaked on purpose (joining threads during interpreter shutdown can deadlock); a forked child starts with a fresh pool
+// (the parent's worker threads do not exist there).
+std::atomic<WorkerPool *> g_pool{nullptr};
+WorkerPool &pool() {
+    WorkerPool *p = g_pool.load(std::memory_order_acquire);
+    if (!p) {
+        static std::once_flag atfork;
+        std::call_once(atfork, [] { pthread_atfork(nullptr, nullptr, [] { g_pool.store(nullptr, std::memory_order_release); }); });
+        WorkerPool *fresh = new WorkerPool();
+        if (g_pool.compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) p = fresh;
+        else delete fresh;
+    }
+    return *p;
+}
+
+// nthreads of a batch call: the reference's default is 1 and an explicit value is honoured; the DEFAULT here is 0 =
+// automatic: one thread for small batches, min(get_num_threads(), 16) host threads for the scan + pack of >= 8192 items
+// (the encode itself runs on the GPU whatever the value).
+int resolve_threads(int nthreads, Py_ssize_t nitems) {
+    if (nthreads > 0) return nthreads;
+    if (nitems < 8192) return 1;
+    const int t = default_threads();
+    return t > 16 ? 16 : (t < 1 ? 1 : t);
 }
 
 [[noreturn]] void throw_status(bsq_status st, const std::string &extra = std::string()) {
@@ -102,10 +199,11 @@ inline bool fast_item(PyObject *o, Item *it) {
 // arrays too but falls through to its error label; they are accepted here.)
 // Large batches without a mask list are first scanned by `nthreads` workers (the scan is bound by the cache
 // misses on 64k object headers); whatever is not a plain bytes / bytearray / ASCII str is left to the serial pass.
-void gather(py::sequence batch, const py::object &mask, Gathered &g, int nthreads = 1) {
+void gather(py::sequence batch, const py::object &mask, Gathered &g, int &nthreads) {
     py::object fast = py::reinterpret_steal<py::object>(PySequence_Fast(batch.ptr(), "batch must be a sequence"));
     if (!fast) throw py::error_already_set();
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast.ptr());
+    nthreads = resolve_threads(nthreads, n);
     PyObject **objs = PySequence_Fast_ITEMS(fast.ptr());
     g.keep.push_back(fast);
     const bool mask_is_list = py::isinstance<py::list>(mask);  // anything else is ignored (tokenize.h:294)
@@ -129,10 +227,7 @@ void gather(py::sequence batch, const py::object &mask, Gathered &g, int nthread
                 }
             part[size_t(t)] = sum;
         };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nthreads; ++t) th.emplace_back(scan, t);
-        scan(0);
-        for (auto &x : th) x.join();
+        pool().parallel_for(nthreads, scan);
         for (size_t v : part) g.total += v;
     } else {
         g.items.reserve(size_t(n));
@@ -225,11 +320,42 @@ Packed pack(const Gathered &g, int nthreads) {
     };
     if (nthreads <= 1 || g.total < (size_t(1) << 20) || p.B < 2 * nthreads) {
         copy_range(0, p.B);
-    } else {  // workers touch raw bytes only; the caller keeps the GIL so the items stay alive
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; ++t)
-            th.emplace_back(copy_range, p.B * t / nthreads, p.B * (t + 1) / nthreads);
-        for (auto &x : th) x.join();
+    } else {
+        // Workers touch raw bytes only; the caller keeps the GIL so the items stay alive.  The batch is cut into pieces of
+        // ~1 MB that the workers take in order; whoever completes the piece at the upload frontier hands everything up to
+        // there to the library (bsq_pinned_commit), so the H2D copy of the head runs while the tail is still being packed.
+        (void)bsq_pinned_commit(p.chars);  // the offsets go first
+        const int64_t B = p.B;
+        const int64_t npieces = std::min<int64_t>(512, std::max<int64_t>(nthreads, int64_t(g.total >> 20)));
+        std::vector<int64_t> cut(size_t(npieces) + 1, B);
+        cut[0] = 0;
+        for (int64_t k = 1, i = 0; k < npieces; ++k) {  // piece k starts at the first sequence at or behind k / npieces of the bytes
+            const int64_t target = int64_t(g.total / size_t(npieces)) * k;
+            while (i < B && p.offsets[i] < target) ++i;
+            cut[size_t(k)] = i;
+        }
+        std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[size_t(npieces)]);
+        for (int64_t k = 0; k < npieces; ++k) done[size_t(k)].store(0, std::memory_order_relaxed);
+        std::atomic<int64_t> next{0};
+        std::mutex frontier_mu;
+        int64_t frontier = 0;
+        pool().parallel_for(nthreads, [&](int) {
+            for (;;) {
+                const int64_t k = next.fetch_add(1, std::memory_order_relaxed);
+                if (k >= npieces) return;
+                copy_range(cut[size_t(k)], cut[size_t(k) + 1]);
+                done[size_t(k)].store(1, std::memory_order_release);
+                if (p.mask) continue;  // (chars | mask are two regions: the mask goes with the final upload)
+                std::unique_lock<std::mutex> l(frontier_mu, std::try_to_lock);
+                if (!l.owns_lock()) continue;
+                int64_t f = frontier;
+                while (f < npieces && done[size_t(f)].load(std::memory_order_acquire)) ++f;
+                if (f > frontier) {
+                    frontier = f;
+                    (void)bsq_pinned_commit(p.chars + p.offsets[cut[size_t(f)]]);
+                }
+            }
+        });
     }
     return p;
 }
@@ -373,9 +499,8 @@ class Tokenizer {
                               int nthreads, const py::object &device) const {
         const bsq_dtype t = parse_dtype(dt);
         check_padlen(padlen);
-        if (nthreads <= 0) nthreads = 1;
         Gathered g;
-        gather(batch, py::none(), g, nthreads);
+        gather(batch, py::none(), g, nthreads);  // (resolves nthreads = 0 to the automatic count)
         PackLock lock;
         OutBuf out;  // first: it makes `device=` the current device, so the pinned scratch and the staging
                      // buffers used by pack() and by the encode call belong to the same device
@@ -406,7 +531,6 @@ class Tokenizer {
         const bool bcl = parse_layout(layout);
         const bsq_dtype t = parse_dtype(dt);
         check_padlen(padlen);
-        if (nthreads <= 0) nthreads = 1;
         static const bool prof = std::getenv("BSQ_PROFILE_HOST") != nullptr;  // per-phase host times on stderr
         const auto t0 = std::chrono::steady_clock::now();
         Gathered g;
@@ -794,10 +918,10 @@ PYBIND11_MODULE(cbioseq, m) {
         .def(py::init<std::string, bool, bool, bool>(), py::arg("key"), py::arg("eos") = false,
              py::arg("bos") = false, py::arg("padchar") = false)
         .def("batch_tokenize", &Tokenizer::batch_tokenize, py::arg("batch"), py::arg("padlen") = -1,
-             py::arg("destchar") = "B", py::arg("batch_first") = false, py::arg("nthreads") = 1, py::kw_only(),
+             py::arg("destchar") = "B", py::arg("batch_first") = false, py::arg("nthreads") = 0, py::kw_only(),
              py::arg("device") = py::none())
         .def("batch_onehot_encode", &Tokenizer::batch_onehot_encode, py::arg("batch"), py::arg("padlen") = -1,
-             py::arg("destchar") = "B", py::arg("nthreads") = 1, py::arg("mask") = py::none(), py::kw_only(),
+             py::arg("destchar") = "B", py::arg("nthreads") = 0, py::arg("mask") = py::none(), py::kw_only(),
              py::arg("device") = py::none(), py::arg("layout") = "tbc")
         .def("tokenize_packed",
              [](const Tokenizer &t, const py::object &chars, const py::object &offsets, py::ssize_t padlen,

@@ -17,39 +17,46 @@ a `.ff`, `FlatFile(fastx, out)` builds it from FASTA/FASTQ (optionally gzipped) 
 """
 from __future__ import annotations
 
-import gzip
 import os
 
 import numpy as np
 
 
-def _read_fastx(path):
-    """Sequences of a FASTA / FASTQ file (plain or gzip), kseq.h semantics: a record starts at a '>' or
-    '@' line; its sequence is every following line up to the next '>' / '@' / '+' line, whitespace
-    dropped; after '+' as many quality characters as sequence characters are skipped."""
-    with open(path, "rb") as f:
-        gz = f.read(2) == b"\x1f\x8b"
-    with (gzip.open if gz else open)(path, "rb") as f:
-        lines = [l.rstrip(b"\r") for l in f.read().split(b"\n")]
-    seqs, i, n = [], 0, len(lines)
-    while i < n:
-        if lines[i][:1] not in (b">", b"@"):
-            i += 1
-            continue
-        i += 1
-        parts = []
-        while i < n and lines[i][:1] not in (b">", b"@", b"+"):
-            parts.append(b"".join(lines[i].split()))
-            i += 1
-        seq = b"".join(parts)
-        seqs.append(seq)
-        if i < n and lines[i][:1] == b"+":
-            i += 1
-            got = 0
-            while i < n and got < len(seq):
-                got += len(lines[i])
-                i += 1
-    return seqs
+def fastx_to_flatfile(inpath, outpath=""):
+    """FASTA / FASTQ (plain or gzip) -> FlatFile at `outpath` (default inpath + '.ff'), by the native streaming reader
+    (`bsq_fastx_to_flatfile`, csrc/bsq_fastx.cpp: the reference's kseq record grammar, only the offsets held in memory).
+    Returns (outpath, nseqs, max_seq_len) -- the reference's FlatFile::make (fxstats.cpp:33-64)."""
+    import ctypes
+    from . import capi
+    lib = capi.load()
+    outpath = outpath or inpath + ".ff"
+    n, longest = ctypes.c_int64(0), ctypes.c_int64(0)
+    st = lib.bsq_fastx_to_flatfile(os.fsencode(inpath), os.fsencode(outpath), ctypes.byref(n), ctypes.byref(longest))
+    if st:
+        raise RuntimeError(lib.bsq_last_error().decode() or "bsq_fastx_to_flatfile failed")   # std::runtime_error in the reference
+    return outpath, n.value, longest.value
+
+
+def getstats(paths):
+    """Sequence lengths of every record of every FASTA / FASTQ file in `paths`: a list of uint64 arrays -- the reference's
+    module-level `getstats` (fxstats.cpp:12-23, 202-219)."""
+    import ctypes
+    from . import capi
+    lib = capi.load()
+    out = []
+    for path in paths:
+        n = ctypes.c_int64(0)
+        cap = 1 << 16
+        while True:
+            lens = np.empty(cap, dtype=np.uint64)
+            st = lib.bsq_fastx_lengths(os.fsencode(path), lens.ctypes.data, cap, ctypes.byref(n))
+            if st:
+                raise RuntimeError(lib.bsq_last_error().decode() or "bsq_fastx_lengths failed")
+            if n.value <= cap:
+                break
+            cap = n.value
+        out.append(lens[:n.value].copy())
+    return out
 
 
 def write_flatfile(seqs, path):
@@ -71,9 +78,8 @@ class FlatFile:
         """FlatFile(path_to_ff, maxseqlen=-1) opens a store; FlatFile(fastx_path, out_path) builds one first
         (`out_path == ''` -> fastx_path + '.ff'), as the reference's two constructors do."""
         if isinstance(maxseqlen, str):
-            out = maxseqlen or inputfile + ".ff"
-            write_flatfile(_read_fastx(inputfile), out)
-            inputfile, maxseqlen = out, -1
+            inputfile, _, _ = fastx_to_flatfile(inputfile, maxseqlen)
+            maxseqlen = -1
         self.path = inputfile
         self._mm = np.memmap(inputfile, mode="r", dtype=np.uint8) if os.path.getsize(inputfile) else np.zeros(8, np.uint8)
         self._n = int(self._mm[:8].view("<u8")[0])

@@ -190,6 +190,14 @@ bsq_status bsq_gather_packed_device(const uint8_t *chars, const int64_t *offsets
                                     int64_t n, uint8_t *out_chars, int64_t out_capacity, int64_t *out_offsets,
                                     int64_t *status_dev, void *hip_stream);
 
+/* ---- FASTA / FASTQ (plain or gzip) -> FlatFile on the host: replaces FlatFile::make (fxstats.cpp:33-64) and getlens /
+ * getstats (:12-23, :202-219).  Same record grammar as the reference's kseq loop (bsq_fastx.cpp lists it), but streaming:
+ * only the offsets stay in memory.  File format: uint64 nseqs | uint64 offsets[nseqs + 1] | sequence bytes -- the packed
+ * batch itself.  bsq_fastx_lengths: lens[0 .. min(n, capacity)) <- sequence length per record, *nrecords <- n (call with
+ * capacity 0 to count).  Host-only: no device is needed. */
+bsq_status bsq_fastx_to_flatfile(const char *inpath, const char *outpath, int64_t *nseqs, int64_t *max_seq_len);
+bsq_status bsq_fastx_lengths(const char *path, uint64_t *lens, int64_t capacity, int64_t *nrecords);
+
 /* ---- host entry points: packed batch in HOST memory (pageable or pinned).  The library stages
  * it through its own pinned + device buffers on the current HIP device, runs the device entry
  * point on `hip_stream`, and leaves the result in `out`:
@@ -212,6 +220,10 @@ bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const in
  * Two buffers alternate (the call waits until the batch packed two calls ago has left the GPU), so packing
  * batch n + 1 overlaps the copy + encode of batch n; a buffer stays valid until the call after next. */
 void *bsq_pinned_scratch(size_t nbytes);
+/* Pipelined upload: everything in the scratch buffer BEFORE `end` is final -- the library starts copying it to the device
+ * (its own copy stream) while the caller packs what lies behind.  Calls must move `end` forward; the following
+ * bsq_*_host call on pointers into the same buffer sends only the rest.  Optional: without it that call copies all. */
+bsq_status bsq_pinned_commit(const void *end);
 /* Free every cached staging buffer of the calling process (tests, shutdown). */
 void bsq_release_staging(void);
 

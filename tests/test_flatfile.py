@@ -59,3 +59,99 @@ def test_flatfile_to_encoder_zero_copy(gpu, bsq, oracle, golden_dir, tmp_path):
         assert ff.batch_onehot_encode(tok, a, b, destchar="f", device=gpu).cpu().numpy().tobytes() == exp_o.tobytes()
         # same result as the reference's route: access() -> list of bytearrays -> batch_tokenize
         assert tok.batch_tokenize(ff.access(a, b), padlen=P, batch_first=True).tobytes() == exp_t.tobytes()
+
+
+# ---------------------------------------------------------------- native FASTX reader vs the compiled reference (CPU)
+
+def _random_fastx(rng):
+    """Adversarial FASTA / FASTQ text: CRLF lines, blank lines, '>' / '@' / '+' inside lines, multi-line sequences,
+    quality strings that are too short / too long / missing, junk before the first header, no final newline."""
+    alpha = b"ACGTNacgtn*MKVLW -\t"
+    out = bytearray()
+    if rng.random() < 0.3:
+        out += rng.choice([b"junk line\n", b"\n\n", b"xx>inline header\n", b"# comment @ here\n"])
+    for _ in range(int(rng.integers(0, 12))):
+        nl = b"\r\n" if rng.random() < 0.25 else b"\n"
+        kind = rng.random()
+        name = bytes(rng.choice(list(b"abcXYZ09_|"), size=int(rng.integers(0, 6))).astype(np.uint8))
+        comment = b"" if rng.random() < 0.5 else b" some comment > with @ signs"
+        lines = []
+        for _ in range(int(rng.integers(0, 4))):
+            body = bytes(rng.choice(list(alpha), size=int(rng.integers(0, 30))).astype(np.uint8))
+            if rng.random() < 0.1:
+                body = b"" if rng.random() < 0.5 else b"\r"
+            if body[:1] in (b">", b"@", b"+"):
+                body = b"A" + body
+            lines.append(body)
+        if kind < 0.55:                                          # FASTA
+            out += b">" + name + comment + nl + b"".join(l + nl for l in lines)
+        else:                                                    # FASTQ
+            seqlen = sum(len(l) for l in lines)
+            q = rng.random()
+            qlen = seqlen if q < 0.7 else max(0, seqlen + int(rng.integers(-3, 4)))
+            qual = bytes(rng.choice(list(b"IIII#!>@+5"), size=qlen).astype(np.uint8))
+            if qual[:1] in (b">", b"@") and rng.random() < 0.5:
+                qual = b"I" + qual[1:]
+            out += b"@" + name + comment + nl + b"".join(l + nl for l in lines) + b"+" + (name if rng.random() < 0.5 else b"") + nl
+            if rng.random() < 0.9:
+                cut = int(rng.integers(0, len(qual) + 1)) if rng.random() < 0.3 else len(qual)
+                out += qual[:cut] + nl + (qual[cut:] + nl if cut < len(qual) else b"")
+    if out and rng.random() < 0.3:
+        out = out.rstrip(b"\r\n")
+    return bytes(out)
+
+
+def test_native_fastx_reader_equals_the_compiled_reference(oracle, tmp_path):
+    """Differential: bioseq_amd.FlatFile(fastx, out) / getstats against oracle/_ref = the reference's own fxstats.cpp
+    (kseq + zlib) on 400 random texts, plain and gzipped.  Skipped where the reference build is absent."""
+    import gzip
+    import bioseq_amd
+    from bioseq_amd.flatfile import FlatFile
+    ref = oracle.load_reference()
+    if ref is None or not hasattr(ref, "FlatFile"):
+        pytest.skip("oracle/_ref (the compiled reference) is not present")
+    rng = np.random.default_rng(2026)
+    nonempty = 0
+    for case in range(400):
+        text = _random_fastx(rng)
+        src = str(tmp_path / ("c%d.fx" % case)) + (".gz" if case % 5 == 0 else "")
+        with (gzip.open if src.endswith(".gz") else open)(src, "wb") as f:
+            f.write(text)
+        want_lens = ref.getstats([src])[0]
+        got_lens = bioseq_amd.getstats([src])[0]
+        assert got_lens.dtype == np.uint64 and got_lens.tolist() == want_lens.tolist(), (case, text)
+        a, b = str(tmp_path / "ref.ff"), str(tmp_path / "mine.ff")
+        ref.FlatFile(src, a)
+        mine = FlatFile(src, b)
+        assert open(b, "rb").read() == open(a, "rb").read(), (case, text)
+        assert len(mine) == len(want_lens)
+        nonempty += len(want_lens) > 0
+        os.remove(src)
+    assert nonempty > 200
+    with pytest.raises(RuntimeError, match="failed to open"):
+        FlatFile(str(tmp_path / "does_not_exist.fa"), str(tmp_path / "o.ff"))
+
+
+def test_native_fastx_reader_streams_a_large_fastq(tmp_path):
+    """200 000 reads of 150 bases (FASTQ-shaped, BASELINE config 4's source format, gzipped): the writer keeps only the offsets
+    in memory; the result round-trips through the FlatFile surface."""
+    import gzip
+    import resource
+    from bioseq_amd.flatfile import FlatFile, fastx_to_flatfile
+    rng = np.random.default_rng(4)
+    n, L = 200000, 150
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L))]
+    src = str(tmp_path / "reads.fq.gz")
+    with gzip.open(src, "wb", compresslevel=1) as f:
+        qual = b"I" * L
+        f.write(b"".join(b"@r%d\n" % i + bases[i].tobytes() + b"\n+\n" + qual + b"\n" for i in range(n)))
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    out, nseqs, longest = fastx_to_flatfile(src, str(tmp_path / "reads.ff"))
+    grown_mb = (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before) / 1024.0
+    assert (nseqs, longest) == (n, L)
+    assert grown_mb < 64, grown_mb                       # the 30 MB of sequence bytes are never held in memory
+    ff = FlatFile(out)
+    assert len(ff) == n and ff.maxseqlen == L
+    c, o = ff.packed()
+    assert c.tobytes() == bases.tobytes() and (np.diff(o) == L).all()
+    assert not os.path.exists(out + ".seq.tmp")
