@@ -94,7 +94,6 @@ def load():
         "bsq_fastx_to_flatfile": (i32, [ctypes.c_char_p, ctypes.c_char_p, i64p, i64p]),
         "bsq_fastx_lengths": (i32, [ctypes.c_char_p, vp, i64, i64p]),
         "bsq_pinned_scratch": (vp, [sz]),
-        "bsq_pinned_commit": (i32, [vp]),
         "bsq_release_staging": (None, []),
     }
     for name, (res, args) in sig.items():

@@ -43,10 +43,6 @@ struct InSlot {
     size_t d_in_cap = 0;
     hipEvent_t busy = nullptr;
     bool busy_pending = false;
-    // Pipelined upload (bsq_pinned_commit): the device input area mirrors the pinned area byte for byte; [0, committed)
-    // has already been handed to the copy stream while the caller was still packing the rest.
-    size_t committed = 0;
-    int device = -1;
 };
 struct Staging {
     int device = -1;
@@ -135,27 +131,6 @@ struct DeviceBatch {
 bsq_status upload(InSlot &s, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask, int64_t B,
                   hipStream_t stream, DeviceBatch *db) {
     const size_t total = static_cast<size_t>(offsets[B]);
-    if (in_pinned(s, offsets) && (total == 0 || in_pinned(s, chars)) && (!mask || in_pinned(s, mask)) && s.d_in_cap >= s.pinned_cap) {
-        // packed into this slot's pinned area (bsq_pinned_scratch): the device area mirrors it; copy what
-        // bsq_pinned_commit has not already sent
-        const char *pb = static_cast<const char *>(s.pinned);
-        size_t used = size_t(reinterpret_cast<const char *>(offsets) - pb) + size_t(B + 1) * 8;
-        if (total) used = std::max(used, size_t(reinterpret_cast<const char *>(chars) - pb) + total);
-        if (mask && total) used = std::max(used, size_t(reinterpret_cast<const char *>(mask) - pb) + total);
-        if (used > s.committed) {
-            g_upload_bytes.fetch_add(used - s.committed, std::memory_order_relaxed);
-            const hipError_t e2 = hipMemcpyAsync(static_cast<char *>(s.d_in) + s.committed, pb + s.committed, used - s.committed,
-                                                 hipMemcpyHostToDevice, stream);
-            if (e2 != hipSuccess) return bsq_internal::set_hip_error("hipMemcpyAsync(H2D)", e2);
-            s.committed = used;
-        }
-        char *db_base = static_cast<char *>(s.d_in);
-        db->offsets = reinterpret_cast<const int64_t *>(db_base + (reinterpret_cast<const char *>(offsets) - pb));
-        db->chars = total ? reinterpret_cast<const uint8_t *>(db_base + (reinterpret_cast<const char *>(chars) - pb))
-                          : reinterpret_cast<const uint8_t *>(db_base);
-        db->mask = mask ? reinterpret_cast<const uint8_t *>(db_base + (reinterpret_cast<const char *>(mask) - pb)) : nullptr;
-        return BSQ_OK;
-    }
     const size_t off_bytes = round_up(size_t(B + 1) * 8, 256);
     const size_t chr_bytes = round_up(total + 8, 256);  // +8: slack so the tail word is always mapped
     const size_t need = off_bytes + chr_bytes + (mask ? chr_bytes : 0);
@@ -563,34 +538,7 @@ void *bsq_pinned_scratch(size_t nbytes) {
         }
         s.pinned_cap = want;
     }
-    s.committed = 0;
-    s.device = sp->device;
-    if (grow_device(&s.d_in, &s.d_in_cap, s.pinned_cap) != BSQ_OK) return nullptr;  // mirrors the pinned area
     return s.pinned;
-}
-
-bsq_status bsq_pinned_commit(const void *end) {
-    std::lock_guard<std::mutex> lock(g_mu);
-    for (Staging &st : g_staging) {
-        if (st.device < 0) continue;
-        for (InSlot &s : st.in) {
-            const char *b = static_cast<const char *>(s.pinned), *e = static_cast<const char *>(end);
-            if (!b || e < b || e > b + s.pinned_cap) continue;
-            const size_t hi = size_t(e - b);
-            if (hi <= s.committed) return BSQ_OK;
-            int prev = 0;
-            (void)hipGetDevice(&prev);  // worker threads of the caller have no current device of their own
-            if (prev != st.device) (void)hipSetDevice(st.device);
-            g_upload_bytes.fetch_add(hi - s.committed, std::memory_order_relaxed);
-            const hipError_t err = hipMemcpyAsync(static_cast<char *>(s.d_in) + s.committed, b + s.committed, hi - s.committed,
-                                                  hipMemcpyHostToDevice, st.copy_stream);
-            if (prev != st.device) (void)hipSetDevice(prev);
-            if (err != hipSuccess) return bsq_internal::set_hip_error("hipMemcpyAsync(H2D, pipelined)", err);
-            s.committed = hi;
-            return BSQ_OK;
-        }
-    }
-    return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_pinned_commit: not inside a buffer of bsq_pinned_scratch");
 }
 
 void bsq_release_staging(void) {

@@ -320,42 +320,13 @@ Packed pack(const Gathered &g, int nthreads) {
     };
     if (nthreads <= 1 || g.total < (size_t(1) << 20) || p.B < 2 * nthreads) {
         copy_range(0, p.B);
-    } else {
-        // Workers touch raw bytes only; the caller keeps the GIL so the items stay alive.  The batch is cut into pieces of
-        // ~1 MB that the workers take in order; whoever completes the piece at the upload frontier hands everything up to
-        // there to the library (bsq_pinned_commit), so the H2D copy of the head runs while the tail is still being packed.
-        (void)bsq_pinned_commit(p.chars);  // the offsets go first
+    } else {  // workers touch raw bytes only; the caller keeps the GIL so the items stay alive
+        // (Handing finished pieces to the copy engine while the rest is still being packed was built and measured in round 3
+        // -- 1 MiB .. 16 MiB pieces, profiles/r03/e2e_lab1.txt: no gain at any piece size, the pack and the H2D copy compete
+        // for the same host memory bandwidth -- and taken out again.)
         const int64_t B = p.B;
-        const int64_t npieces = std::min<int64_t>(512, std::max<int64_t>(nthreads, int64_t(g.total >> 20)));
-        std::vector<int64_t> cut(size_t(npieces) + 1, B);
-        cut[0] = 0;
-        for (int64_t k = 1, i = 0; k < npieces; ++k) {  // piece k starts at the first sequence at or behind k / npieces of the bytes
-            const int64_t target = int64_t(g.total / size_t(npieces)) * k;
-            while (i < B && p.offsets[i] < target) ++i;
-            cut[size_t(k)] = i;
-        }
-        std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[size_t(npieces)]);
-        for (int64_t k = 0; k < npieces; ++k) done[size_t(k)].store(0, std::memory_order_relaxed);
-        std::atomic<int64_t> next{0};
-        std::mutex frontier_mu;
-        int64_t frontier = 0;
-        pool().parallel_for(nthreads, [&](int) {
-            for (;;) {
-                const int64_t k = next.fetch_add(1, std::memory_order_relaxed);
-                if (k >= npieces) return;
-                copy_range(cut[size_t(k)], cut[size_t(k) + 1]);
-                done[size_t(k)].store(1, std::memory_order_release);
-                if (p.mask) continue;  // (chars | mask are two regions: the mask goes with the final upload)
-                std::unique_lock<std::mutex> l(frontier_mu, std::try_to_lock);
-                if (!l.owns_lock()) continue;
-                int64_t f = frontier;
-                while (f < npieces && done[size_t(f)].load(std::memory_order_acquire)) ++f;
-                if (f > frontier) {
-                    frontier = f;
-                    (void)bsq_pinned_commit(p.chars + p.offsets[cut[size_t(f)]]);
-                }
-            }
-        });
+        const int nt = nthreads;
+        pool().parallel_for(nt, [&](int t) { copy_range(B * t / nt, B * (t + 1) / nt); });
     }
     return p;
 }

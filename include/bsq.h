@@ -220,10 +220,6 @@ bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const in
  * Two buffers alternate (the call waits until the batch packed two calls ago has left the GPU), so packing
  * batch n + 1 overlaps the copy + encode of batch n; a buffer stays valid until the call after next. */
 void *bsq_pinned_scratch(size_t nbytes);
-/* Pipelined upload: everything in the scratch buffer BEFORE `end` is final -- the library starts copying it to the device
- * (its own copy stream) while the caller packs what lies behind.  Calls must move `end` forward; the following
- * bsq_*_host call on pointers into the same buffer sends only the rest.  Optional: without it that call copies all. */
-bsq_status bsq_pinned_commit(const void *end);
 /* Free every cached staging buffer of the calling process (tests, shutdown). */
 void bsq_release_staging(void);
 
