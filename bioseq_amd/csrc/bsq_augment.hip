@@ -78,14 +78,18 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-// i-th 64-bit word of the stream keyed by (seed, sequence).  Host twin: tests/test_augment.py.
+// i-th 64-bit word of the stream keyed by (seed, sequence): mix64(h0 + 0xD1342543DE82EF95 * (i + 1)) with
+// h0 = mix64(seed + 0x9E3779B97F4A7C15 * (seq + 1)).  Host twin: tests/test_augment.py.
+#ifdef BSQ_LABS
 __device__ __forceinline__ uint64_t rnd(uint64_t seed, uint64_t seq, uint64_t i) {
     return mix64(mix64(seed + 0x9E3779B97F4A7C15ull * (seq + 1)) + 0xD1342543DE82EF95ull * (i + 1));
 }
+#endif
 __device__ __forceinline__ double unit(uint64_t x) { return static_cast<double>(x >> 11) * 0x1.0p-53; }
 
 constexpr int kMaxAttempts = 1 << 14;  // the reference's `while inchar == outchar` is unbounded (an all-W sequence accepts with p = 0.006 per try)
 
+#ifdef BSQ_LABS  // round-1 form (knob augment_mode 1): kept for A/B runs in diagnostic builds only
 // One mutation = the reference's loop `repeat { idx = choice(L); new = choice(letters, p = row(seq[idx])) } until
 // new != seq[idx]` (bioseq/blosum.py:63-87), sampled in two steps with the same joint distribution: a position is
 // ACCEPTED with probability 1 - row(old)[old] (what the reference's rejection amounts to), and only then is the
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(256) void k_augment(uint8_t *chars, const int64_t *
         for (int a0 = 4; a0 < kMaxAttempts && !done; a0 += 16) done = round(std::integral_constant<int, 16>{});
     }
 }
+#endif  // BSQ_LABS
 
 // Attempt-parallel form of the same algorithm and the SAME random stream (results are identical to k_augment; the
 // numpy twin in tests/test_augment.py is the judge of both).  k_augment gives every sequence one lane, so a wave runs
@@ -314,11 +319,16 @@ bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B,
     if (st != BSQ_OK) return st;
     const int64_t blocks = (B + 255) / 256;
     if (blocks >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "batch too large");
-    if (bsq_internal::tuning("augment_mode") == 1)  // one lane per sequence (round 1)
+#ifdef BSQ_LABS
+    if (bsq_internal::tuning().augment_mode == 1) {  // one lane per sequence (round 1)
         hipLaunchKernelGGL(k_augment, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
                            offsets, B, chain_len, frac, seed, tab);
-    else
-        hipLaunchKernelGGL(k_augment_groups, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
+        const hipError_t e1 = hipGetLastError();
+        if (e1 != hipSuccess) return bsq_internal::set_hip_error("k_augment", e1);
+        return BSQ_OK;
+    }
+#endif
+    hipLaunchKernelGGL(k_augment_groups, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
                            offsets, B, chain_len, frac, seed, tab);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bsq_internal::set_hip_error("k_augment", e);

@@ -146,14 +146,14 @@ bsq_status bsq_fill_device(void *dst, size_t nbytes, uint32_t pattern, void *hip
     const size_t blocks = (n16 + kThreads - 1) / kThreads;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     uint4 *d4 = static_cast<uint4 *>(dst);
-    const int mode = bsq_internal::tuning("fill_mode");
+    const int mode = bsq_internal::tuning().fill_mode;
     if (blocks >= (size_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "fill too large");
     switch (mode) {
     case 1: hipLaunchKernelGGL((k_fill_blocks<1, false>), dim3(unsigned(blocks)), dim3(kThreads),
-                               size_t(bsq_internal::tuning("fill_pad")), s, d4, n16, pattern); break;
+                               size_t(bsq_internal::tuning().fill_pad), s, d4, n16, pattern); break;
     case 2: hipLaunchKernelGGL((k_fill_blocks<4, false>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;
     case 3: hipLaunchKernelGGL((k_fill_blocks<1, true>), dim3(unsigned(blocks)), dim3(kThreads),
-                               size_t(bsq_internal::tuning("fill_pad")), s, d4, n16, pattern); break;
+                               size_t(bsq_internal::tuning().fill_pad), s, d4, n16, pattern); break;
     case 4: hipLaunchKernelGGL((k_fill_blocks<4, true>), dim3(unsigned((blocks + 3) / 4)), dim3(kThreads), 0, s, d4, n16, pattern); break;
     default: {
         const unsigned grid = unsigned(blocks > 256 * 16 ? 256 * 16 : blocks);
@@ -176,8 +176,8 @@ bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32
     }
     const dim3 grid(unsigned(int64_t(ncb) * nrb));
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const size_t pad = size_t(bsq_internal::tuning("fill_pad"));  // unused dynamic LDS: caps the workgroups per CU
-    const int32_t wait = bsq_internal::tuning("pattern_wait");
+    const size_t pad = size_t(bsq_internal::tuning().fill_pad);  // unused dynamic LDS: caps the workgroups per CU
+    const int32_t wait = bsq_internal::tuning().pattern_wait;
     if (nt)
         hipLaunchKernelGGL((k_fill_pattern<true>), grid, dim3(kThreads), pad, s, static_cast<uint8_t *>(dst), rows, pitch,
                            seg, rows_per_wave, ncb, nrb, order, interleave, wait);
@@ -200,7 +200,7 @@ bsq_status bsq_copy_mix_device(void *dst, size_t dst_bytes, const void *src, siz
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "copy mix too large");
     const dim3 grid(unsigned(groups * 8));
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const size_t pad = size_t(bsq_internal::tuning("fill_pad"));
+    const size_t pad = size_t(bsq_internal::tuning().fill_pad);
     if (nt)
         hipLaunchKernelGGL((k_copy_mix<true>), grid, dim3(kThreads), pad, s, static_cast<uint4 *>(dst), nchunks,
                            static_cast<const uint4 *>(src), nsrc16, int32_t(per_chunk), mode);

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -156,7 +157,7 @@ bsq_status upload(InSlot &s, const uint8_t *chars, const int64_t *offsets, const
 // destination (every worker takes its 1/n of each piece, so the page faults of the destination are spread
 // over the workers too).  Small results take the plain path.  Knob "host_copy_threads" (default 8, 1 = plain).
 bsq_status download(Staging &s, void *out, const void *dev_out, size_t nbytes, hipStream_t stream) {
-    int nthreads = bsq_internal::tuning("host_copy_threads");
+    int nthreads = bsq_internal::tuning().host_copy_threads;
     if (nthreads <= 0) nthreads = 8;
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw && unsigned(nthreads) > hw) nthreads = int(hw);
@@ -310,46 +311,39 @@ bsq_status set_hip_error(const char *what, hipError_t e) {
 }
 
 namespace {
-struct Knob {
+struct KnobInfo {
     const char *name;
-    const char *env;
-    int value;
-    bool init;
+    int32_t Tuning::*field;
+    bool labs;
 };
-Knob g_knobs[] = {{"nt_stores", "BSQ_NT_STORES", 1, false},
-                  {"onehot_tb", "BSQ_ONEHOT_TB", 0, false},
-                  {"tile_order", "BSQ_TILE_ORDER", 0, false},
-                  {"fill_mode", "BSQ_FILL_MODE", 0, false},
-                  {"onehot_path", "BSQ_ONEHOT_PATH", 0, false},
-                  {"expand_pad", "BSQ_EXPAND_PAD", 0, false},
-                  {"chunks_cpw", "BSQ_CHUNKS_CPW", 0, false},
-                  {"tokenize_path", "BSQ_TOKENIZE_PATH", 0, false},
-                  {"fill_pad", "BSQ_FILL_PAD", 0, false},
-                  {"chunks_pad", "BSQ_CHUNKS_PAD", 0, false},
-                  {"host_copy_threads", "BSQ_HOST_COPY_THREADS", 0, false},
-                  {"tokenize_pad", "BSQ_TOKENIZE_PAD", 0, false},
-                  {"expand_slots", "BSQ_EXPAND_SLOTS", 0, false},
-                  {"tokenize_nch", "BSQ_TOKENIZE_NCH", 0, false},
-                  {"expand_mode", "BSQ_EXPAND_MODE", 0, false},
-                  {"tile_group", "BSQ_TILE_GROUP", 0, false},
-                  {"bcl_path", "BSQ_BCL_PATH", 0, false},
-                  {"bcl_pad", "BSQ_BCL_PAD", 0, false},
-                  {"raw_mode", "BSQ_RAW_MODE", 0, false},
-                  {"xcd_claim", "BSQ_XCD_CLAIM", 0, false},
-                  {"augment_mode", "BSQ_AUGMENT_MODE", 0, false},
-                  {"workspace_cache", "BSQ_WORKSPACE_CACHE", 0, false},
-                  {"chunk_math", "BSQ_CHUNK_MATH", 0, false},
-                  {"tokens8", "BSQ_TOKENS8", 0, false},
-                  {"tokens8_abl", "BSQ_TOKENS8_ABL", 0, false},
-                  {"tokens8_fast", "BSQ_TOKENS8_FAST", 0, false},
-                  {"tokens8_lookup", "BSQ_TOKENS8_LOOKUP", 0, false},
-                  {"tokens8_pad", "BSQ_TOKENS8_PAD", 0, false},
-                  {"pattern_wait", "BSQ_PATTERN_WAIT", 0, false},
-                  {"tokenize_tb", "BSQ_TOKENIZE_TB", 0, false},
-                  {"wide_index", "BSQ_WIDE_INDEX", 0, false}};
-std::mutex g_knob_mu;
-Knob *find_knob(const char *name) {
-    for (Knob &k : g_knobs)
+const KnobInfo g_knobs[] = {
+#define BSQ_KNOB_PRODUCT(n, d) {#n, &Tuning::n, false},
+#define BSQ_KNOB_LABS(n, d) {#n, &Tuning::n, true},
+    BSQ_KNOB_LIST(BSQ_KNOB_PRODUCT, BSQ_KNOB_LABS)
+#undef BSQ_KNOB_PRODUCT
+#undef BSQ_KNOB_LABS
+};
+#ifdef BSQ_LABS
+constexpr bool kLabs = true;
+#else
+constexpr bool kLabs = false;
+#endif
+std::mutex g_knob_mu;                          // writers only
+std::atomic<const Tuning *> g_tuning{nullptr};  // the published snapshot (old ones are never freed: a handful per process)
+
+const Tuning *initial_tuning() {  // defaults, then BSQ_<NAME> from the environment -- once
+    Tuning *t = new Tuning();
+    for (const KnobInfo &k : g_knobs) {
+        if (k.labs && !kLabs) continue;
+        std::string env = "BSQ_";
+        for (const char *c = k.name; *c; ++c) env.push_back(char(std::toupper(static_cast<unsigned char>(*c))));
+        const char *e = std::getenv(env.c_str());
+        if (e && *e) t->*(k.field) = std::atoi(e);
+    }
+    return t;
+}
+const KnobInfo *find_knob(const char *name) {
+    for (const KnobInfo &k : g_knobs)
         if (name && std::strcmp(k.name, name) == 0) return &k;
     return nullptr;
 }
@@ -406,7 +400,7 @@ bsq_status workspace_acquire(size_t nbytes, hipStream_t stream, void **ptr) {
     if (nbytes == 0) nbytes = 16;
     // Scratch above kWsCacheCap is never kept: one huge call would otherwise pin its bytes (invisible to the caller's
     // allocator) per (device, stream) slot until bsq_release_staging().  cfg3 needs 64 MiB, cfg4 160 MiB.
-    if (capturing(stream) || nbytes > kWsCacheCap || tuning("workspace_cache") == 1) {
+    if (capturing(stream) || nbytes > kWsCacheCap || tuning().workspace_cache == 1) {
         e = hipMallocAsync(ptr, nbytes, stream);
         if (e != hipSuccess) return set_hip_error("hipMallocAsync(workspace)", e);
         return BSQ_OK;
@@ -476,24 +470,32 @@ void workspace_drop_cache() {
     (void)hipGetLastError();
 }
 
-int tuning(const char *name) {
+const Tuning &tuning() {
+    const Tuning *t = g_tuning.load(std::memory_order_acquire);
+    if (t) return *t;
     std::lock_guard<std::mutex> lock(g_knob_mu);
-    Knob *k = find_knob(name);
-    if (!k) return 0;
-    if (!k->init) {
-        const char *e = std::getenv(k->env);
-        if (e && *e) k->value = std::atoi(e);
-        k->init = true;
+    t = g_tuning.load(std::memory_order_acquire);
+    if (!t) {
+        t = initial_tuning();
+        g_tuning.store(t, std::memory_order_release);
     }
-    return k->value;
+    return *t;
+}
+
+int get_tuning(const char *name) {
+    const KnobInfo *k = find_knob(name);
+    return k ? tuning().*(k->field) : 0;
 }
 
 bool set_tuning(const char *name, int value) {
+    const KnobInfo *k = find_knob(name);
+    if (!k || (k->labs && !kLabs)) return false;
+    const Tuning &cur = tuning();
     std::lock_guard<std::mutex> lock(g_knob_mu);
-    Knob *k = find_knob(name);
-    if (!k) return false;
-    k->value = value;
-    k->init = true;
+    Tuning *next = new Tuning(*g_tuning.load(std::memory_order_acquire));
+    (void)cur;
+    next->*(k->field) = value;
+    g_tuning.store(next, std::memory_order_release);
     return true;
 }
 
@@ -505,9 +507,9 @@ const char *bsq_last_error(void) { return t_last_error.c_str(); }
 
 bsq_status bsq_tuning_set(const char *name, int32_t value) {
     return bsq_internal::set_tuning(name, value) ? BSQ_OK
-                                                 : bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "unknown tuning knob");
+                                                 : bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "unknown tuning knob (or one that exists only in a -DBSQ_LABS build)");
 }
-int32_t bsq_tuning_get(const char *name) { return bsq_internal::tuning(name); }
+int32_t bsq_tuning_get(const char *name) { return bsq_internal::get_tuning(name); }
 uint64_t bsq_host_upload_bytes(void) { return g_upload_bytes.load(std::memory_order_relaxed); }
 
 int32_t bsq_device_count(void) {

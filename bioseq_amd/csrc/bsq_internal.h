@@ -11,8 +11,11 @@ namespace bsq_internal {
 // Record a thread-local error message (returned by bsq_last_error()) and pass the status through.
 bsq_status set_error(bsq_status st, const char *msg);
 bsq_status set_hip_error(const char *what, hipError_t e);
-// Tuning / diagnostic knobs (bsq_tuning_set, or environment BSQ_<NAME> read at first use):
-// (speed only -- results never depend on them; every variant is covered by the GPU parity tests)
+// Tuning / diagnostic knobs (bsq_tuning_set, or environment BSQ_<NAME> read once, at the first launch):
+// (speed only -- in the product build results never depend on them; every variant is covered by the GPU parity tests.
+//  LABS = exists only with -DBSQ_LABS: chunks_cpw, tokenize_nch, expand_mode, xcd_claim, chunk_math, tokens8_abl, augment_mode
+//  (1: the round-1 one-lane-per-sequence k_augment), and the
+//  values 2 / 3 of raw_mode)
 //   nt_stores     1: `global_store ... nt` for the output streams (default 1)
 //   onehot_path   0: automatic, 1: tiled kernel, 2: two-pass (tokens + expansion), 3: chunk-owner kernel
 //   expand_pad    unused dynamic LDS of k_expand_chunks = occupancy cap: 0 automatic, > 0 bytes, < 0 none
@@ -32,7 +35,6 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //                 int8 matrix of >= 4096 sequences, 256 x 64 for the expansion scratch)
 //   xcd_claim     1: k_expand_chunks takes its chunk class from HW_REG_XCC_ID and its slot from per-class atomic counters
 //                 (placement-independent; measured 17-32 % slower: profiles/r02/claim_lab.txt)
-//   augment_mode  1: one lane per sequence (round-1 k_augment) instead of the attempt-parallel k_augment_groups
 //   chunk_math    2: scalar 64-bit integer reciprocals (div64) for the chunk coordinates of the expansion kernels
 //                 instead of the double reciprocals (div_by); measured 1 % slower at the optimum occupancy
 //   tokens8       1: never use k_tokens_bp8 for the (B,P) int8 token matrix (falls back to k_tokenize_chunks / _rows);
@@ -52,9 +54,26 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //                         otherwise needs more than 2^31 16-byte pieces of output)
 //   pattern_wait          bsq_fill_pattern_device: n > 0 = s_waitcnt vmcnt(n - 1) after every row of a wave
 //   host_copy_threads     worker threads of the pipelined device -> host result copy (0: 8)
-int tuning(const char *name);
-bool set_tuning(const char *name, int value);
-inline bool nontemporal_stores() { return tuning("nt_stores") != 0; }
+// The knobs are ONE plain struct, published as an immutable snapshot: a launcher reads it with a single atomic load
+// (tuning()), never a name lookup under a mutex.  bsq_tuning_set() copies the current snapshot, changes one field and
+// publishes the copy.  Knobs marked LABS select experiment kernels that LOST their measurement, or ablations that
+// CHANGE RESULTS; both are compiled -- and settable -- only in a diagnostic build (-DBSQ_LABS, scripts/build_labs.sh).
+// In the product build bsq_tuning_set() refuses them and no environment variable reaches them.
+#define BSQ_KNOB_LIST(X, L)                                                                                             \
+    X(nt_stores, 1) X(onehot_tb, 0) X(tile_order, 0) X(fill_mode, 0) X(onehot_path, 0) X(expand_pad, 0) X(tokenize_path, 0)   \
+    X(fill_pad, 0) X(chunks_pad, 0) X(host_copy_threads, 0) X(tokenize_pad, 0) X(expand_slots, 0) X(tile_group, 0)             \
+    X(bcl_path, 0) X(bcl_pad, 0) X(raw_mode, 0) X(workspace_cache, 0) X(tokens8, 0) X(tokens8_fast, 0) X(tokens8_lookup, 0)    \
+    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0)                                                 \
+    L(chunks_cpw, 0) L(tokenize_nch, 0) L(expand_mode, 0) L(xcd_claim, 0) L(chunk_math, 0) L(tokens8_abl, 0) L(augment_mode, 0)
+struct Tuning {
+#define BSQ_KNOB_FIELD(name, def) int32_t name = def;
+    BSQ_KNOB_LIST(BSQ_KNOB_FIELD, BSQ_KNOB_FIELD)
+#undef BSQ_KNOB_FIELD
+};
+const Tuning &tuning();
+int get_tuning(const char *name);             // by name (bsq_tuning_get); 0 for unknown names
+bool set_tuning(const char *name, int value);  // false: unknown name, or a LABS knob in a product build
+inline bool nontemporal_stores() { return tuning().nt_stores != 0; }
 
 // Stream-ordered scratch: the buffer of the last few (device, stream) pairs is kept between calls (knob
 // "workspace_cache" = 1: a hipMallocAsync / hipFreeAsync pair per call instead, as under graph capture).

@@ -249,6 +249,7 @@ __device__ __forceinline__ uint32_t finish4(const TokenRule p, const uint8_t *s_
     return w;
 }
 
+#ifdef BSQ_LABS  // helpers of k_tokens_raw2
 // The position rules of finish4 on an already looked-up word (bytes = positions tpos .. tpos + 3).
 __device__ __forceinline__ uint32_t rules4(const TokenRule p, uint32_t w, int32_t L, int32_t tpos) {
     const int32_t j0 = tpos - p.bos;
@@ -277,6 +278,8 @@ __device__ __forceinline__ uint32_t lookup4_folded(uint32_t cw, const uint32_t (
     const uint32_t s4 = ((cw >> 2) & 0x04040404u) | 0x03020100u;
     return __builtin_amdgcn_perm(hi, lo, s4);
 }
+
+#endif  // BSQ_LABS
 
 __device__ __forceinline__ uint32_t resolve4(const TokenRule p, const uint8_t *s_lut, uint32_t start, int32_t L,
                                              int32_t tpos) {
@@ -717,6 +720,7 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     }
 }
 
+#ifdef BSQ_LABS  // an experiment that lost (knob expand_mode 2 / 9); not in the product binary
 // The same expansion for SMALL rows (a chunk holds hundreds of rows: 7-byte rows of int8 DNA, 28-byte rows of f32
 // DNA): a lane takes FOUR consecutive rows from one unaligned dword of tokens, every token dword of the wave's
 // CPW chunks is in flight before the first one is used, and the chunks are then scattered / streamed one after
@@ -821,6 +825,7 @@ __global__ __launch_bounds__(kThreads) void k_expand_small(const EParams p) {
         }
     }
 }
+#endif  // BSQ_LABS
 
 // Raw (P,B) uint8 tokens (kNone kept) for k_expand_chunks.  Workgroup = 256 sequences x 64 positions.
 // Phase 1: 4 characters per lane (two aligned words + alignbyte, 8 fetches of a thread in flight together),
@@ -976,6 +981,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     }
 }
 
+#ifdef BSQ_LABS  // an experiment that lost (knob raw_mode 2 / 3); not in the product binary
 // Round-2 EXPERIMENT on the same tile (no mask; knob "raw_mode" 2 / 3; measured slower, see launch_tokens_raw).  The idea:
 // k_tokens_raw spends four ds_read_u8 lookups and four transposed ds_write_b8 per word of four tokens.  Here
 //   * the 4 x 4 byte transpose happens in registers: the four lanes l, l+16, l+32, l+48 hold the same four positions of
@@ -1082,6 +1088,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw2(const KParams p) {
         }
     }
 }
+#endif  // BSQ_LABS
 
 // ------------------------------------------------------------------------------------------
 // Tokens, (B,P) layout: one wave per sequence, 4 positions per lane per step, no transpose.
@@ -1661,9 +1668,9 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     // knob "tile_order": 0 automatic (XCD-aware), 1 position-tile index fastest, 2 XCD-aware, 3 sequence-tile index fastest.
     // XCD-aware placement fetches the characters once instead of ~3 times on the 1M x 160 DNA batch (FETCH_SIZE 234 ->
     // 78 MB; k_tokens_raw 97 -> 66 us, k_onehot_tile 258 -> 233 us: profiles/r02/order_lab.txt).
-    const int order_knob = bsq_internal::tuning("tile_order");
+    const int order_knob = bsq_internal::tuning().tile_order;
     k.order = order_knob == 1 ? 1 : (order_knob == 3 ? 0 : (order_knob == 4 ? 4 : (order_knob == 5 ? 5 : 2)));
-    const int group_knob = bsq_internal::tuning("tile_group");
+    const int group_knob = bsq_internal::tuning().tile_group;
     k.group = group_knob > 0 && group_knob <= 4096 ? group_knob : 1;
     if (k.order == 2 && (B / 64 + 8 * int64_t(k.group)) * int64_t(k.ntt) >= (int64_t(1) << 31)) k.order = 0;  // keep the rounded-up grid in 32 bits
     k.aligned = 0;
@@ -1733,14 +1740,14 @@ bsq_status dispatch_onehot_tile(KParams &k, hipStream_t s) {
     // Row segment = TB*C*sizeof(ST) bytes of contiguous output per (tile,row): keep it >= 2 KiB.
     const int seg64 = 64 * k.C * int(sizeof(ST));
     int tb = seg64 >= 2048 ? 64 : 256;
-    const int forced = bsq_internal::tuning("onehot_tb");
+    const int forced = bsq_internal::tuning().onehot_tb;
     if ((forced == 64 || forced == 128 || forced == 256) &&
         4 * (forced * k.C * int(sizeof(ST)) + 16) + tile_fixed_bytes<256>() <= 64 * 1024)
         tb = forced;
     // automatic tile order: XCD-aware only for the 256-sequence tiles of tiny rows (cfg4 int8: 258 -> 233 us); the
     // 64-sequence tiles of wide rows stream 5-9 % faster with the sequence-tile index fastest (sweep_shapes_r02.txt
     // vs profiles/r01/sweep_shapes5.txt, column p1)
-    if (bsq_internal::tuning("tile_order") == 0 && tb != 256) k.order = 0;
+    if (bsq_internal::tuning().tile_order == 0 && tb != 256) k.order = 0;
     k.ntb = int32_t((k.B + tb - 1) / tb);
     if (tb == 64) return launch_onehot_tile<ST, 64>(k, s);
     if (tb == 128) return launch_onehot_tile<ST, 128>(k, s);
@@ -1878,7 +1885,7 @@ bsq_status launch_chunks(const CParams &c, hipStream_t s) {
     // Occupancy cap through unused dynamic LDS: 4 workgroups per CU (17 KiB + 22 KiB each) stream at 7.2 TB/s
     // on cfg3; 5 (the VGPR limit) at 6.9, 3 at 6.6, 2 at 4.8 (profiles/r01/chunks_occupancy.txt).  The same
     // holds for a plain fill: 6.8 TB/s at 8 workgroups per CU, 7.4 at 3.  Knob "chunks_pad" overrides (bytes).
-    const int padv = bsq_internal::tuning("chunks_pad");
+    const int padv = bsq_internal::tuning().chunks_pad;
     const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : size_t(22528));
     if (bsq_internal::nontemporal_stores())
         hipLaunchKernelGGL((k_onehot_chunks<ST, true>), grid, dim3(kThreads), pad, s, c);
@@ -1906,7 +1913,7 @@ bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
     c.at_len_id = k.eos ? uint32_t(k.eos_id) : c.fill_id;
     const int64_t room = k.P - k.bos - k.eos;
     c.room = int32_t(room < 0 ? 0 : room);
-    const int cpw = bsq_internal::tuning("chunks_cpw");  // chunks per wave (1 is fastest: 0.75 / 0.86 / 0.93 ms for 1 / 2 / 4 on cfg3)
+    const int cpw = bsq_internal::tuning().chunks_cpw;  // chunks per wave (1 is fastest: 0.75 / 0.86 / 0.93 ms for 1 / 2 / 4 on cfg3)
     c.cpw = cpw > 0 ? cpw : 1;
     c.one_bits = k.one_bits;
     c.inv_rowbytes = 1.0 / double(k.C * int64_t(sz));
@@ -1941,10 +1948,11 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     // (ablation).  k_expand_small is an experiment that lost: once the token scratch is written in XCD-aware tile
     // order the byte-load kernel under an occupancy cap is 1-2 % ahead of it, and two or four chunks per wave were
     // 20-40 % slower (profiles/r02/pad_lab*.txt, expand_lab3.txt; those instantiations are no longer built).
+#ifdef BSQ_LABS
     const int mode = e.mode;
     const int64_t rb = e.C * int64_t(sizeof(ST));
     if (rb >= 4 && (mode == 2 || mode == 9)) {
-        const int padv2 = bsq_internal::tuning("expand_pad");
+        const int padv2 = bsq_internal::tuning().expand_pad;
         const size_t pad2 = padv2 > 0 ? size_t(padv2) : 0;
         if (bsq_internal::nontemporal_stores())
             hipLaunchKernelGGL((k_expand_small<ST, true, 1, 0>), grid, dim3(kThreads), pad2, s, e);
@@ -1952,10 +1960,12 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
             hipLaunchKernelGGL((k_expand_small<ST, false, 1, 0>), grid, dim3(kThreads), pad2, s, e);
         return check_launch("k_expand_small");
     }
-    const int padv = bsq_internal::tuning("expand_pad");
+#endif
+    const int padv = bsq_internal::tuning().expand_pad;
     const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;
     const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : (big_rows ? size_t(36864) : size_t(16384)));
-    if (bsq_internal::tuning("xcd_claim") == 1) {  // measurement only: placement-independent chunk classes (see the kernel)
+#ifdef BSQ_LABS
+    if (bsq_internal::tuning().xcd_claim == 1) {  // measurement only: placement-independent chunk classes (see the kernel)
         static unsigned int *counters[16] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return bsq_internal::set_error(BSQ_ERR_HIP, "hipGetDevice");
@@ -1971,22 +1981,25 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
             hipLaunchKernelGGL((k_expand_chunks<ST, false, 0, 1>), grid, dim3(kThreads), pad, s, ec);
         return check_launch("k_expand_chunks<claim>");
     }
+#endif
     // knob "chunk_math": 2 = scalar 64-bit reciprocal multiplies (div64) instead of the double reciprocals (div_by).
     // Measured (profiles/r02/math_lab1.txt): the scalar prologue is ~90 SALU instructions instead of ~130 VALU ones
     // (22 of them FP64) and wins where a wave's latency is exposed (2 workgroups per CU: 0.938 vs 0.969 ms on cfg3),
     // but at the bandwidth optimum (3 per CU) the double form is 1 % FASTER (0.734 vs 0.741 ms): the stream is paced by
     // the memory system there, not by the prologue.  So the double form stays the default.
-    if (bsq_internal::tuning("chunk_math") == 2) {
+#ifdef BSQ_LABS
+    if (bsq_internal::tuning().chunk_math == 2) {
         if (bsq_internal::nontemporal_stores())
             hipLaunchKernelGGL((k_expand_chunks<ST, true, 1>), grid, dim3(kThreads), pad, s, e);
         else
             hipLaunchKernelGGL((k_expand_chunks<ST, false, 1>), grid, dim3(kThreads), pad, s, e);
-    } else {
-        if (bsq_internal::nontemporal_stores())
-            hipLaunchKernelGGL((k_expand_chunks<ST, true, 0>), grid, dim3(kThreads), pad, s, e);
-        else
-            hipLaunchKernelGGL((k_expand_chunks<ST, false, 0>), grid, dim3(kThreads), pad, s, e);
+        return check_launch("k_expand_chunks<div64>");
     }
+#endif
+    if (bsq_internal::nontemporal_stores())
+        hipLaunchKernelGGL((k_expand_chunks<ST, true, 0>), grid, dim3(kThreads), pad, s, e);
+    else
+        hipLaunchKernelGGL((k_expand_chunks<ST, false, 0>), grid, dim3(kThreads), pad, s, e);
     return check_launch("k_expand_chunks");
 }
 
@@ -2006,7 +2019,7 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
     // register table.  k_tokens_raw2 is an experiment that LOST (profiles/r02/raw_lab.txt: cfg2 as (P,B) int8 tokens
     // 24.0 us -> 25.8 (2) / 27.4 (3); cfg3 / cfg4 f32 steps +0.1 / +0.3 %): the tile is bound by vector instructions at
     // least as much as by LDS traffic, and the transpose trades 3 LDS writes for 6 vector instructions per word.
-    const int rm = bsq_internal::tuning("raw_mode");
+    const int rm = bsq_internal::tuning().raw_mode;
     if (!k.mask && rm == 4 && k.P <= (int64_t(1) << 20)) {  // measurement: the wide tile of the (P,B) int8 token matrix
         k.ntb = int32_t((k.B + kWideTB - 1) / kWideTB);
         k.ntt = int32_t((k.P + kWideTT - 1) / kWideTT);
@@ -2015,13 +2028,15 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
                            dim3(kThreads), 0, s, k);
         return check_launch("k_tokens_raw<wide>");
     }
-    if (k.mask || rm < 2 || rm == 4)
-        if (k.mask) hipLaunchKernelGGL(k_tokens_raw<true>, grid, dim3(kThreads), 0, s, k);
-        else hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
-    else if (rm == 3 && k.foldable)
-        hipLaunchKernelGGL((k_tokens_raw2<true, true>), grid, dim3(kThreads), 0, s, k);
-    else
-        hipLaunchKernelGGL((k_tokens_raw2<true, false>), grid, dim3(kThreads), 0, s, k);
+#ifdef BSQ_LABS
+    if (!k.mask && (rm == 2 || rm == 3)) {
+        if (rm == 3 && k.foldable) hipLaunchKernelGGL((k_tokens_raw2<true, true>), grid, dim3(kThreads), 0, s, k);
+        else hipLaunchKernelGGL((k_tokens_raw2<true, false>), grid, dim3(kThreads), 0, s, k);
+        return check_launch("k_tokens_raw2");
+    }
+#endif
+    if (k.mask) hipLaunchKernelGGL(k_tokens_raw<true>, grid, dim3(kThreads), 0, s, k);
+    else hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
     return check_launch("k_tokens_raw");
 }
 
@@ -2046,8 +2061,8 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
     e.claim = nullptr;
     e.groups_per_class = 0;
     div_constants(uint32_t(C * int64_t(sz)), &e.rb_magic, &e.rb_shift, &e.rb_pow2);
-    e.force4 = bsq_internal::tuning("expand_slots") == 4;
-    e.mode = bsq_internal::tuning("expand_mode");
+    e.force4 = bsq_internal::tuning().expand_slots == 4;
+    e.mode = bsq_internal::tuning().expand_mode;
     switch (sz) {
     case 1: return launch_expand<uint8_t>(e, s);
     case 2: return launch_expand<uint16_t>(e, s);
@@ -2069,7 +2084,7 @@ bsq_status launch_tokenize_tile(KParams &k, hipStream_t s) {
     // automatic tile order: sequence-tile index fastest.  This kernel writes TB * sizeof(T) = 256..512-byte row segments;
     // with the XCD-aware order their neighbours in a row are written far apart in time and the (P,B) int32 / f32 matrix of
     // the cfg2 batch takes 62 us instead of 48 (profiles/r02/tokens_dtypes.txt); its character re-reads are small beside that.
-    if (bsq_internal::tuning("tile_order") == 0 && k.order != 4) k.order = 0;  // (4: chosen by the caller for unaligned rows)
+    if (bsq_internal::tuning().tile_order == 0 && k.order != 4) k.order = 0;  // (4: chosen by the caller for unaligned rows)
     k.ntb = int32_t((k.B + TB - 1) / TB);
     const int64_t ntt = (k.P + kTT - 1) / kTT;
     const size_t smem = tile_fixed_bytes<TB>();
@@ -2095,7 +2110,7 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     c.ppr = uint32_t((k.P + EPL - 1) / EPL) + (ragged ? 1u : 0u);  // ragged: + the head slot
     c.a0e = uint32_t(reinterpret_cast<uintptr_t>(k.out) % 16) / uint32_t(sizeof(T));
     c.pmod = uint32_t(k.P % EPL);
-    c.wide_index = bsq_internal::tuning("wide_index");
+    c.wide_index = bsq_internal::tuning().wide_index;
     c.nchunks = (k.B * (HOT ? int64_t(k.C) : 1) * int64_t(c.ppr) + kChunk / 16 - 1) / (kChunk / 16);  // 256 pieces per wave
     c.bos = k.bos;
     c.bos_id = uint32_t(k.bos_id);
@@ -2110,19 +2125,25 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     // Chunks per wave: 1.  The software-pipelined 4-chunk form (knob "tokenize_nch" = 4) is 15-20 % SLOWER on cfg2 /
     // cfg5: the kernel is bound by its ~550 VALU instructions per chunk, not by memory latency, and four chunks
     // per wave cost occupancy (102 VGPRs).
-    const int nch = bsq_internal::tuning("tokenize_nch") == 4 && !ragged ? 4 : 1;
+#ifdef BSQ_LABS
+    const int nch = bsq_internal::tuning().tokenize_nch == 4 && !ragged ? 4 : 1;
+#else
+    const int nch = 1;
+#endif
     const int64_t groups = ((c.nchunks + 7) / 8 + int64_t(4) * nch - 1) / (int64_t(4) * nch);
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
-    const int padv = bsq_internal::tuning("tokenize_pad");  // unused dynamic LDS = occupancy cap (experiments)
+    const int padv = bsq_internal::tuning().tokenize_pad;  // unused dynamic LDS = occupancy cap (experiments)
     const size_t pad = padv > 0 ? size_t(padv) : 0;
     const bool nt = bsq_internal::nontemporal_stores();
     if (ragged) {
         if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 1, true>), grid, dim3(kThreads), pad, s, c);
         else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 1, true>), grid, dim3(kThreads), pad, s, c);
+#ifdef BSQ_LABS
     } else if (nch == 4) {
         if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 4>), grid, dim3(kThreads), pad, s, c);
         else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 4>), grid, dim3(kThreads), pad, s, c);
+#endif
     } else {
         if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 1>), grid, dim3(kThreads), pad, s, c);
         else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 1>), grid, dim3(kThreads), pad, s, c);
@@ -2146,7 +2167,7 @@ bsq_status launch_expand_bcl(const uint8_t *tokens, int64_t B, int64_t P, int32_
     div_constants(uint32_t(C), &b.magic_c, &b.shift_c, &b.pow2_c);
     const int64_t groups = ((b.nchunks + 7) / 8 + 3) / 4;
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
-    const int padv = bsq_internal::tuning("bcl_pad");  // unused dynamic LDS = occupancy cap: 0 -> 3 workgroups per CU
+    const int padv = bsq_internal::tuning().bcl_pad;  // unused dynamic LDS = occupancy cap: 0 -> 3 workgroups per CU
     const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : size_t(53248));
     if (bsq_internal::nontemporal_stores())
         hipLaunchKernelGGL((k_expand_bcl<T, true>), dim3(unsigned(groups * 8)), dim3(kThreads), pad, s, b);
@@ -2165,7 +2186,7 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool m
     const bool tiled_ok = C <= 250 && 4 * (64 * C * int64_t(sz) + 16) + tile_fixed_bytes<64>() <= 60 * 1024 &&
                           ntiles < (int64_t(1) << 31) && B < (int64_t(1) << 31) - 256 && P <= kMaxTiledP;
     if (!tiled_ok) return 0;
-    int path = bsq_internal::tuning("onehot_path");
+    int path = bsq_internal::tuning().onehot_path;
     if (path == 0) {
         // Measured on MI355X over 22 shapes (profiles/r01/sweep_shapes5.txt, sweep_occupancy2.txt):
         //  2 two-pass   : the fastest streamer once the output is large -- 7.3-7.4 TB/s at 3 workgroups per CU
@@ -2203,8 +2224,12 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
     case 1: return "k_onehot_tile";
     case 2: {
         const int64_t rb = bsq_alphabet_size(d) * int64_t(bsq_dtype_size(t));
-        const int mode = bsq_internal::tuning("expand_mode");
-        return (rb >= 4 && (mode == 2 || mode == 9)) ? "k_tokens_raw+k_expand_small" : "k_tokens_raw+k_expand_chunks";
+#ifdef BSQ_LABS
+        const int mode = bsq_internal::tuning().expand_mode;
+        if (rb >= 4 && (mode == 2 || mode == 9)) return "k_tokens_raw+k_expand_small";
+#endif
+        (void)rb;
+        return "k_tokens_raw+k_expand_chunks";
     }
     case 3: return "k_onehot_chunks";
     default: return "k_onehot_generic";
@@ -2288,14 +2313,14 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const uintptr_t addr = reinterpret_cast<uintptr_t>(out);
     // int8 (B,P): k_tokens_bp8 takes any padlen >= 128 and any alignment (its row-piece form when P % 16 != 0)
-    if (batch_first && t == BSQ_I8 && bsq_internal::tuning("tokenize_path") != 1 && bsq_internal::tuning("tokens8") != 1 &&
+    if (batch_first && t == BSQ_I8 && bsq_internal::tuning().tokenize_path != 1 && bsq_internal::tuning().tokens8 != 1 &&
         bsq_internal::tokens_bp8_applicable(d, B, P, out) &&
-        ((addr % 16 == 0 && P % 16 == 0) || bsq_internal::tuning("tokens8") != 2))  // knob 2: aligned shapes only (round-2 state)
+        ((addr % 16 == 0 && P % 16 == 0) || bsq_internal::tuning().tokens8 != 2))  // knob 2: aligned shapes only (round-2 state)
         return bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, out, s);
     // chunk kernel: a lane's 16 output bytes lie inside one row (its row-piece form when P % (16 / sz) != 0 or the output
     // is not 16-byte aligned; knob "tokenize_path" 2: aligned shapes only, the rest falls to k_tokenize_rows as in round 1)
-    if (batch_first && bsq_internal::tuning("tokenize_path") != 1 && addr % sz == 0 &&
-        ((addr % 16 == 0 && P % int64_t(16 / sz) == 0) || bsq_internal::tuning("tokenize_path") != 2)) {
+    if (batch_first && bsq_internal::tuning().tokenize_path != 1 && addr % sz == 0 &&
+        ((addr % 16 == 0 && P % int64_t(16 / sz) == 0) || bsq_internal::tuning().tokenize_path != 2)) {
         switch (t) {
         case BSQ_I8: return launch_tokenize_chunks<int8_t, false>(k, s);
         case BSQ_I16: return launch_tokenize_chunks<int16_t, false>(k, s);
@@ -2322,15 +2347,15 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         return check_launch("k_tokenize_rows");
     }
     k.aligned = (addr % 16 == 0) && ((B * int64_t(sz)) % 16 == 0);
-    k.vw = (!k.aligned && addr % sz == 0 && bsq_internal::tuning("tokenize_path") != 2) ? 2 : 1;  // k_tokenize_tile: 2 = line-aligned slots
-    if (t == BSQ_I8 && bsq_internal::tuning("tokenize_path") != 1) {  // int8 (P,B): the raw-token kernel in value mode
+    k.vw = (!k.aligned && addr % sz == 0 && bsq_internal::tuning().tokenize_path != 2) ? 2 : 1;  // k_tokenize_tile: 2 = line-aligned slots
+    if (t == BSQ_I8 && bsq_internal::tuning().tokenize_path != 1) {  // int8 (P,B): the raw-token kernel in value mode
         const uint64_t al = uint64_t(addr) | uint64_t(B);  // every row starts at out + t * B
         k.vw = al % 16 == 0 ? 16 : (al % 8 == 0 ? 8 : (al % 4 == 0 ? 4 : 1));
         // tile order 5 (XCD-contiguous ranges of sequence tiles, their position tiles back to back): the 256-byte row
         // segments of neighbouring tiles meet in one L2 -- cfg5 43.0 -> 41.3 us, 100000 x 256 DNA 13.8 -> 12.7,
         // 65000 x 1001 29.1 -> 27.3, cfg2 24.7 -> 24.0 (profiles/r02/seqfirst_orders2.txt)
-        if (bsq_internal::tuning("tile_order") == 0) k.order = 5;
-        const int rm = bsq_internal::tuning("raw_mode");
+        if (bsq_internal::tuning().tile_order == 0) k.order = 5;
+        const int rm = bsq_internal::tuning().raw_mode;
         // knob "raw_mode": 0 automatic, 1 the 256 x 64 tile, 4 the wide 1024 x 16 tile, 2 / 3 the round-2 experiments
         const bool wide_ok = P <= (int64_t(1) << 20);  // 1024 sequences x padlen in 32-bit window offsets
         if (wide_ok && rm == 4) {  // measurement only: 35 vs 24 us on cfg2 (profiles/r02/seqfirst_lab1.txt)
@@ -2343,14 +2368,17 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         }
         k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
         const dim3 vgrid(unsigned(tile_grid(k, k.ntt)));
-        if ((rm < 2 || rm >= 4) && vgrid.x <= 2048u)  // about one round of workgroups: the latency form
+#ifdef BSQ_LABS
+        if (rm == 2 || rm == 3) {
+            if (rm == 3 && k.foldable) hipLaunchKernelGGL((k_tokens_raw2<false, true>), vgrid, dim3(kThreads), 0, s, k);
+            else hipLaunchKernelGGL((k_tokens_raw2<false, false>), vgrid, dim3(kThreads), 0, s, k);
+            return check_launch("k_tokens_raw2<value>");
+        }
+#endif
+        if (vgrid.x <= 2048u)  // about one round of workgroups: the latency form
             hipLaunchKernelGGL((k_tokens_raw<false, false, kRawTB, kTT, true>), vgrid, dim3(kThreads), 0, s, k);
-        else if (rm < 2 || rm >= 4)
-            hipLaunchKernelGGL((k_tokens_raw<false, false>), vgrid, dim3(kThreads), 0, s, k);
-        else if (rm == 3 && k.foldable)
-            hipLaunchKernelGGL((k_tokens_raw2<false, true>), vgrid, dim3(kThreads), 0, s, k);
         else
-            hipLaunchKernelGGL((k_tokens_raw2<false, false>), vgrid, dim3(kThreads), 0, s, k);
+            hipLaunchKernelGGL((k_tokens_raw<false, false>), vgrid, dim3(kThreads), 0, s, k);
         return check_launch("k_tokens_raw<value>");
     }
     // Sequences per tile (knob "tokenize_tb": 0 automatic, 64 / 128 / 256).  A tile writes TB * sz-byte row segments;
@@ -2361,8 +2389,8 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     // tiles, so the sectors two tiles share are merged in ONE L2): int16 55 -> 42 us, int32 78 -> 69 us on 65000 x 1024
     // (profiles/r02/tile_tb_lab2.txt).  8-byte elements gain from neither (151-161 us whatever the tile).
     const bool shared_sectors = (B * int64_t(sz)) % 64 != 0 && B >= 16384 && sz < 8;
-    const int tbk = shared_sectors && bsq_internal::tuning("tokenize_tb") == 0 ? 256 : bsq_internal::tuning("tokenize_tb");
-    if (shared_sectors && bsq_internal::tuning("tile_order") == 0) k.order = 4;
+    const int tbk = shared_sectors && bsq_internal::tuning().tokenize_tb == 0 ? 256 : bsq_internal::tuning().tokenize_tb;
+    if (shared_sectors && bsq_internal::tuning().tile_order == 0) k.order = 4;
 #define BSQ_TILE(T, AUTO)                                                        \
     switch (tbk ? tbk : AUTO) {                                                  \
     case 64: return launch_tokenize_tile<T, 64>(k, s);                           \
@@ -2396,7 +2424,7 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
     k.one_bits = one_bits_of(t);
     // Two-pass form (raw (B,P) ids, then k_expand_bcl) for large outputs, masked or not; knob "bcl_path": 0 automatic,
     // 1 never, 2 whenever it applies.
-    const int bcl_path = bsq_internal::tuning("bcl_path");
+    const int bcl_path = bsq_internal::tuning().bcl_path;
     const int64_t total_bytes = B * int64_t(k.C) * P * int64_t(sz);
     if (bcl_path != 1 && (bcl_path == 2 || total_bytes >= (int64_t(256) << 20)) && k.C <= 250 &&
         reinterpret_cast<uintptr_t>(out) % 16 == 0 && P % 16 == 0 && B * int64_t(k.C) * P < (int64_t(1) << 51) &&

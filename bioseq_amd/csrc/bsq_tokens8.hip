@@ -510,21 +510,22 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
 
 template <bool NT, int LK>
 void launch_variant(const T8Params &c, dim3 grid, size_t pad, hipStream_t s) {
+#ifdef BSQ_LABS  // ablations: their output is WRONG on purpose; they exist in diagnostic builds only
     switch (c.abl) {
-    case 1: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 1>), grid, dim3(kThreads), pad, s, c); break;
-    case 2: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 2>), grid, dim3(kThreads), pad, s, c); break;
-    case 3: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 3>), grid, dim3(kThreads), pad, s, c); break;
-    case 4: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 4>), grid, dim3(kThreads), pad, s, c); break;
-    case 5: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 5>), grid, dim3(kThreads), pad, s, c); break;
-    default:
-        if (c.mask)  // raw ids for the masked channels-first one-hot (aligned shapes only: see launch_tokens_bp8)
-            hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0, false, true>), grid, dim3(kThreads), pad, s, c);
-        else if (c.P % 16 != 0 || reinterpret_cast<uintptr_t>(c.out) % 16 != 0)
-            hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0, true>), grid, dim3(kThreads), pad, s, c);
-        else
-            hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0>), grid, dim3(kThreads), pad, s, c);
-        break;
+    case 1: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 1>), grid, dim3(kThreads), pad, s, c); return;
+    case 2: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 2>), grid, dim3(kThreads), pad, s, c); return;
+    case 3: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 3>), grid, dim3(kThreads), pad, s, c); return;
+    case 4: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 4>), grid, dim3(kThreads), pad, s, c); return;
+    case 5: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 5>), grid, dim3(kThreads), pad, s, c); return;
+    default: break;
     }
+#endif
+    if (c.mask)  // raw ids for the masked channels-first one-hot (aligned shapes only: see launch_tokens_bp8)
+        hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0, false, true>), grid, dim3(kThreads), pad, s, c);
+    else if (c.P % 16 != 0 || reinterpret_cast<uintptr_t>(c.out) % 16 != 0)
+        hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0, true>), grid, dim3(kThreads), pad, s, c);
+    else
+        hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0>), grid, dim3(kThreads), pad, s, c);
 }
 
 }  // namespace
@@ -582,20 +583,20 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
     const uint32_t fill = d->padchar ? uint32_t(bsq_pad_id(d)) : c.none_v;  // no padchar: the memset 0 of tokenize.h:427 stays
     c.fill_v = fill;
     c.at_len_v = d->eos ? uint32_t(bsq_eos_id(d)) : fill;
-    c.abl = tuning("tokens8_abl");
-    c.wide_index = tuning("wide_index");
-    int lk = tuning("tokens8_lookup");  // 0 automatic (registers when the table folds), 1 LDS byte table, 2 registers
+    c.abl = tuning().tokens8_abl;
+    c.wide_index = tuning().wide_index;
+    int lk = tuning().tokens8_lookup;  // 0 automatic (registers when the table folds), 1 LDS byte table, 2 registers
     if (lk == 0) lk = foldable ? 2 : 1;
     if (lk == 2 && !foldable) lk = 1;
     const int64_t groups = ((c.nchunks + 7) / 8 + 3) / 4;
     if (groups * 8 >= (int64_t(1) << 31)) return set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
-    const int padv = tuning("tokens8_pad");  // unused dynamic LDS = occupancy cap (experiments)
+    const int padv = tuning().tokens8_pad;  // unused dynamic LDS = occupancy cap (experiments)
     const size_t pad = padv > 0 ? size_t(padv) : 0;
     const bool nt = nontemporal_stores() && !raw;
     // the fast form: register table, aligned rows, no mask, 32-bit piece indices (knob tokens8_fast = 1: never)
     if (lk == 2 && !mask && c.abl == 0 && P % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && !c.wide_index &&
-        c.nchunks < (int64_t(1) << 23) && B < (int64_t(1) << 31) && tuning("tokens8_fast") != 1) {
+        c.nchunks < (int64_t(1) << 23) && B < (int64_t(1) << 31) && tuning().tokens8_fast != 1) {
         uint32_t magic = c.magic, shift = c.shift;
         if (c.pow2) {  // d = 2^s, s >= 3: mulhi(n, 2^(32 - s)) == n >> s
             magic = uint32_t(1) << (32 - c.shift);

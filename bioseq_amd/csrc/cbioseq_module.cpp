@@ -403,8 +403,13 @@ ArrayArg as_array(const py::object &o, const char *np_dtype, size_t itemsize, co
     if (py::hasattr(o, "data_ptr") && py::hasattr(o, "is_cuda")) {  // torch tensor
         py::object t = o;
         if (!t.attr("is_contiguous")().cast<bool>()) t = t.attr("contiguous")();
-        if (py::str(t.attr("dtype")).cast<std::string>() != std::string("torch.") + np_dtype)
-            throw std::invalid_argument(std::string(what) + ": expected a torch." + np_dtype + " tensor");
+        // one-byte arguments (chars, mask): any 1-byte integer or bool tensor is the same bytes, as the numpy branch below
+        // accepts any 1-byte array; wider arguments (offsets) must be exactly the named type -- float64 offsets were the hazard
+        const std::string dt = py::str(t.attr("dtype")).cast<std::string>();
+        const bool same_bytes = itemsize == 1 && (dt == "torch.uint8" || dt == "torch.int8" || dt == "torch.bool");
+        if (!same_bytes && dt != std::string("torch.") + np_dtype)
+            throw std::invalid_argument(std::string(what) + ": expected a torch." + np_dtype + " tensor" +
+                                        (itemsize == 1 ? " (or torch.int8 / torch.bool)" : ""));
         a.on_device = t.attr("is_cuda").cast<bool>();
         a.ptr = reinterpret_cast<const void *>(t.attr("data_ptr")().cast<uintptr_t>());
         a.n = t.attr("numel")().cast<int64_t>();

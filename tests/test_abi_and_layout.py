@@ -47,6 +47,11 @@ def test_host_only_abi_calls(alphabets_golden):
     assert lib.bsq_validate_lengths(offs.ctypes.data, 3, 6, 1, 1, ctypes.byref(bad)) == capi.ERR_SEQ_TOO_LONG and bad.value == 1
     assert lib.bsq_strerror(capi.ERR_SEQ_TOO_LONG) == b"seq len + bos + eos > padlen"
     assert lib.bsq_tuning_set(b"no_such_knob", 1) == capi.ERR_INVALID_ARG
+    # result-changing ablations and the experiment kernels that lost exist only in -DBSQ_LABS builds: the product
+    # library refuses their knobs, and no environment variable reaches them
+    for labs_knob in (b"tokens8_abl", b"expand_mode", b"xcd_claim", b"chunk_math", b"tokenize_nch", b"chunks_cpw", b"augment_mode"):
+        assert lib.bsq_tuning_set(labs_knob, 1) == capi.ERR_INVALID_ARG, labs_knob
+        assert lib.bsq_tuning_get(labs_knob) == 0
     assert lib.bsq_tuning_set(b"onehot_path", 0) == capi.OK and lib.bsq_tuning_get(b"onehot_path") == 0
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("AMINO20")), 65536, 1024, capi.F32) == b"k_tokens_raw+k_expand_chunks"
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("AMINO20")), 8192, 1024, capi.F32) == b"k_onehot_chunks"
@@ -128,3 +133,16 @@ def test_index_math_selftest():
     exact multiples and the top of both ranges."""
     from bioseq_amd import capi
     assert capi.load().bsq_selftest_index_math() == 0
+
+
+def test_environment_cannot_reach_result_changing_knobs():
+    """BSQ_TOKENS8_ABL / BSQ_EXPAND_MODE used to select ablation kernels whose output is wrong on purpose (ADVICE round 2,
+    medium): in the product build they are not knobs at all; ordinary knobs still take their initial value from the
+    environment."""
+    import subprocess
+    import sys
+    code = ("import ctypes; from bioseq_amd import capi; L = capi.load(); "
+            "print(L.bsq_tuning_get(b'tokens8_abl'), L.bsq_tuning_get(b'expand_mode'), L.bsq_tuning_get(b'onehot_path'), L.bsq_tuning_get(b'nt_stores'))")
+    env = dict(os.environ, BSQ_TOKENS8_ABL="4", BSQ_EXPAND_MODE="9", BSQ_ONEHOT_PATH="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, check=True).stdout.split()
+    assert out == ["0", "0", "2", "1"], out
