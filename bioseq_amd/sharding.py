@@ -14,14 +14,13 @@ Whole-batch assembly:
     (one extra read+write of the tensor on the receiver; SURVEY.md section 8e option 2).
 Ragged shard counts (B % world != 0) are padded to the largest shard for the collective and trimmed.
 
-`gather_direct` is the point-to-point form (SURVEY.md section 8e option 1): no ring, no staging, no concatenate.
+`gather_direct` is the point-to-point form (SURVEY.md section 8e option 1): no ring.
 xGMI is a full mesh of point-to-point links (7 links x ~153 GB/s per GPU), so every rank posts ONE grouped
-batch of isend / irecv -- peer k of the group is rank +- k, i.e. every link of the mesh carries exactly one shard
-in each direction at the same time -- and the receives land straight in the destination tensor: batch-first slabs
-as one message per peer, seq-first / one-hot column blocks as one message per (peer, position row) (a row's block
-of B_g * C elements is contiguous in the destination even though the block as a whole is not).  `root=r` is the
-gather `north_star` names (only rank r ends up with the whole batch, the others only send); `root=None` leaves the
-whole batch on every rank like all_gather does.
+batch of isend / irecv with ONE message per peer -- peer k of the group is rank +- k, i.e. every link of the mesh
+carries exactly one shard in each direction at the same time: batch-first slabs land straight in the destination
+tensor, seq-first / one-hot column blocks in a per-peer staging buffer that one strided device copy lays into the
+result (an HBM pass, a few percent of the link time).  `root=r` is the gather `north_star` names (only rank r ends
+up with the whole batch, the others only send); `root=None` leaves the whole batch on every rank like all_gather does.
 
 `onehot_gathered` is the xGMI-friendly form of the whole-batch one-hot: the shards that travel are the raw
 uint8 TOKEN matrices (P, B_g) -- 1/(C*sizeof(T)) of the one-hot's bytes, 1/80 at cfg3 -- and every rank expands
@@ -100,12 +99,17 @@ def _gather(local, batch_axis: int, B: int, group=None):
     return torch.cat(_all_gather_padded(local, batch_axis, B, group), dim=batch_axis)
 
 
-def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, group=None, rows_per_call: int = 64):
-    """Whole batch from per-rank shards by grouped point-to-point transfers written straight into the result.
+def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, group=None, rows_per_call: int = 0):
+    """Whole batch from per-rank shards by grouped point-to-point transfers: ONE message per peer.
 
     local: this rank's shard, contiguous; batch_axis 0 = (B_g, ...) slabs, 1 = (P, B_g, ...) column blocks.
     root: None -> every rank returns the whole batch; r -> only (group) rank r does, the others return None.
-    rows_per_call: position rows per batch_isend_irecv call (bounds the number of operations in one RCCL group).
+    Batch-first slabs are received straight into the result.  Column blocks (seq-first tokens, the (P,B,C) one-hot)
+    arrive as one contiguous message per peer in a staging buffer and are laid into the result by one strided device
+    copy each -- an HBM pass (5.4 GB at cfg3: ~2 ms) against >= 35 ms of xGMI time for the same bytes.  (Until round 3
+    every position row of every peer was its own message: P x (world - 1) sends and as many receives per rank, 7168 +
+    7168 at cfg3 on 8 ranks -- per-operation overhead, not link bandwidth, would have bounded it.  rows_per_call > 0
+    keeps that form, in calls of that many rows, for measurement.)
     """
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -139,18 +143,34 @@ def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, gr
         ops += [dist.P2POp(dist.isend, local, peer(r), group) for r in sends]
         if ops:
             reqs += dist.batch_isend_irecv(ops)
+        for q in reqs:
+            q.wait()
+    elif rows_per_call <= 0:
+        stage = {}
+        for r in recvs:
+            shape = list(local.shape)
+            shape[1] = bounds[r][1] - bounds[r][0]
+            stage[r] = local.new_empty(shape)
+        ops = [dist.P2POp(dist.irecv, stage[r], peer(r), group) for r in recvs]
+        ops += [dist.P2POp(dist.isend, local, peer(r), group) for r in sends]
+        if ops:
+            reqs += dist.batch_isend_irecv(ops)
+        for q in reqs:
+            q.wait()
+        for r in recvs:  # column block of every position row: one strided copy per peer
+            full.narrow(1, bounds[r][0], bounds[r][1] - bounds[r][0]).copy_(stage[r])
     else:
         P = int(local.shape[0])
-        for t0 in range(0, P, max(1, rows_per_call)):
+        for t0 in range(0, P, rows_per_call):
             ops = []
-            for t in range(t0, min(P, t0 + max(1, rows_per_call))):
+            for t in range(t0, min(P, t0 + rows_per_call)):
                 ops += [dist.P2POp(dist.irecv, full[t].narrow(0, bounds[r][0], bounds[r][1] - bounds[r][0]), peer(r), group)
                         for r in recvs]
                 ops += [dist.P2POp(dist.isend, local[t], peer(r), group) for r in sends]
             if ops:
                 reqs += dist.batch_isend_irecv(ops)
-    for q in reqs:
-        q.wait()
+        for q in reqs:
+            q.wait()
     return full
 
 

@@ -61,7 +61,9 @@ def _worker(rank, world, port, B, P, q):
         direct_ok = (d_oh.numpy().tobytes() == full_oh.tobytes() and d_bf.numpy().tobytes() == full_bf.tobytes()
                      and d_sf.numpy().tobytes() == full_sf.tobytes())
         for root in range(world):
-            r_oh = sharding.gather_direct(torch.from_numpy(keep), 1, B, root, rows_per_call=5)
+            r_oh = sharding.gather_direct(torch.from_numpy(keep), 1, B, root, rows_per_call=5)     # one message per (peer, row)
+            r_oh1 = sharding.gather_direct(torch.from_numpy(keep), 1, B, root)                     # one message per peer (default)
+            direct_ok = direct_ok and ((r_oh1 is None) if rank != root else r_oh1.numpy().tobytes() == full_oh.tobytes())
             r_bf = sharding.gather_direct(torch.from_numpy(np.ascontiguousarray(full_bf[slice(*sharding.shard_bounds(B, world, rank))])), 0, B, root)
             if rank == root:
                 direct_ok = direct_ok and r_oh.numpy().tobytes() == full_oh.tobytes() and r_bf.numpy().tobytes() == full_bf.tobytes()
