@@ -451,6 +451,19 @@ def main():
                 "ms": timed(lambda: expand(sharding.gather_direct(raw_tokens(d_chars, d_offs), 1, n_job, None).contiguous()), 1),
                 "what": "token pass on the shard + point-to-point gather of the (P, B_g) uint8 token matrices (%d bytes "
                         "received per rank) + local expansion of the whole batch" % int(recv_bytes / max(1, C * sz))}
+        if (op == "tokenize" and batch_first) or op == "onehot_bcl":
+            # SURVEY 8e option 3: the encode kernels of every rank store straight into rank 0's buffer (IPC-mapped memory over
+            # xGMI): encode AND gather in one step, no collective on the data path.  Slab layouts only.
+            import bioseq_amd as _pkg
+            tokz = _pkg.Tokenizer(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
+            try:
+                forms["store_into_root"] = {
+                    "ms": timed(lambda: sharding.store_shard_into_root(tokz, d_chars, d_offs, first, n_job, P,
+                                                                       destchar, "tokens_bf" if op == "tokenize" else "bcl", dev, 0, None, False), None),
+                    "what": "every rank ENCODES its shard directly into rank 0's buffer through peer-mapped memory "
+                            "(sharding.store_shard_into_root): the time includes the encode; no data-path collective"}
+            except Exception as ex:  # an IPC / peer-mapping failure must not cost the run its other numbers
+                forms["store_into_root"] = {"ms": float("nan"), "what": "failed: %r" % (ex,)}
         for f in forms.values():
             f["gb_per_s_into_each_rank"] = recv_bytes / (f["ms"] * 1e-3) / 1e9
         gather_info = {"bytes_received_per_rank": recv_bytes, "forms": forms, "note": "encode time excluded; mean of %d "

@@ -22,6 +22,11 @@ tensor, seq-first / one-hot column blocks in a per-peer staging buffer that one 
 result (an HBM pass, a few percent of the link time).  `root=r` is the gather `north_star` names (only rank r ends
 up with the whole batch, the others only send); `root=None` leaves the whole batch on every rank like all_gather does.
 
+`encode_into_root` is SURVEY.md section 8e option 3 for the layouts in which a shard is one contiguous slab of the result
+(batch-first tokens, the channels-first one-hot): the root's buffer is mapped into every rank through an IPC handle
+(`open_root_buffer`) and the encode kernels store straight into it over xGMI -- the only form with no data-path collective
+and no second pass over the bytes.
+
 `onehot_gathered` is the xGMI-friendly form of the whole-batch one-hot: the shards that travel are the raw
 uint8 TOKEN matrices (P, B_g) -- 1/(C*sizeof(T)) of the one-hot's bytes, 1/80 at cfg3 -- and every rank expands
 the assembled (P, B) token matrix into the (P, B, C) tensor locally at HBM speed (the second pass of the
@@ -234,6 +239,97 @@ def device_passes(tokenizer, padlen: int, destchar: str, device):
         return out
 
     return raw_tokens, expand
+
+
+def open_root_buffer(shape, dtype, device, root: int = 0, group=None):
+    """SURVEY.md section 8e option 3, step 1 (collective): rank `root` allocates the whole-batch tensor in ITS HBM, every
+    other rank maps the same memory into its own address space through an IPC handle (torch.multiprocessing's
+    hipIpcGetMemHandle / hipIpcOpenMemHandle path; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver).  A kernel on a peer
+    GPU that stores through the mapped tensor writes over xGMI straight into the root's memory: no collective, no
+    staging, no copy.  Returns the tensor (the real one on `root`, the mapped view elsewhere); keep it alive on `root`
+    until every rank is done with it."""
+    import torch
+    from torch.multiprocessing.reductions import reduce_tensor
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if not 0 <= root < world:
+        raise ValueError("bad root")
+    src = dist.get_global_rank(group, root) if group is not None else root
+    payload = [None]
+    full = None
+    if rank == root:
+        full = torch.empty(tuple(shape), dtype=dtype, device=device)
+        payload = [reduce_tensor(full)]
+    dist.broadcast_object_list(payload, src=src, group=group)
+    if rank != root:
+        rebuild, args = payload[0]
+        full = rebuild(*args)
+    return full
+
+
+def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int, padlen: int, destchar: str, layout: str,
+                          device, root: int = 0, group=None, validate: bool = True):
+    """SURVEY.md section 8e option 3: this rank encodes ITS shard (sequences [b0, b0 + B_g) of a B-sequence batch, packed,
+    on `device`) with the ordinary kernels, but the output pointer is its slab of the ROOT's buffer (peer-mapped,
+    `open_root_buffer`) -- the stores of the encode kernels are the gather.  No data-path collective: one small object
+    broadcast (the handle) before, one barrier after.  Collective call (every rank of the group).
+
+    layout: 'tokens_bf' -> (B, padlen) tokens, 'bcl' -> (B, C, padlen) one-hot -- the layouts in which a rank's shard is one
+    CONTIGUOUS slab of the result.  (The seq-first (P, B, C) one-hot is a column block of every position row, and the
+    expansion kernels write their output as ONE flat stream: it would take a row-pitch form of them; use `gather_direct`
+    or `onehot_gathered` for that layout.)  Returns the whole-batch tensor on `root`, None elsewhere."""
+    import ctypes
+
+    import torch
+
+    from . import capi
+    dist = _dist()
+    rank = dist.get_rank(group)
+    if layout not in ("tokens_bf", "bcl"):
+        raise ValueError("layout must be 'tokens_bf' or 'bcl' (a shard must be a contiguous slab of the result)")
+    lib = capi.load()
+    desc = capi.make_desc(tokenizer.key, tokenizer.includes_eos(), tokenizer.includes_bos(), tokenizer.is_padded())
+    C = int(tokenizer.alphabet_size())
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt)))
+    tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt.value]
+    dev = torch.device(device)
+    shape = (int(B), padlen) if layout == "tokens_bf" else (int(B), C, padlen)
+    full = open_root_buffer(shape, tdt, dev, root, group)
+    ch = torch.as_tensor(shard_chars).to(dev)
+    of = torch.as_tensor(shard_offsets).to(dev).to(torch.int64).contiguous()
+    nb = int(of.shape[0]) - 1
+    if nb > 0:
+        slab = full[b0:b0 + nb]
+        assert slab.is_contiguous() and slab.shape[0] == nb
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if validate:
+                bad = ctypes.c_int64(-1)
+                capi.check(lib.bsq_validate_packed_device(of.data_ptr(), nb, padlen, desc.bos, desc.eos, ch.numel(), ctypes.byref(bad), stream))
+            if layout == "tokens_bf":
+                capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), nb, padlen, 1, dt,
+                                                   slab.data_ptr(), stream))
+            else:
+                capi.check(lib.bsq_onehot_bcl_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), None, nb, padlen, dt,
+                                                     slab.data_ptr(), stream))
+    torch.cuda.synchronize(dev)   # this rank's stores have left its GPU ...
+    dist.barrier(group=group)     # ... and every rank's have: the root may read the batch
+    if rank != root:
+        del full
+        return None
+    return full
+
+
+def encode_into_root(tokenizer, chars, offsets, padlen: int, destchar: str, layout: str, device, root: int = 0, group=None):
+    """`store_shard_into_root` for a WHOLE packed batch (host arrays or tensors) that every rank holds: sharded here with
+    `shard_bounds`."""
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = int(offsets.shape[0]) - 1
+    b0, _ = shard_bounds(B, world, rank)
+    c, o = shard_packed(chars, offsets, world, rank)
+    return store_shard_into_root(tokenizer, c, o, b0, B, padlen, destchar, layout, device, root, group)
 
 
 def encode_sharded(encode: Callable, chars, offsets, gather: Optional[str] = None, group=None):
