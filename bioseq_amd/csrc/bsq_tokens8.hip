@@ -356,17 +356,24 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8(const T8Params p) {
 //   * the scalars the first loads depend on are KERNEL ARGUMENTS IN SGPRs at wave start (14 dwords, gfx950 kernarg
 //     preload: -mllvm -amdgpu-kernarg-preload-count=14 in build.py) instead of five serialised rounds of s_load +
 //     s_waitcnt out of a 400-byte by-value struct;
-//   * the offsets loads are issued FIRST; the per-wave rule table (18 lanes x ~30 VALU + 2 ds_write_b128), the register
-//     alphabet table (one s_load_dwordx8) and offsets[B] are produced while they are in flight;
+//   * the offsets loads are issued FIRST; the per-wave rule table (host-built, two vector loads out of the kernel
+//     arguments + 2 ds_write_b128), the register alphabet table (one s_load_dwordx8) and offsets[B] arrive while they are in flight;
 //   * one division constant pair for every row width (powers of two as magic = 2^(32-s), shift 0: no branch per divide).
 struct T8Tab {
     uint32_t t[8];
+};
+// The BOS / EOS / PAD rule table of a launch (entry n + 1: n bytes kept, byte n = the token at bos + L, the rest fill), built
+// on the HOST and handed over in the kernel-argument segment: every wave copies its 576 bytes into LDS with two vector loads
+// instead of rebuilding them with ~45 vector instructions (of ~490 per wave).
+struct T8Rules {
+    uint4 keep[18];
+    uint4 cst[18];
 };
 template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                               uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
                                                               uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
-                                                              T8Tab tab) {
+                                                              T8Tab tab, T8Rules rules) {
     __shared__ __align__(16) uint4 s_rule[4][2][18];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t wave_s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(wave));
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
     if (k0 >= nchunks) return;
     auto div_p = [&](uint32_t n) { return __umulhi(n, magic) >> shift; };
     const uint32_t bos = packed & 1u, none_v = (packed & 2u) ? 0xFFu : 0u;
-    const uint32_t bos_id = (packed >> 8) & 0xFFu, at_len_v = (packed >> 16) & 0xFFu, fill_v = packed >> 24;
+    const uint32_t bos_id = (packed >> 8) & 0xFFu;
 
     // ---- rows of the chunk; their offsets go out first ----
     const uint32_t g0 = k0 * (kChunk / 16);  // first piece (nchunks < 2^23)
@@ -394,28 +401,17 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
     for (int i = 0; i < 8; ++i) T[i] = tab.t[i];
     asm volatile("" : "+s"(T[0]), "+s"(T[1]), "+s"(T[2]), "+s"(T[3]), "+s"(T[4]), "+s"(T[5]), "+s"(T[6]), "+s"(T[7]), "+s"(total_chars));
 
-    // ---- per-wave rule table, built while the offsets are in flight ----
+    // ---- per-wave rule table: copied out of the kernel arguments while the offsets are in flight ----
     {
-        const uint32_t fill_w = fill_v * 0x01010101u, at_w = at_len_v * 0x01010101u;
-        if (lane < 18) {  // entry `lane`: n = lane - 1 bytes kept, byte n (if any) = token at bos + L, the rest fill
-            const int n = lane - 1;
-            uint32_t keep[4], cst[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nv = n - 4 * q;
-                const int nvc = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
-                const uint32_t kq = nvc == 4 ? 0xFFFFFFFFu : ((1u << (8 * nvc)) - 1u);
-                const uint32_t at = (nv >= 0 && nv < 4) ? (0xFFu << (8 * nv)) : 0u;
-                keep[q] = kq;
-                cst[q] = (fill_w & ~kq & ~at) | (at_w & at);
-            }
-            s_rule[wave][0][lane] = uint4{keep[0], keep[1], keep[2], keep[3]};
-            s_rule[wave][1][lane] = uint4{cst[0], cst[1], cst[2], cst[3]};
+        if (lane < 18) {
+            s_rule[wave][0][lane] = rules.keep[lane];
+            s_rule[wave][1][lane] = rules.cst[lane];
         }
         // wave-private: LDS operations of one wave execute in order, only the compiler must not reorder them
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+
     // ---- the characters: 4 unconditional unaligned 16-byte loads, all in flight together (see k_tokens_bp8) ----
     const int64_t off0 = (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(static_cast<int32_t>(o0 >> 32))) << 32) |
                          static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int32_t>(o0)));
@@ -605,12 +601,30 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
         const uint32_t packed = uint32_t(c.bos != 0) | (raw ? 2u : 0u) | (c.bos_id << 8) | ((c.at_len_v & 0xFFu) << 16) | ((c.fill_v & 0xFFu) << 24);
         T8Tab tab;
         for (int i = 0; i < 8; ++i) tab.t[i] = c.tab[i];
+        T8Rules rules;
+        {
+            const uint32_t fill_w = (c.fill_v & 0xFFu) * 0x01010101u, at_w = (c.at_len_v & 0xFFu) * 0x01010101u;
+            for (int e = 0; e < 18; ++e) {  // entry e: n = e - 1 bytes kept, byte n (if any) = token at bos + L, the rest fill
+                const int n = e - 1;
+                uint32_t keep[4], cst[4];
+                for (int q = 0; q < 4; ++q) {
+                    const int nv = n - 4 * q;
+                    const int nvc = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+                    const uint32_t kq = nvc == 4 ? 0xFFFFFFFFu : ((1u << (8 * nvc)) - 1u);
+                    const uint32_t at = (nv >= 0 && nv < 4) ? (0xFFu << (8 * nv)) : 0u;
+                    keep[q] = kq;
+                    cst[q] = (fill_w & ~kq & ~at) | (at_w & at);
+                }
+                rules.keep[e] = uint4{keep[0], keep[1], keep[2], keep[3]};
+                rules.cst[e] = uint4{cst[0], cst[1], cst[2], cst[3]};
+            }
+        }
         if (nt)
             hipLaunchKernelGGL((k_tokens_bp8_fast<true>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks),
-                               uint32_t(B), c.ppr, magic, shift, c.room, packed, tab);
+                               uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules);
         else
             hipLaunchKernelGGL((k_tokens_bp8_fast<false>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks),
-                               uint32_t(B), c.ppr, magic, shift, c.room, packed, tab);
+                               uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules);
         const hipError_t ef = hipGetLastError();
         if (ef != hipSuccess) return set_hip_error("k_tokens_bp8_fast", ef);
         return BSQ_OK;
