@@ -167,23 +167,28 @@ __global__ __launch_bounds__(256) void k_augment(uint8_t *chars, const int64_t *
 constexpr int kSeqPerWave = 64;
 __global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len,
                                                         double frac, uint64_t seed, const AugTable *tab) {
-    __shared__ AugTable s_tab;
+    __shared__ __align__(16) AugTable s_tab;
     __shared__ int64_t s_start[4][kSeqPerWave], s_len[4][kSeqPerWave];
     __shared__ uint64_t s_h0[4][kSeqPerWave];
     __shared__ uint32_t s_ctr[4][kSeqPerWave];
     __shared__ int32_t s_rem[4][kSeqPerWave], s_tries[4][kSeqPerWave];
-    for (int i = threadIdx.x; i < int(sizeof(AugTable) / 4); i += 256)
-        reinterpret_cast<uint32_t *>(&s_tab)[i] = reinterpret_cast<const uint32_t *>(tab)[i];
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t b = (static_cast<int64_t>(blockIdx.x) * 4 + wave) * kSeqPerWave + lane;
-    {   // home lanes: which sequences are augmented at all (word 0 of their stream), their spans and keys
+    // the spans first: their loads are in flight while the table is staged (round 3: the kernel is latency-bound --
+    // 59 % of its wave cycles are waits, profiles/r03/augment_groups_pmc.txt -- and this was one dependent round trip more)
+    int64_t start = 0, L = 0;
+    if (b < B) {
+        start = offsets[b];
+        L = offsets[b + 1] - start;
+    }
+    static_assert(sizeof(AugTable) % 16 == 0, "staged as 16-byte pieces");
+    for (int i = threadIdx.x; i < int(sizeof(AugTable) / 16); i += 256)
+        reinterpret_cast<uint4 *>(&s_tab)[i] = reinterpret_cast<const uint4 *>(tab)[i];
+    __syncthreads();
+    {   // home lanes: which sequences are augmented at all (word 0 of their stream), their keys
         int32_t rem = 0;
-        int64_t start = 0, L = 0;
         uint64_t h0 = 0;
         if (b < B) {
-            start = offsets[b];
-            L = offsets[b + 1] - start;
             h0 = mix64(seed + 0x9E3779B97F4A7C15ull * (static_cast<uint64_t>(b) + 1));
             const bool pick = L > 0 && (!(frac < 1.0) || unit(mix64(h0 + 0xD1342543DE82EF95ull)) < frac);
             rem = pick ? chain_len : 0;
