@@ -457,15 +457,16 @@ def main():
                 "ms": timed(lambda: expand(sharding.gather_direct(raw_tokens(d_chars, d_offs), 1, n_job, None).contiguous()), 1),
                 "what": "token pass on the shard + point-to-point gather of the (P, B_g) uint8 token matrices (%d bytes "
                         "received per rank) + local expansion of the whole batch" % int(recv_bytes / max(1, C * sz))}
-        if (op == "tokenize" and batch_first) or op == "onehot_bcl":
+        if (op == "tokenize" and batch_first) or op in ("onehot_bcl", "onehot"):
             # SURVEY 8e option 3: the encode kernels of every rank store straight into rank 0's buffer (IPC-mapped memory over
-            # xGMI): encode AND gather in one step, no collective on the data path.  Slab layouts only.
+            # xGMI): encode AND gather in one step, no collective on the data path.  (The seq-first one-hot goes through the
+            # tiled kernel with the root tensor's row pitch, bsq_onehot_block_device.)
             import bioseq_amd as _pkg
             tokz = _pkg.Tokenizer(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
             try:
                 forms["store_into_root"] = {
                     "ms": timed(lambda: sharding.store_shard_into_root(tokz, d_chars, d_offs, first, n_job, P,
-                                                                       destchar, "tokens_bf" if op == "tokenize" else "bcl", dev, 0, None, False), None),
+                                                                       destchar, {"tokenize": "tokens_bf", "onehot_bcl": "bcl", "onehot": "tbc"}[op], dev, 0, None, False), None),
                     "what": "every rank ENCODES its shard directly into rank 0's buffer through peer-mapped memory "
                             "(sharding.store_shard_into_root): the time includes the encode; no data-path collective"}
             except Exception as ex:  # an IPC / peer-mapping failure must not cost the run its other numbers

@@ -77,6 +77,7 @@ struct KParams {
     int32_t order;    // 0: sequence-tile index fastest over blockIdx, 1: position-tile index fastest, 2: XCD-aware
     int32_t group;    // order 2: sequence tiles per XCD and group (see tile_of_block)
     int64_t out_pitch;  // k_tokens_raw only: bytes between two position rows of its output
+    int64_t row_seqs;  // k_onehot_tile: sequences per position row of the DESTINATION tensor (= B unless the batch is a column block of a larger one)
     uint64_t one_bits;
     uint32_t tab_raw[8], tab_val[8];  // 32-entry folded alphabet (index c & 31): ids with kNone / values with 0 for unmapped
     int32_t foldable;                 // the folded tables represent lut[] exactly (letters only, both cases alike)
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TB == 
     const int32_t nb = nb64 < TB ? static_cast<int32_t>(nb64) : TB;
     const int32_t seg = nb * C * static_cast<int32_t>(sizeof(ST));  // bytes of one output row segment
     const ST one = static_cast<ST>(p.one_bits);
-    const int64_t row_pitch = p.B * C * static_cast<int64_t>(sizeof(ST));
+    const int64_t row_pitch = p.row_seqs * C * static_cast<int64_t>(sizeof(ST));
     uint8_t *gtile = static_cast<uint8_t *>(p.out) + b0 * C * static_cast<int64_t>(sizeof(ST));
 
     constexpr int kRowsPerWave = kTT / 4;
@@ -1676,6 +1677,7 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     k.aligned = 0;
     k.vw = 1;
     k.out_pitch = B;
+    k.row_seqs = B;
     k.one_bits = 1;
     {   // folded tables (see k_tokens_raw2): exact iff only letter positions are mapped and both cases map alike
         bool ok = true;
@@ -2268,6 +2270,34 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
         bsq_internal::workspace_release(ws, s);
         return wst;
     }
+    switch (sz) {
+    case 1: return dispatch_onehot_tile<uint8_t>(k, s);
+    case 2: return dispatch_onehot_tile<uint16_t>(k, s);
+    case 4: return dispatch_onehot_tile<uint32_t>(k, s);
+    default: return dispatch_onehot_tile<uint64_t>(k, s);
+    }
+}
+
+bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                   const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out, int64_t row_seqs,
+                                   void *hip_stream) {
+    if (row_seqs < B) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "row_seqs < B");
+    if (row_seqs == B) return bsq_onehot_device(d, chars, offsets, mask_or_null, B, P, t, out, hip_stream);
+    KParams k;
+    bsq_status st = fill_common(k, d, chars, offsets, mask_or_null, B, P, out);
+    if (st != BSQ_OK) return st;
+    if (B == 0) return BSQ_OK;
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    if (reinterpret_cast<uintptr_t>(out) % sz) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output is not aligned to its element size");
+    if (choose_onehot_path(k.C, sz, B, P, false) == 0)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "column-block one-hot: alphabets with ids > 250 / shapes of the generic kernel are not supported");
+    // the tiled kernel: a workgroup owns (sequence tile x 64 positions) and writes one row SEGMENT per position, so a row
+    // pitch other than B * C is just another stride (the chunk kernels write the tensor as one flat stream and cannot)
+    k.one_bits = one_bits_of(t);
+    k.row_seqs = row_seqs;
+    k.aligned = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && ((row_seqs * k.C * int64_t(sz)) % 16 == 0);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
     switch (sz) {
     case 1: return dispatch_onehot_tile<uint8_t>(k, s);
     case 2: return dispatch_onehot_tile<uint16_t>(k, s);

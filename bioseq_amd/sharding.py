@@ -22,10 +22,10 @@ tensor, seq-first / one-hot column blocks in a per-peer staging buffer that one 
 result (an HBM pass, a few percent of the link time).  `root=r` is the gather `north_star` names (only rank r ends
 up with the whole batch, the others only send); `root=None` leaves the whole batch on every rank like all_gather does.
 
-`encode_into_root` is SURVEY.md section 8e option 3 for the layouts in which a shard is one contiguous slab of the result
-(batch-first tokens, the channels-first one-hot): the root's buffer is mapped into every rank through an IPC handle
-(`open_root_buffer`) and the encode kernels store straight into it over xGMI -- the only form with no data-path collective
-and no second pass over the bytes.
+`store_shard_into_root` / `encode_into_root` are SURVEY.md section 8e option 3: the root's buffer is mapped into every rank
+through an IPC handle (`open_root_buffer`) and the encode kernels store straight into it over xGMI -- the only form with no
+data-path collective and no second pass over the bytes.  Batch-first tokens and the channels-first one-hot are contiguous
+slabs of the result; the seq-first (P, B, C) one-hot is written as a column block by `bsq_onehot_block_device`.
 
 `onehot_gathered` is the xGMI-friendly form of the whole-batch one-hot: the shards that travel are the raw
 uint8 TOKEN matrices (P, B_g) -- 1/(C*sizeof(T)) of the one-hot's bytes, 1/80 at cfg3 -- and every rank expands
@@ -274,10 +274,11 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
     `open_root_buffer`) -- the stores of the encode kernels are the gather.  No data-path collective: one small object
     broadcast (the handle) before, one barrier after.  Collective call (every rank of the group).
 
-    layout: 'tokens_bf' -> (B, padlen) tokens, 'bcl' -> (B, C, padlen) one-hot -- the layouts in which a rank's shard is one
-    CONTIGUOUS slab of the result.  (The seq-first (P, B, C) one-hot is a column block of every position row, and the
-    expansion kernels write their output as ONE flat stream: it would take a row-pitch form of them; use `gather_direct`
-    or `onehot_gathered` for that layout.)  Returns the whole-batch tensor on `root`, None elsewhere."""
+    layout: 'tokens_bf' -> (B, padlen) tokens and 'bcl' -> (B, C, padlen) one-hot: a rank's shard is one CONTIGUOUS slab of
+    the result, written by the streaming kernels; 'tbc' -> the seq-first (padlen, B, C) one-hot: the shard is a column block
+    of every position row and goes through `bsq_onehot_block_device` (the tiled kernel with the root tensor's row pitch --
+    slower than the flat-stream kernels in HBM terms, 0.68 vs 0.93 of the roofline at cfg3, but the xGMI links, not HBM,
+    bound a remote store).  Returns the whole-batch tensor on `root`, None elsewhere."""
     import ctypes
 
     import torch
@@ -285,8 +286,8 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
     from . import capi
     dist = _dist()
     rank = dist.get_rank(group)
-    if layout not in ("tokens_bf", "bcl"):
-        raise ValueError("layout must be 'tokens_bf' or 'bcl' (a shard must be a contiguous slab of the result)")
+    if layout not in ("tokens_bf", "bcl", "tbc"):
+        raise ValueError("layout must be 'tokens_bf', 'bcl' or 'tbc'")
     lib = capi.load()
     desc = capi.make_desc(tokenizer.key, tokenizer.includes_eos(), tokenizer.includes_bos(), tokenizer.is_padded())
     C = int(tokenizer.alphabet_size())
@@ -294,14 +295,15 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
     capi.check(lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt)))
     tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt.value]
     dev = torch.device(device)
-    shape = (int(B), padlen) if layout == "tokens_bf" else (int(B), C, padlen)
+    shape = {"tokens_bf": (int(B), padlen), "bcl": (int(B), C, padlen), "tbc": (padlen, int(B), C)}[layout]
     full = open_root_buffer(shape, tdt, dev, root, group)
     ch = torch.as_tensor(shard_chars).to(dev)
     of = torch.as_tensor(shard_offsets).to(dev).to(torch.int64).contiguous()
     nb = int(of.shape[0]) - 1
     if nb > 0:
-        slab = full[b0:b0 + nb]
-        assert slab.is_contiguous() and slab.shape[0] == nb
+        # 'tbc': this rank's sequences are a COLUMN BLOCK of every position row of the (P, B, C) tensor
+        slab = full[:, b0:b0 + nb] if layout == "tbc" else full[b0:b0 + nb]
+        assert layout == "tbc" or (slab.is_contiguous() and slab.shape[0] == nb)
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             if validate:
@@ -310,9 +312,12 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
             if layout == "tokens_bf":
                 capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), nb, padlen, 1, dt,
                                                    slab.data_ptr(), stream))
-            else:
+            elif layout == "bcl":
                 capi.check(lib.bsq_onehot_bcl_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), None, nb, padlen, dt,
                                                      slab.data_ptr(), stream))
+            else:  # the tiled kernel with the root tensor's row pitch (bsq_onehot_block_device)
+                capi.check(lib.bsq_onehot_block_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), None, nb, padlen, dt,
+                                                       slab.data_ptr(), int(B), stream))
     torch.cuda.synchronize(dev)   # this rank's stores have left its GPU ...
     dist.barrier(group=group)     # ... and every rank's have: the root may read the batch
     if rank != root:

@@ -118,6 +118,12 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
 bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                  const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                                  void *hip_stream);
+/* The same one-hot written as a COLUMN BLOCK of a larger (P, row_seqs, C) tensor: `out` points at element (0, b0, 0) of it and
+ * row t of this batch goes to out + t * row_seqs * C * sizeof(T).  What a rank of a sharded job needs to store its
+ * sequences straight into the whole-batch tensor of another GPU (peer-mapped memory, sharding.store_shard_into_root). */
+bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
+                                   const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out, int64_t row_seqs,
+                                   void *hip_stream);
 /* Name of the kernel(s) bsq_onehot_device would launch for this shape (profiling / bench labels). */
 const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_dtype t);
 /* Same results through the simple one-thread-per-element kernels (any shape/alignment/alphabet).

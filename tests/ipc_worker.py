@@ -36,6 +36,10 @@ def main():
                 exp = np.ascontiguousarray(ora.onehot_packed(chars, offs, P, "f").transpose(1, 2, 0))
                 ok = ok and got.cpu().numpy().tobytes() == exp.tobytes()
             del got
+            got = sharding.encode_into_root(tok, chars, offs, P, "f", "tbc", dev, root=root)     # seq-first (P, B, C): column blocks
+            if rank == root:
+                ok = ok and got.cpu().numpy().tobytes() == ora.onehot_packed(chars, offs, P, "f").tobytes()
+            del got
             dist.barrier()
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)

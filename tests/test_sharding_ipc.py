@@ -23,3 +23,36 @@ def test_two_ranks_encode_into_the_roots_buffer(gpu):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "IPC_ROOT_BUFFER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("key,flags,dtype", [("AMINO20", (1, 1, 1), "f"), ("DNA", (1, 1, 1), "b"), ("SEB8", (0, 1, 0), "h"), ("DNA5", (1, 0, 1), "d")])
+def test_onehot_written_as_a_column_block_of_a_larger_tensor(gpu, oracle, key, flags, dtype):
+    """bsq_onehot_block_device: three shards written side by side into ONE (P, B, C) tensor == the oracle's one-hot of the
+    whole batch; bytes outside the tensor untouched; ragged shard sizes, unaligned column offsets."""
+    import ctypes
+    import numpy as np
+    import torch
+    from bioseq_amd import capi, synth
+    lib = capi.load()
+    desc = capi.make_desc(key, *flags)
+    ora = oracle.OracleTokenizer(key, *flags)
+    C = ora.alphabet_size()
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(dtype.encode(), ctypes.byref(dt)))
+    tdt = {0: torch.int8, 1: torch.int16, 4: torch.float32, 5: torch.float64}[dt.value]
+    for B, P, cuts in ((1000, 130, (0, 333, 334, 1000)), (257, 64, (0, 1, 256, 257)), (70000, 40, (0, 30000, 30001, 70000))):
+        chars, offs = synth.synth_packed(B + P, B, 0, P - 2, synth.DIRTY)
+        exp = ora.onehot_packed(chars, offs, P, dtype)
+        guard = 64
+        buf = torch.full((P * B * C + 2 * guard,), 7, dtype=tdt, device=gpu)
+        full = buf[guard:guard + P * B * C].view(P, B, C)
+        for b0, b1 in zip(cuts[:-1], cuts[1:]):
+            c = torch.from_numpy(chars[offs[b0]:offs[b1]].copy()).to(gpu)
+            o = torch.from_numpy(offs[b0:b1 + 1] - offs[b0]).to(gpu)
+            capi.check(lib.bsq_onehot_block_device(ctypes.byref(desc), c.data_ptr(), o.data_ptr(), None, b1 - b0, P, dt,
+                                                   full[:, b0:b1].data_ptr(), B, None))
+        torch.cuda.synchronize()
+        host = buf.cpu().numpy()
+        assert (host[:guard] == 7).all() and (host[-guard:] == 7).all(), "wrote outside the tensor"
+        assert host[guard:-guard].tobytes() == exp.tobytes(), (key, B, P)
+    assert lib.bsq_onehot_block_device(ctypes.byref(desc), c.data_ptr(), o.data_ptr(), None, 10, P, dt, full.data_ptr(), 5, None) != 0   # row_seqs < B
