@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void k_augment(uint8_t *chars, const int64_t *
 // accepted attempt in counter order, that lane draws the new residue and writes it.  32 pending sequences take 2
 // attempts each, the ~16 left 4 each, the ~4 left 16 each: three or four dependent memory round trips per wave.
 constexpr int kSeqPerWave = 64;
+template <int K>
 __global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len,
                                                         double frac, uint64_t seed, const AugTable *tab) {
     __shared__ __align__(16) AugTable s_tab;
@@ -223,39 +224,64 @@ __global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const in
         const int sidx = have ? s_sel[wave][g] : 0;
         const int64_t start = s_start[wave][sidx], L = s_len[wave][sidx];
         const uint64_t h0 = s_h0[wave][sidx];
-        const uint32_t c = s_ctr[wave][sidx] + static_cast<uint32_t>(a);  // counter of this lane's attempt
+        const uint32_t ctr0 = s_ctr[wave][sidx];
         const int32_t tries = s_tries[wave][sidx];
-        const uint64_t r = mix64(h0 + 0xD1342543DE82EF95ull * (static_cast<uint64_t>(c) + 1));
-        const int64_t idx = static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(L)));  // uniform in [0, L)
-        bool accepted = false;
-        int row = 0;
-        double pself = 0.0;
-        if (have && tries + a < kMaxAttempts) {  // (attempts beyond the cap of this mutation are not made)
-            row = s_tab.row_of[chars[start + idx]];
-            pself = s_tab.self[row];
-            accepted = static_cast<double>(static_cast<uint32_t>(r)) * 0x1.0p-32 < 1.0 - pself;
+        // K attempts per lane and round (round 3): attempt j = k * A + a has counter ctr0 + j.  Every position is a function
+        // of (key, counter, length) alone, so the K gathers of a lane go out TOGETHER -- one memory round trip evaluates A * K
+        // attempts of a sequence instead of A.  K = 1 is the round-2 kernel; results do not depend on K (the first accepted
+        // attempt in counter order wins either way).  The kernel is latency-bound (59 % of its wave cycles are waits,
+        // profiles/r03/augment_groups_pmc.txt): K = 4 takes the typical wave from 3-4 dependent rounds to 2, 21.8 -> 17.3-18.2 us.
+        uint64_t r[K];
+        int64_t idx[K];
+        uint8_t ch[K];
+        bool valid[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t j = static_cast<uint32_t>(k * A + a);
+            r[k] = mix64(h0 + 0xD1342543DE82EF95ull * (static_cast<uint64_t>(ctr0 + j) + 1));
+            idx[k] = static_cast<int64_t>(__umul64hi(r[k], static_cast<uint64_t>(L)));  // uniform in [0, L)
+            valid[k] = have && tries + static_cast<int32_t>(j) < kMaxAttempts;         // (attempts beyond the cap of this mutation are not made)
         }
-        const uint64_t acc = __builtin_amdgcn_ballot_w64(accepted);
-        const uint64_t mine = (acc >> (g << shiftA)) & (A == 64 ? ~uint64_t(0) : ((uint64_t(1) << A) - 1));  // this group's attempts
+#pragma unroll
+        for (int k = 0; k < K; ++k) ch[k] = valid[k] ? chars[start + idx[k]] : uint8_t(0);
+        int win_k = -1, win_a = 0;  // group-uniform: the first accepted attempt in counter order
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool accepted = valid[k] && static_cast<double>(static_cast<uint32_t>(r[k])) * 0x1.0p-32 < 1.0 - s_tab.self[s_tab.row_of[ch[k]]];
+            const uint64_t acc = __builtin_amdgcn_ballot_w64(accepted);
+            const uint64_t mine = (acc >> (g << shiftA)) & (A == 64 ? ~uint64_t(0) : ((uint64_t(1) << A) - 1));  // this group's attempts
+            if (win_k < 0 && mine != 0) {
+                win_k = k;
+                win_a = __builtin_ctzll(mine);
+            }
+        }
         if (have) {
-            if (mine != 0) {
-                if (a == __builtin_ctzll(mine)) {  // first accepted attempt in counter order: draw the new residue, write it
+            if (win_k >= 0) {
+                if (a == win_a) {  // this lane made the winning attempt: draw the new residue, write it
+                    int64_t iw = idx[0];
+                    uint8_t cw = ch[0];
+#pragma unroll
+                    for (int k = 1; k < K; ++k)
+                        if (win_k == k) iw = idx[k], cw = ch[k];
+                    const uint32_t c = ctr0 + static_cast<uint32_t>(win_k * A + a);
+                    const int row = s_tab.row_of[cw];
+                    const double pself = s_tab.self[row];
                     const double *cdf = s_tab.cdf[row];
                     const double u = unit(mix64(h0 + 0xD1342543DE82EF95ull * (static_cast<uint64_t>(c) + 2))) * (cdf[kCols - 1] - pself);
                     int pick = -1;
-                    for (int k = 0; k < kCols; ++k) {
-                        if (k == row) continue;
-                        pick = k;
-                        if (u < cdf[k] - (k > row ? pself : 0.0)) break;
+                    for (int q = 0; q < kCols; ++q) {
+                        if (q == row) continue;
+                        pick = q;
+                        if (u < cdf[q] - (q > row ? pself : 0.0)) break;
                     }
-                    chars[start + idx] = s_tab.letter[pick];
+                    chars[start + iw] = s_tab.letter[pick];
                     s_ctr[wave][sidx] = c + 2;
                     s_rem[wave][sidx] -= 1;
                     s_tries[wave][sidx] = 0;
                 }
-            } else if (a == 0) {  // A rejections: the next counters, or give this mutation up at the cap like the twin
-                const int32_t made = tries + A < kMaxAttempts ? A : kMaxAttempts - tries;
-                s_ctr[wave][sidx] = c + static_cast<uint32_t>(made);
+            } else if (a == 0) {  // A * K rejections: the next counters, or give this mutation up at the cap like the twin
+                const int32_t made = tries + A * K < kMaxAttempts ? A * K : kMaxAttempts - tries;
+                s_ctr[wave][sidx] = ctr0 + static_cast<uint32_t>(made);
                 if (tries + made >= kMaxAttempts) {
                     s_rem[wave][sidx] -= 1;
                     s_tries[wave][sidx] = 0;
@@ -333,7 +359,16 @@ bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B,
         return BSQ_OK;
     }
 #endif
-    hipLaunchKernelGGL(k_augment_groups, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
+    // knob "augment_k": attempts per lane and round (0 automatic = 4; 1 = the round-2 form; 2) -- speed only
+    const int ak = bsq_internal::tuning().augment_k;
+    if (ak == 1)
+        hipLaunchKernelGGL(k_augment_groups<1>, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
+                           offsets, B, chain_len, frac, seed, tab);
+    else if (ak == 2)
+        hipLaunchKernelGGL(k_augment_groups<2>, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
+                           offsets, B, chain_len, frac, seed, tab);
+    else
+        hipLaunchKernelGGL(k_augment_groups<4>, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
                            offsets, B, chain_len, frac, seed, tab);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bsq_internal::set_hip_error("k_augment", e);

@@ -1,0 +1,5 @@
+#!/bin/bash
+OUT=gpurun_out/r03g; mkdir -p $OUT
+timeout 1200 python -m pytest tests/test_augment.py tests/test_bcl_and_loaders.py tests/test_index_batches.py tests/test_every_device.py -m gpu -x -q 2>&1 | tail -3
+for i in 1 2; do for k in 1 2 0; do echo "augment_k=$k cfg5aug: $(BSQ_AUGMENT_K=$k python3 bench.py --workload cfg5aug --no-cpu-baseline --no-e2e --no-sustained 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']; print('loop %.2f us frac %.3f' % (r['kernel_avg_ms']*1e3, r['frac']))")"; done; done | tee $OUT/augment_k_ab.txt
+bash scripts/r03_kstats.sh r03g/ks_final_aug --workload cfg5aug | tee -a $OUT/augment_k_ab.txt

@@ -85,11 +85,18 @@ def test_kernel_equals_its_twin_and_invariants(gpu):
     import torch
     from bioseq_amd import blosum, synth
     chars, offs = synth.synth_packed(31, 400, 0, 60, synth.AA + "XBZxa*")
+    from bioseq_amd import capi
+    lib = capi.load()
     for chain_len, frac, seed in ((1, 1.0, 7), (3, 0.5, 123456789012345), (2, 1.5, 2 ** 63 + 5)):
-        d = blosum.augment_packed(torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu), chain_len, frac, seed)
-        got = d.cpu().numpy()
         exp = twin(chars, offs, chain_len, frac, seed, blosum.normrows)
-        assert got.tobytes() == exp.tobytes()
+        for k in (1, 2, 4, 0):   # attempts per lane and round (knob augment_k): a speed matter only
+            capi.check(lib.bsq_tuning_set(b"augment_k", k))
+            try:
+                d = blosum.augment_packed(torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu), chain_len, frac, seed)
+            finally:
+                capi.check(lib.bsq_tuning_set(b"augment_k", 0))
+            got = d.cpu().numpy()
+            assert got.tobytes() == exp.tobytes(), (chain_len, frac, seed, k)
         ndiff, touched = 0, 0
         for b in range(len(offs) - 1):
             a, g = chars[offs[b]:offs[b + 1]], got[offs[b]:offs[b + 1]]
