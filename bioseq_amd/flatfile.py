@@ -86,8 +86,9 @@ class FlatFile:
         self._seq_offset = (self._n + 2) * 8
         self._offsets = self._mm[8:self._seq_offset].view("<u8").astype(np.int64)  # small copy: B+1 entries
         self._chars = self._mm[self._seq_offset:self._seq_offset + int(self._offsets[-1])]
+        self._longest = int(np.diff(self._offsets).max()) if self._n else 0   # the true maximum, whatever maxseqlen says
         if maxseqlen is None or maxseqlen < 0:
-            maxseqlen = int(np.diff(self._offsets).max()) if self._n else 0
+            maxseqlen = self._longest
         self._maxseqlen = int(maxseqlen)
         self._dev = {}
 
@@ -191,8 +192,7 @@ class FlatFile:
                 raise IndexError("Accessing sequence out of range")
             idx = torch.from_numpy(host).to(dev)
         n = idx.numel()
-        longest = int(np.diff(self._offsets).max()) if self._n else 0
-        capacity = n * longest
+        capacity = n * self._longest
         out_chars = torch.empty(max(capacity, 1), dtype=torch.uint8, device=dev)
         out_offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
         status = torch.empty(1, dtype=torch.int64, device=dev)
