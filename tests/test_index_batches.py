@@ -156,3 +156,43 @@ def test_a_shuffled_epoch_copies_nothing_host_to_device(gpu, bsq, oracle, tmp_pa
     perm = torch.randperm(2048, device=gpu, generator=g).cpu().numpy()
     exp = ora.batch_tokenize([seqs[i] for i in perm], padlen=ds.max_seq_len, batch_first=True).astype(np.int64)
     assert torch.cat(order).cpu().numpy().tobytes() == exp.tobytes()
+
+
+def test_a_loader_step_as_one_hip_graph(gpu, bsq, oracle, tmp_path):
+    """Gather + augmentation + encode of an index batch are plain stream-ordered launches: captured ONCE into a HIP graph and
+    replayed on new index lists (a launch-bound loader step becomes one graph launch).  Expected: the oracle on the gathered
+    sequences (augmentation off) / exactly one residue changed in about half of them (on)."""
+    import torch
+    from bioseq_amd import blosum
+    ff, seqs = make_store(tmp_path, n=4000, lo=1, hi=200)
+    tok, ora = bsq.Tokenizer("AMINO20", 1, 1, 1), oracle.OracleTokenizer("AMINO20", 1, 1, 1)
+    P, nb = 202, 512
+    ff.to_device(gpu)
+    idx = torch.zeros(nb, dtype=torch.int64, device=gpu)
+    rng = np.random.default_rng(8)
+
+    def step(augment):
+        chars, offs = ff.gather_device(idx, gpu, validate=False)      # validate=False: no synchronising status read inside a capture
+        if augment:
+            blosum.augment_packed(chars, offs, 1, 0.5, 1234)
+        return tok.tokenize_packed(chars, offs, P, "q", True, validate=False)
+
+    for augment in (False, True):
+        step(augment)                                                 # warm-up outside the capture (tables, scratch)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = step(augment)
+        for rep in range(3):
+            pick = rng.integers(0, 4000, size=nb)
+            idx.copy_(torch.from_numpy(pick))
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            exp = ora.batch_tokenize([seqs[i] for i in pick], padlen=P, batch_first=True).astype(np.int64)
+            got = out.cpu().numpy()
+            if not augment:
+                assert got.tobytes() == exp.tobytes()
+            else:
+                ndiff = (got != exp).sum(axis=1)
+                assert set(np.unique(ndiff)) <= {0, 1} and 0.35 * nb < (ndiff == 1).sum() < 0.65 * nb
