@@ -65,6 +65,23 @@ __device__ __forceinline__ uint32_t lookup4_perm(uint32_t cw, const uint32_t (&T
     return __builtin_amdgcn_perm(hi, lo, s4);
 }
 
+// The same lookup with the table in VECTOR registers and the selector constant 0x03020100 in one (round 3): gfx9 VOP3
+// encodings take neither a literal nor two scalar operands, so with the table in SGPRs every v_perm_b32 above costs a
+// v_mov_b32 of one table word first (4 per word of four tokens) and every selector a separate v_and + v_or: 18 vector
+// instructions per word.  Here 1 v_and + 4 v_perm + (v_lshrrev + v_and_or) x 2 + 3 v_perm = 12.
+__device__ __forceinline__ uint32_t lookup4_perm_v(uint32_t cw, const uint32_t (&Tv)[8], uint32_t k3210) {
+    const uint32_t sel = cw & 0x07070707u;
+    const uint32_t r0 = __builtin_amdgcn_perm(Tv[1], Tv[0], sel);
+    const uint32_t r1 = __builtin_amdgcn_perm(Tv[3], Tv[2], sel);
+    const uint32_t r2 = __builtin_amdgcn_perm(Tv[5], Tv[4], sel);
+    const uint32_t r3 = __builtin_amdgcn_perm(Tv[7], Tv[6], sel);
+    const uint32_t s3 = ((cw >> 1) & 0x04040404u) | k3210;  // byte i: i + 4 * bit 3 of character i
+    const uint32_t lo = __builtin_amdgcn_perm(r1, r0, s3);
+    const uint32_t hi = __builtin_amdgcn_perm(r3, r2, s3);
+    const uint32_t s4 = ((cw >> 2) & 0x04040404u) | k3210;  // ... bit 4
+    return __builtin_amdgcn_perm(hi, lo, s4);
+}
+
 // 0xFF in every byte of cw that is NOT a letter position (0x40..0x7F): those bytes are unmapped.
 __device__ __forceinline__ uint32_t nonletter_mask(uint32_t cw) {
     const uint32_t x = (cw ^ 0x40404040u) & 0xC0C0C0C0u;
@@ -504,6 +521,175 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
     }
 }
 
+// k_tokens_pb8_fast: the (P,B) int8 token matrix -- batch_tokenize's DEFAULT layout (batch_first=False,
+// tokenize.cpp:82-98) -- without a mask, rows (pitch) and output 16-byte aligned.  Round 3.
+// k_tokens_raw (bsq_kernels.hip) spends ~40 vector and ~10.6 LDS instructions per word of four tokens (byte lookups
+// in an LDS table, four transposed ds_write_b8 per word, spans staged through LDS) and sits at 0.59 of the HBM roof on
+// cfg2's shape, bound by instruction issue in BOTH pipes (profiles/r02/cfg2sf_sq_tcc_counters.txt).  Here, on a tile of
+// TB sequences x 64 positions:
+//   * lane (R, a, b) of a wave -- 16-lane row R, a = lane / 4 % 4, b = lane % 4 -- fetches the unaligned 16-byte piece b
+//     of sequence 4 (4 wave + R) + a of the pass: four adjacent lanes read 64 contiguous characters (a first form with
+//     one sequence per lane was bound by its 64-line load instructions: profiles/r03/pb8_lane_per_sequence_walk_lab.txt);
+//     the pieces of all TB / 64 passes are in flight together;
+//   * lookups out of the register table (LK = 1; foldable alphabets) or the LDS byte table (LK = 0), BOS / EOS / PAD
+//     from the host-built rule table, exactly as k_tokens_bp8_fast;
+//   * the byte transpose happens IN REGISTERS between the four lanes b, b + 4, b + 8, b + 12 of a row (the same piece of
+//     four consecutive sequences): v_mov_dpp row_ror:12 / row_ror:4 (bank masks) + v_perm_b32, then row_ror:8 + v_perm_b32
+//     leave lane (R, a, b) with position 16 b + 4 k + a of the row's four sequences -- ONE ds_write_b32 per word;
+//   * LDS tile: position p lives in physical row 4 (p % 16) + p / 16, row stride TB + 8 bytes (2 banks): the 32 writes of a
+//     half-wave fall on 32 banks; the rows leave as 8-byte LDS reads -> 16-byte stores of TB-byte segments.
+// XCD-aware order: block b -> class b % 8 walks its own sequence tiles, the position tiles of a sequence tile back to back.
+struct T8Lut {
+    uint32_t w[64];  // LK = 0: token VALUE of every byte (unmapped: none_v)
+};
+template <bool NT, int TB, int LK>
+__global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
+                                                              uint8_t *__restrict__ out, int64_t pitch, uint32_t B, uint32_t P,
+                                                              uint32_t ntb, uint32_t ntt, uint32_t magic, uint32_t shift, int32_t room,
+                                                              uint32_t packed, T8Tab tab, T8Rules rules, T8Lut lut) {
+    constexpr int TT = 64, STRIDE = TB + 8, PASSES = TB / 64;
+    static_assert(TB % 64 == 0 && (STRIDE / 4) % 32 == 2, "tile shape");
+    __shared__ __align__(16) uint4 s_rule[2][18];
+    __shared__ __align__(16) uint8_t s_lut[LK == 0 ? 256 : 16];
+    __shared__ __align__(16) uint8_t s_t[TT * STRIDE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t cls = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    const uint32_t tbl = (magic ? __umulhi(i, magic) : i) >> shift;  // i / ntt (magic 0: ntt is a power of two)
+    const uint32_t tt = i - tbl * ntt, tb = tbl * 8u + cls;
+    if (tb >= ntb) return;
+    const uint32_t bos = packed & 1u, none_v = (packed & 2u) ? 0xFFu : 0u;
+    const uint32_t bos_id = (packed >> 8) & 0xFFu;
+    const int32_t t0 = static_cast<int32_t>(tt) * TT;
+    const int la = (lane >> 2) & 3, lb = lane & 3;
+
+    // ---- the spans first (the four lanes of a sequence read the same two words) ----
+    int64_t o0[PASSES], o1[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const uint32_t b = tb * TB + ps * 64 + (tid >> 2);  // the lane's sequence of this pass
+        o0[ps] = offsets[b < B ? b : B];
+        o1[ps] = offsets[b + 1 < B ? b + 1 : B];
+    }
+    int64_t total_chars = offsets[B];
+    uint32_t T[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) T[q] = tab.t[q];
+    asm volatile("" : "+s"(T[0]), "+s"(T[1]), "+s"(T[2]), "+s"(T[3]), "+s"(T[4]), "+s"(T[5]), "+s"(T[6]), "+s"(T[7]), "+s"(total_chars));
+    uint32_t Tv[8], k3210 = 0x03020100u;  // the table and the selector constant in vector registers (see lookup4_perm_v)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Tv[q] = T[q];
+    asm volatile("" : "+v"(Tv[0]), "+v"(Tv[1]), "+v"(Tv[2]), "+v"(Tv[3]), "+v"(Tv[4]), "+v"(Tv[5]), "+v"(Tv[6]), "+v"(Tv[7]), "+v"(k3210));
+    if (tid < 18) {
+        s_rule[0][tid] = rules.keep[tid];
+        s_rule[1][tid] = rules.cst[tid];
+    }
+    if constexpr (LK == 0) {
+        if (tid >= 64 && tid < 128) reinterpret_cast<uint32_t *>(s_lut)[tid - 64] = lut.w[tid - 64];
+    }
+    __syncthreads();
+
+    // ---- the characters: the piece of every pass in flight together ----
+    const int32_t j0 = t0 + 16 * lb - static_cast<int32_t>(bos);  // character index of the piece's first byte (>= -1)
+    u32x4u cw[PASSES];
+    int32_t Lr[PASSES];
+    bool slow_any = false;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const uint32_t len = static_cast<uint32_t>(o1[ps] - o0[ps]);
+        Lr[ps] = static_cast<int32_t>(len > static_cast<uint32_t>(room) ? static_cast<uint32_t>(room) : len);
+        const int64_t a = o0[ps] + j0;
+        const bool need = j0 < Lr[ps];
+        const bool fast = need && a >= 0 && a + 16 <= total_chars;  // never read outside the buffer
+        slow_any |= need && !fast;
+        cw[ps] = u32x4u{0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+        if (fast) cw[ps] = *reinterpret_cast<const u32x4u *>(chars + a);
+    }
+    if (__builtin_amdgcn_ballot_w64(slow_any) != 0) {  // first / last bytes of the buffer (a handful of lanes per launch)
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int64_t a = o0[ps] + j0;
+            if (j0 < Lr[ps] && !(a >= 0 && a + 16 <= total_chars)) {
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+                for (int k = 0; k < 16; ++k)
+                    if (j0 + k >= 0 && j0 + k < Lr[ps]) w[k >> 2] |= static_cast<uint32_t>(chars[a + k]) << (8 * (k & 3));
+                cw[ps] = u32x4u{w[0], w[1], w[2], w[3]};
+            }
+        }
+    }
+
+    // ---- lookups, rules, transposes between the lanes a = 0..3 of a piece, one ds_write_b32 per word ----
+    const uint32_t sel1 = (la & 1) ? 0x03070105u : 0x06020400u;  // even a: (w0, p0, w2, p2); odd a: (p1, w1, p3, w3)
+    const uint32_t sel2 = (la & 2) ? 0x03020706u : 0x05040100u;  // a = 0, 1: (x.lo, y.lo); a = 2, 3: (y.hi, x.hi)
+    // word k of the lane goes to physical row 4 (4 k + a) + b, dword column 16 pass + 4 wave + R
+    uint8_t *wbase = s_t + (4 * la + lb) * STRIDE + wave * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int32_t dd = Lr[ps] - j0;
+        const int32_t idx = (dd < -1 ? -1 : (dd > 16 ? 16 : dd)) + 1;
+        const uint4 keep = s_rule[0][idx], cst = s_rule[1][idx];
+        const uint32_t in[4] = {cw[ps].x, cw[ps].y, cw[ps].z, cw[ps].w};
+        uint32_t w[4];
+        if constexpr (LK == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[q] = static_cast<uint32_t>(s_lut[in[q] & 0xFFu]) | (static_cast<uint32_t>(s_lut[(in[q] >> 8) & 0xFFu]) << 8) |
+                       (static_cast<uint32_t>(s_lut[(in[q] >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(s_lut[in[q] >> 24]) << 24);
+        } else {
+            uint32_t bad = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                w[q] = lookup4_perm_v(in[q], Tv, k3210);
+                bad |= (in[q] ^ 0x40404040u) & 0xC0C0C0C0u;
+            }
+            if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {  // some lane holds a non-letter: exact masks (rare)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t m = nonletter_mask(in[q]);
+                    w[q] = (w[q] & ~m) | (m & (none_v * 0x01010101u));
+                }
+            }
+        }
+        w[0] = (w[0] & keep.x) | cst.x;
+        w[1] = (w[1] & keep.y) | cst.y;
+        w[2] = (w[2] & keep.z) | cst.z;
+        w[3] = (w[3] & keep.w) | cst.w;
+        if (j0 < 0) w[0] = (w[0] & ~0xFFu) | bos_id;  // position 0 with BOS
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // the word of lane a ^ 1 (4 lanes away): row_ror:12 brings lane + 4 (even a: banks 0, 2), row_ror:4 lane - 4 (odd a)
+            int p1 = __builtin_amdgcn_update_dpp(0, static_cast<int>(w[q]), 0x12C, 0xF, 0x5, false);
+            p1 = __builtin_amdgcn_update_dpp(p1, static_cast<int>(w[q]), 0x124, 0xF, 0xA, false);
+            const uint32_t x = __builtin_amdgcn_perm(static_cast<uint32_t>(p1), w[q], sel1);
+            const uint32_t y = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x128, 0xF, 0xF, false));  // lane a ^ 2
+            const uint32_t tr = __builtin_amdgcn_perm(y, x, sel2);  // position 16 b + 4 q + a of the row's four sequences
+            *reinterpret_cast<uint32_t *>(wbase + 16 * q * STRIDE + ps * 64) = tr;
+        }
+    }
+    __syncthreads();
+
+    // ---- the tile's position rows: TB contiguous bytes of the output each ----
+    constexpr int PPR = TB / 16;       // 16-byte pieces per tile row
+    constexpr int RPI = kThreads / PPR;  // physical tile rows per step of the workgroup
+    static_assert(kThreads % PPR == 0 && RPI % 4 == 0 && TT % RPI == 0, "row walk");
+    const int row0 = tid / PPR, piece = tid % PPR;
+    const int64_t col = static_cast<int64_t>(tb) * TB + piece * 16;
+    if (col < pitch) {
+        // physical row rr = row0 + RPI * i holds position 16 (rr % 4) + rr / 4 = 16 (row0 % 4) + row0 / 4 + (RPI / 4) * i
+        int32_t t = t0 + 16 * (row0 & 3) + (row0 >> 2);
+        uint8_t *dst = out + static_cast<int64_t>(t) * pitch + col;  // one 64-bit multiply per thread, then additions
+        const uint8_t *src = s_t + row0 * STRIDE + piece * 16;
+        const int64_t step = pitch * (RPI / 4);
+#pragma unroll
+        for (int r = 0; r < TT; r += RPI) {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * STRIDE), hi = *reinterpret_cast<const uint2 *>(src + r * STRIDE + 8);
+            if (t < static_cast<int32_t>(P)) store16<NT>(dst, uint4{lo.x, lo.y, hi.x, hi.y});
+            dst += step;
+            t += RPI / 4;
+        }
+    }
+}
+
 template <bool NT, int LK>
 void launch_variant(const T8Params &c, dim3 grid, size_t pad, hipStream_t s) {
 #ifdef BSQ_LABS  // ablations: their output is WRONG on purpose; they exist in diagnostic builds only
@@ -545,6 +731,25 @@ static bool fold_table(const int8_t lut[256], uint32_t tab[8], uint32_t none_v) 
     for (int c = 0x40; c < 0x80; ++c)
         if ((lut[c] >= 0) != (lut[c ^ 0x20] >= 0)) return false;
     return true;
+}
+
+// The BOS / EOS / PAD rule table of a launch (see T8Rules): entry e holds n = e - 1 kept bytes.
+static void build_rules(uint32_t fill_v, uint32_t at_len_v, T8Rules &rules) {
+    const uint32_t fill_w = (fill_v & 0xFFu) * 0x01010101u, at_w = (at_len_v & 0xFFu) * 0x01010101u;
+    for (int e = 0; e < 18; ++e) {  // entry e: n = e - 1 bytes kept, byte n (if any) = token at bos + L, the rest fill
+        const int n = e - 1;
+        uint32_t keep[4], cst[4];
+        for (int q = 0; q < 4; ++q) {
+            const int nv = n - 4 * q;
+            const int nvc = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+            const uint32_t kq = nvc == 4 ? 0xFFFFFFFFu : ((1u << (8 * nvc)) - 1u);
+            const uint32_t at = (nv >= 0 && nv < 4) ? (0xFFu << (8 * nv)) : 0u;
+            keep[q] = kq;
+            cst[q] = (fill_w & ~kq & ~at) | (at_w & at);
+        }
+        rules.keep[e] = uint4{keep[0], keep[1], keep[2], keep[3]};
+        rules.cst[e] = uint4{cst[0], cst[1], cst[2], cst[3]};
+    }
 }
 
 bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out) {
@@ -602,23 +807,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
         T8Tab tab;
         for (int i = 0; i < 8; ++i) tab.t[i] = c.tab[i];
         T8Rules rules;
-        {
-            const uint32_t fill_w = (c.fill_v & 0xFFu) * 0x01010101u, at_w = (c.at_len_v & 0xFFu) * 0x01010101u;
-            for (int e = 0; e < 18; ++e) {  // entry e: n = e - 1 bytes kept, byte n (if any) = token at bos + L, the rest fill
-                const int n = e - 1;
-                uint32_t keep[4], cst[4];
-                for (int q = 0; q < 4; ++q) {
-                    const int nv = n - 4 * q;
-                    const int nvc = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
-                    const uint32_t kq = nvc == 4 ? 0xFFFFFFFFu : ((1u << (8 * nvc)) - 1u);
-                    const uint32_t at = (nv >= 0 && nv < 4) ? (0xFFu << (8 * nv)) : 0u;
-                    keep[q] = kq;
-                    cst[q] = (fill_w & ~kq & ~at) | (at_w & at);
-                }
-                rules.keep[e] = uint4{keep[0], keep[1], keep[2], keep[3]};
-                rules.cst[e] = uint4{cst[0], cst[1], cst[2], cst[3]};
-            }
-        }
+        build_rules(c.fill_v, c.at_len_v, rules);
         if (nt)
             hipLaunchKernelGGL((k_tokens_bp8_fast<true>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks),
                                uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules);
@@ -635,6 +824,68 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
 #undef BSQ_T8
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_hip_error("k_tokens_bp8", e);
+    return BSQ_OK;
+}
+
+// (P,B) int8 tokens (pitch = bytes between two position rows; the final matrix: pitch = B) through k_tokens_pb8_fast.
+bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out, int64_t pitch) {
+    if (tuning().tokens_pb8 == 1) return false;
+    return B > 0 && P >= 1 && P <= (int64_t(1) << 30) && B < (int64_t(1) << 31) - 4096 && pitch >= B && pitch % 16 == 0 &&
+           reinterpret_cast<uintptr_t>(out) % 16 == 0 && bsq_alphabet_size(d) <= 250;
+}
+
+bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
+                             int64_t pitch, hipStream_t s, bool raw) {
+    const uint32_t none_v = raw ? 0xFFu : 0u;
+    T8Tab tab;
+    const bool foldable = fold_table(d->lut, tab.t, none_v);
+    // knob "tokens8_lookup": 0 automatic (registers when the table folds), 1 LDS byte table, 2 registers
+    int lk = tuning().tokens8_lookup;
+    if (lk == 0) lk = foldable ? 2 : 1;
+    if (lk == 2 && !foldable) lk = 1;
+    T8Lut lut;
+    for (int w = 0; w < 64; ++w) {
+        uint32_t v = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * w + k;
+            const uint32_t tkn = (c < 128 && d->lut[c] >= 0) ? uint32_t(uint8_t(d->lut[c])) : none_v;
+            v |= tkn << (8 * k);
+        }
+        lut.w[w] = v;
+    }
+    const uint32_t fill = d->padchar ? uint32_t(bsq_pad_id(d)) : none_v;  // no padchar: the memset 0 of tokenize.h:427 stays
+    const uint32_t at_len = d->eos ? uint32_t(bsq_eos_id(d)) : fill;
+    const uint32_t bos_id = uint32_t(bsq_bos_id(d)) & 0xFFu;
+    T8Rules rules;
+    build_rules(fill, at_len, rules);
+    const int64_t room64 = P - d->bos - d->eos;
+    const int32_t room = int32_t(room64 < 0 ? 0 : room64);
+    const uint32_t packed = uint32_t(d->bos != 0) | (raw ? 2u : 0u) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
+    const bool nt = nontemporal_stores() && !raw;  // the raw matrix is re-read by the expansion right away
+    // knob "pb8_tile": 0 automatic (256 sequences x 64 positions), 1: 512 x 64
+    const int tile = tuning().pb8_tile;
+    const int TB = tile == 1 ? 512 : 256, TT = 64;
+    const int64_t ntb = (B + TB - 1) / TB, ntt = (P + TT - 1) / TT;
+    const int64_t blocks = (ntb + 7) / 8 * 8 * ntt;
+    if (blocks >= (int64_t(1) << 31)) return set_error(BSQ_ERR_INVALID_ARG, "output too large");
+    uint32_t magic = 0, shift = 0, pow2 = 0;
+    div_constants(uint32_t(ntt), &magic, &shift, &pow2);
+    if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)
+#define BSQ_PB8(NTV, TBV, LKV)                                                                                                  \
+    hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, TBV, LKV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,          \
+                       static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift, \
+                       room, packed, tab, rules, lut)
+#define BSQ_PB8_T(TBV)                                                         \
+    do {                                                                       \
+        if (lk == 2) { if (nt) BSQ_PB8(true, TBV, 1); else BSQ_PB8(false, TBV, 1); } \
+        else { if (nt) BSQ_PB8(true, TBV, 0); else BSQ_PB8(false, TBV, 0); }         \
+    } while (0)
+    if (tile == 1) BSQ_PB8_T(512);
+    else BSQ_PB8_T(256);
+#undef BSQ_PB8_T
+#undef BSQ_PB8
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_hip_error("k_tokens_pb8_fast", e);
     return BSQ_OK;
 }
 

@@ -1,7 +1,7 @@
 """The (P,B) int8 token matrix -- batch_tokenize's DEFAULT layout (batch_first=False, destchar 'B';
-/root/reference/src/tokenize.cpp:82-98, tokenize.h:454-479) -- from k_tokens_raw in value mode, for both of its
-tile shapes (256 sequences x 64 positions, and the wide 1024 x 16 tile) and as the expansion scratch of the
-two-pass one-hot.  Bit-exact against the oracle."""
+/root/reference/src/tokenize.cpp:82-98, tokenize.h:454-479) -- from k_tokens_pb8_fast (round 3: register-transposed tiles of
+256 x 64 and 512 x 64, register or LDS alphabet table; 16-byte aligned rows) and from k_tokens_raw in value mode (every
+other case; both of its tile shapes), and as the expansion scratch of the two-pass one-hot.  Bit-exact against the oracle."""
 import ctypes
 import itertools
 
@@ -16,13 +16,27 @@ pytestmark = pytest.mark.gpu
 COMBOS = list(itertools.product([0, 1], repeat=3))  # (eos, bos, padchar)
 
 
-@pytest.fixture(params=[0, 1, 4], ids=["auto", "tile256x64", "tile1024x16"])
+# the quad-transposed kernel with each of its tiles, walk lengths and lookups (shapes it does not take fall to
+# k_tokens_raw by themselves), then k_tokens_raw alone with each of ITS tiles
+VARIANTS = {
+    "auto": {},
+    "pb8-512x64": {"pb8_tile": 1},
+    "pb8-ldslut": {"tokens8_lookup": 1},
+    "pb8-512x64-ldslut": {"pb8_tile": 1, "tokens8_lookup": 1},
+    "raw-256x64": {"tokens_pb8": 1, "raw_mode": 1},
+    "raw-1024x16": {"tokens_pb8": 1, "raw_mode": 4},
+}
+
+
+@pytest.fixture(params=list(VARIANTS), ids=list(VARIANTS))
 def raw_mode(request):
     from bioseq_amd import capi
     lib = capi.load()
-    capi.check(lib.bsq_tuning_set(b"raw_mode", request.param))
+    for name, v in VARIANTS[request.param].items():
+        capi.check(lib.bsq_tuning_set(name.encode(), v))
     yield request.param
-    capi.check(lib.bsq_tuning_set(b"raw_mode", 0))
+    for name in ("tokens_pb8", "pb8_tile", "tokens8_lookup", "raw_mode"):
+        capi.check(lib.bsq_tuning_set(name.encode(), 0))
 
 
 def dev_tokens_pb(lib, capi, desc, chars, offs, P, gpu, shift=0, out_shift=0):
@@ -42,7 +56,10 @@ def dev_tokens_pb(lib, capi, desc, chars, offs, P, gpu, shift=0, out_shift=0):
 
 @pytest.mark.parametrize("B,lo,hi,P", [(1, 0, 0, 1), (1, 5, 5, 7), (3, 0, 9, 16), (1000, 1, 254, 256), (1004, 0, 62, 64), (1024, 0, 30, 33),
                                        (1025, 0, 14, 17), (4096, 0, 100, 100), (5000, 3, 60, 64), (9000, 0, 15, 15),
-                                       (2047, 100, 300, 302), (70000, 0, 20, 24)])
+                                       (2047, 100, 300, 302), (70000, 0, 20, 24),
+                                       # 16-byte aligned rows (k_tokens_pb8_fast): one piece, ragged tiles, padlen around 16 / 32 / 64
+                                       (16, 0, 9, 11), (48, 0, 40, 41), (512, 0, 62, 64), (528, 10, 63, 65), (1040, 0, 127, 129),
+                                       (4112, 0, 299, 301), (16400, 0, 30, 31), (272, 700, 1100, 1111)])
 def test_shapes_vs_oracle(gpu, oracle, raw_mode, B, lo, hi, P):
     """Single sequences, ragged tails of the sequence tile (B not a multiple of 16 / 256 / 1024), padlen that is not a
     multiple of the tile's 16 / 64 positions, empty sequences, every byte value; output rows at every alignment the
