@@ -81,6 +81,7 @@ struct KParams {
     uint64_t one_bits;
     uint32_t tab_raw[8], tab_val[8];  // 32-entry folded alphabet (index c & 31): ids with kNone / values with 0 for unmapped
     int32_t foldable;                 // the folded tables represent lut[] exactly (letters only, both cases alike)
+    const bsq_desc *desc;             // HOST only: the descriptor this was filled from (launchers that hand the work to bsq_tokens8.hip)
 };
 
 // order 2 (XCD-aware): the position tiles of ONE sequence tile go to blocks b, b + 8, b + 16, ... -- one XCD under
@@ -1652,6 +1653,7 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
     if (!d || !offsets || !out || B < 0 || P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
     if (P > (int64_t(1) << 30)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "padlen > 2^30 is not supported");
     for (int i = 0; i < 256; ++i) k.lut[i] = d->lut[i];
+    k.desc = d;
     k.chars = chars;
     k.offsets = offsets;
     k.mask = mask;
@@ -2016,6 +2018,10 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
     k.aligned = reinterpret_cast<uintptr_t>(tokens) % 16 == 0 && pitch % 16 == 0;  // every row starts 16-byte aligned
     k.vw = k.aligned ? 16 : 1;
     k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
+    // no mask, 16-byte aligned rows: the register-transposed tiles of k_tokens_pb8_fast in raw-id mode (round 3; knob
+    // tokens_pb8 = 1 or any raw_mode != 0: k_tokens_raw)
+    if (!k.mask && k.desc && bsq_internal::tuning().raw_mode == 0 && bsq_internal::tokens_pb8_applicable(k.desc, k.B, k.P, tokens, pitch))
+        return bsq_internal::launch_tokens_pb8(k.desc, k.chars, k.offsets, k.B, k.P, tokens, pitch, s, true);
     const dim3 grid(unsigned(tile_grid(k, k.ntt)));
     // knob "raw_mode": 0 / 1 k_tokens_raw; 2 k_tokens_raw2 (register transpose) with the LDS byte table, 3 with the
     // register table.  k_tokens_raw2 is an experiment that LOST (profiles/r02/raw_lab.txt: cfg2 as (P,B) int8 tokens
