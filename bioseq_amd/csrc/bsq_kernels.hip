@@ -2384,9 +2384,9 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
     }
     k.aligned = (addr % 16 == 0) && ((B * int64_t(sz)) % 16 == 0);
     k.vw = (!k.aligned && addr % sz == 0 && bsq_internal::tuning().tokenize_path != 2) ? 2 : 1;  // k_tokenize_tile: 2 = line-aligned slots
-    // int8 (P,B), foldable alphabet, 16-byte aligned rows: quad-transposed 512 x 64 tiles (bsq_tokens8.hip; knob tokens_pb8 = 1: never)
-    if (t == BSQ_I8 && bsq_internal::tuning().tokenize_path != 1 && bsq_internal::tokens_pb8_applicable(d, B, P, out, B))
-        return bsq_internal::launch_tokens_pb8(d, chars, offsets, B, P, out, B, s);
+    // (P,B) with 16-byte aligned rows, any element type: register-transposed 256 x 64 tiles (bsq_tokens8.hip; knob tokens_pb8 = 1: never)
+    if (bsq_internal::tuning().tokenize_path != 1 && bsq_internal::tokens_pb8_applicable(d, B, P, out, B, t))
+        return bsq_internal::launch_tokens_pb8(d, chars, offsets, B, P, out, B, s, false, t);
     if (t == BSQ_I8 && bsq_internal::tuning().tokenize_path != 1) {  // int8 (P,B): the raw-token kernel in value mode
         const uint64_t al = uint64_t(addr) | uint64_t(B);  // every row starts at out + t * B
         k.vw = al % 16 == 0 ? 16 : (al % 8 == 0 ? 8 : (al % 4 == 0 ? 4 : 1));

@@ -528,21 +528,52 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
 // cfg2's shape, bound by instruction issue in BOTH pipes (profiles/r02/cfg2sf_sq_tcc_counters.txt).  Here, on a tile of
 // TB sequences x 64 positions:
 //   * lane (R, a, b) of a wave -- 16-lane row R, a = lane / 4 % 4, b = lane % 4 -- fetches the unaligned 16-byte piece b
-//     of sequence 4 (4 wave + R) + a of the pass: four adjacent lanes read 64 contiguous characters (a first form with
+//     (3 - b in odd a) of sequence 4 (4 wave + R) + a of the pass: four adjacent lanes read 64 contiguous characters (a first form with
 //     one sequence per lane was bound by its 64-line load instructions: profiles/r03/pb8_lane_per_sequence_walk_lab.txt);
 //     the pieces of all TB / 64 passes are in flight together;
 //   * lookups out of the register table (LK = 1; foldable alphabets) or the LDS byte table (LK = 0), BOS / EOS / PAD
 //     from the host-built rule table, exactly as k_tokens_bp8_fast;
 //   * the byte transpose happens IN REGISTERS between the four lanes b, b + 4, b + 8, b + 12 of a row (the same piece of
-//     four consecutive sequences): v_mov_dpp row_ror:12 / row_ror:4 (bank masks) + v_perm_b32, then row_ror:8 + v_perm_b32
-//     leave lane (R, a, b) with position 16 b + 4 k + a of the row's four sequences -- ONE ds_write_b32 per word;
+//     four consecutive sequences): v_mov_dpp row_half_mirror + v_perm_b32, then row_ror:8 + v_perm_b32 leave lane (R, a, b)
+//     with position 16 piece + 4 k + a of the row's four sequences -- ONE ds_write_b32 per word;
 //   * LDS tile: position p lives in physical row 4 (p % 16) + p / 16, row stride TB + 8 bytes (2 banks): the 32 writes of a
 //     half-wave fall on 32 banks; the rows leave as 8-byte LDS reads -> 16-byte stores of TB-byte segments.
 // XCD-aware order: block b -> class b % 8 walks its own sequence tiles, the position tiles of a sequence tile back to back.
 struct T8Lut {
     uint32_t w[64];  // LK = 0: token VALUE of every byte (unmapped: none_v)
 };
-template <bool NT, int TB, int LK>
+// SZ / FLT: the element type of the matrix -- 1, 2, 4, 8-byte integers (ids zero-extended: < 251) or, FLT, float / double.
+// The tile is built in bytes whatever the type; only the last phase differs: a thread turns 16 / SZ token bytes of a tile row into
+// one 16-byte store, so a tile row leaves as TB * SZ contiguous bytes.
+template <int SZ, bool FLT>
+__device__ __forceinline__ uint4 widen_tokens(const uint8_t *src) {
+    if constexpr (SZ == 1) {
+        const uint2 lo = *reinterpret_cast<const uint2 *>(src), hi = *reinterpret_cast<const uint2 *>(src + 8);
+        return uint4{lo.x, lo.y, hi.x, hi.y};
+    } else if constexpr (SZ == 2) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(src);  // 8 tokens; 0x0c in a selector byte = constant 0
+        return uint4{__builtin_amdgcn_perm(0u, w.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, w.x, 0x0c030c02u),
+                     __builtin_amdgcn_perm(0u, w.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, w.y, 0x0c030c02u)};
+    } else if constexpr (SZ == 4) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(src);  // 4 tokens
+        if constexpr (FLT)
+            return uint4{__float_as_uint(static_cast<float>(w & 0xFFu)), __float_as_uint(static_cast<float>((w >> 8) & 0xFFu)),
+                         __float_as_uint(static_cast<float>((w >> 16) & 0xFFu)), __float_as_uint(static_cast<float>(w >> 24))};
+        else
+            return uint4{w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu, w >> 24};
+    } else {
+        const uint32_t w = *reinterpret_cast<const uint16_t *>(src);  // 2 tokens
+        if constexpr (FLT) {
+            const uint64_t a = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(w & 0xFFu)));
+            const uint64_t b = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(w >> 8)));
+            return uint4{static_cast<uint32_t>(a), static_cast<uint32_t>(a >> 32), static_cast<uint32_t>(b), static_cast<uint32_t>(b >> 32)};
+        } else {
+            return uint4{w & 0xFFu, 0u, w >> 8, 0u};
+        }
+    }
+}
+
+template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false>
 __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                               uint8_t *__restrict__ out, int64_t pitch, uint32_t B, uint32_t P,
                                                               uint32_t ntb, uint32_t ntt, uint32_t magic, uint32_t shift, int32_t room,
@@ -589,7 +620,8 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     __syncthreads();
 
     // ---- the characters: the piece of every pass in flight together ----
-    const int32_t j0 = t0 + 16 * lb - static_cast<int32_t>(bos);  // character index of the piece's first byte (>= -1)
+    const int pc = (la & 1) ? 3 - lb : lb;  // the lane's piece: reversed in odd a, so that row_half_mirror pairs a with a ^ 1 on the SAME piece
+    const int32_t j0 = t0 + 16 * pc - static_cast<int32_t>(bos);  // character index of the piece's first byte (>= -1)
     u32x4u cw[PASSES];
     int32_t Lr[PASSES];
     bool slow_any = false;
@@ -621,8 +653,8 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     // ---- lookups, rules, transposes between the lanes a = 0..3 of a piece, one ds_write_b32 per word ----
     const uint32_t sel1 = (la & 1) ? 0x03070105u : 0x06020400u;  // even a: (w0, p0, w2, p2); odd a: (p1, w1, p3, w3)
     const uint32_t sel2 = (la & 2) ? 0x03020706u : 0x05040100u;  // a = 0, 1: (x.lo, y.lo); a = 2, 3: (y.hi, x.hi)
-    // word k of the lane goes to physical row 4 (4 k + a) + b, dword column 16 pass + 4 wave + R
-    uint8_t *wbase = s_t + (4 * la + lb) * STRIDE + wave * 16 + (lane >> 4) * 4;
+    // word k of the lane goes to physical row 4 (4 k + a) + piece, dword column 16 pass + 4 wave + R
+    uint8_t *wbase = s_t + (4 * la + pc) * STRIDE + wave * 16 + (lane >> 4) * 4;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         const int32_t dd = Lr[ps] - j0;
@@ -657,36 +689,28 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
         if (j0 < 0) w[0] = (w[0] & ~0xFFu) | bos_id;  // position 0 with BOS
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            // the word of lane a ^ 1 (4 lanes away): row_ror:12 brings lane + 4 (even a: banks 0, 2), row_ror:4 lane - 4 (odd a)
-            int p1 = __builtin_amdgcn_update_dpp(0, static_cast<int>(w[q]), 0x12C, 0xF, 0x5, false);
-            p1 = __builtin_amdgcn_update_dpp(p1, static_cast<int>(w[q]), 0x124, 0xF, 0xA, false);
+            // the word of lane a ^ 1 on the same piece: row_half_mirror (lane i <-> 7 - i of each half row)
+            const int p1 = __builtin_amdgcn_update_dpp(0, static_cast<int>(w[q]), 0x141, 0xF, 0xF, false);
             const uint32_t x = __builtin_amdgcn_perm(static_cast<uint32_t>(p1), w[q], sel1);
             const uint32_t y = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x128, 0xF, 0xF, false));  // lane a ^ 2
-            const uint32_t tr = __builtin_amdgcn_perm(y, x, sel2);  // position 16 b + 4 q + a of the row's four sequences
+            const uint32_t tr = __builtin_amdgcn_perm(y, x, sel2);  // position 16 piece + 4 q + a of the row's four sequences
             *reinterpret_cast<uint32_t *>(wbase + 16 * q * STRIDE + ps * 64) = tr;
         }
     }
     __syncthreads();
 
-    // ---- the tile's position rows: TB contiguous bytes of the output each ----
-    constexpr int PPR = TB / 16;       // 16-byte pieces per tile row
-    constexpr int RPI = kThreads / PPR;  // physical tile rows per step of the workgroup
-    static_assert(kThreads % PPR == 0 && RPI % 4 == 0 && TT % RPI == 0, "row walk");
-    const int row0 = tid / PPR, piece = tid % PPR;
-    const int64_t col = static_cast<int64_t>(tb) * TB + piece * 16;
-    if (col < pitch) {
-        // physical row rr = row0 + RPI * i holds position 16 (rr % 4) + rr / 4 = 16 (row0 % 4) + row0 / 4 + (RPI / 4) * i
-        int32_t t = t0 + 16 * (row0 & 3) + (row0 >> 2);
-        uint8_t *dst = out + static_cast<int64_t>(t) * pitch + col;  // one 64-bit multiply per thread, then additions
-        const uint8_t *src = s_t + row0 * STRIDE + piece * 16;
-        const int64_t step = pitch * (RPI / 4);
+    // ---- the tile's position rows: TB * SZ contiguous bytes of the output each (pitch in ELEMENTS) ----
+    constexpr int N = 16 / SZ;     // tokens per 16-byte store
+    constexpr int PPR = TB / N;    // stores per tile row
+    static_assert((TT * PPR) % kThreads == 0 && (PPR & (PPR - 1)) == 0, "row walk");
 #pragma unroll
-        for (int r = 0; r < TT; r += RPI) {
-            const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * STRIDE), hi = *reinterpret_cast<const uint2 *>(src + r * STRIDE + 8);
-            if (t < static_cast<int32_t>(P)) store16<NT>(dst, uint4{lo.x, lo.y, hi.x, hi.y});
-            dst += step;
-            t += RPI / 4;
-        }
+    for (int f0 = 0; f0 < TT * PPR; f0 += kThreads) {
+        const int f = f0 + tid;
+        const int rr = f / PPR, piece = f % PPR;           // physical row rr holds position 16 (rr % 4) + rr / 4
+        const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
+        const int64_t col = static_cast<int64_t>(tb) * TB + piece * N;
+        if (t < static_cast<int32_t>(P) && col < pitch)
+            store16<NT>(out + (static_cast<int64_t>(t) * pitch + col) * SZ, widen_tokens<SZ, FLT>(s_t + rr * STRIDE + piece * N));
     }
 }
 
@@ -827,16 +851,23 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
     return BSQ_OK;
 }
 
-// (P,B) int8 tokens (pitch = bytes between two position rows; the final matrix: pitch = B) through k_tokens_pb8_fast.
-bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out, int64_t pitch) {
+// (P,B) tokens of any element type (pitch = ELEMENTS between two position rows; the final matrix: pitch = B) through
+// k_tokens_pb8_fast: rows and output 16-byte aligned.
+bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out, int64_t pitch, bsq_dtype t) {
     if (tuning().tokens_pb8 == 1) return false;
-    return B > 0 && P >= 1 && P <= (int64_t(1) << 30) && B < (int64_t(1) << 31) - 4096 && pitch >= B && pitch % 16 == 0 &&
-           reinterpret_cast<uintptr_t>(out) % 16 == 0 && bsq_alphabet_size(d) <= 250;
+    const int64_t sz = int64_t(bsq_dtype_size(t));
+    if (sz == 0) return false;
+    // 4- and 8-byte elements: measured SLOWER than k_tokenize_tile (cfg2: int32 53 vs 48 us, 8-byte 111 vs 103;
+    // profiles/r03/pb8_wider_types.txt) -- taken only under knob tokens_pb8 = 2 (tests, measurement)
+    if (sz > 2 && tuning().tokens_pb8 != 2) return false;
+    return B > 0 && P >= 1 && P <= (int64_t(1) << 30) && B < (int64_t(1) << 31) - 4096 && pitch >= B && pitch < (int64_t(1) << 31) &&
+           (pitch * sz) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && bsq_alphabet_size(d) <= 250;
 }
 
 bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
-                             int64_t pitch, hipStream_t s, bool raw) {
+                             int64_t pitch, hipStream_t s, bool raw, bsq_dtype t) {
     const uint32_t none_v = raw ? 0xFFu : 0u;
+    if (raw && t != BSQ_I8) return set_error(BSQ_ERR_INVALID_ARG, "raw ids are bytes");
     T8Tab tab;
     const bool foldable = fold_table(d->lut, tab.t, none_v);
     // knob "tokens8_lookup": 0 automatic (registers when the table folds), 1 LDS byte table, 2 registers
@@ -862,26 +893,33 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     const int32_t room = int32_t(room64 < 0 ? 0 : room64);
     const uint32_t packed = uint32_t(d->bos != 0) | (raw ? 2u : 0u) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
     const bool nt = nontemporal_stores() && !raw;  // the raw matrix is re-read by the expansion right away
-    // knob "pb8_tile": 0 automatic (256 sequences x 64 positions), 1: 512 x 64
-    const int tile = tuning().pb8_tile;
-    const int TB = tile == 1 ? 512 : 256, TT = 64;
+    // one tile shape: 256 sequences x 64 positions (512 x 64 and 512 x 32 were built and measured slower:
+    // profiles/r03/pb8_coalesced_ab.txt, pb8_512x32_tile_lost.txt)
+    const int TB = 256, TT = 64;
     const int64_t ntb = (B + TB - 1) / TB, ntt = (P + TT - 1) / TT;
     const int64_t blocks = (ntb + 7) / 8 * 8 * ntt;
     if (blocks >= (int64_t(1) << 31)) return set_error(BSQ_ERR_INVALID_ARG, "output too large");
     uint32_t magic = 0, shift = 0, pow2 = 0;
     div_constants(uint32_t(ntt), &magic, &shift, &pow2);
     if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)
-#define BSQ_PB8(NTV, TBV, LKV)                                                                                                  \
-    hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, TBV, LKV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,          \
-                       static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift, \
+#define BSQ_PB8(NTV, LKV, SZV, FLTV)                                                                                              \
+    hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, 256, LKV, SZV, FLTV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,  \
+                       static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift,    \
                        room, packed, tab, rules, lut)
-#define BSQ_PB8_T(TBV)                                                         \
-    do {                                                                       \
-        if (lk == 2) { if (nt) BSQ_PB8(true, TBV, 1); else BSQ_PB8(false, TBV, 1); } \
-        else { if (nt) BSQ_PB8(true, TBV, 0); else BSQ_PB8(false, TBV, 0); }         \
+#define BSQ_PB8_T(SZV, FLTV)                                                                   \
+    do {                                                                                       \
+        if (lk == 2) { if (nt) BSQ_PB8(true, 1, SZV, FLTV); else BSQ_PB8(false, 1, SZV, FLTV); } \
+        else { if (nt) BSQ_PB8(true, 0, SZV, FLTV); else BSQ_PB8(false, 0, SZV, FLTV); }         \
     } while (0)
-    if (tile == 1) BSQ_PB8_T(512);
-    else BSQ_PB8_T(256);
+    switch (t) {
+    case BSQ_I8: BSQ_PB8_T(1, false); break;
+    case BSQ_I16: BSQ_PB8_T(2, false); break;
+    case BSQ_I32: BSQ_PB8_T(4, false); break;
+    case BSQ_F32: BSQ_PB8_T(4, true); break;
+    case BSQ_U64: BSQ_PB8_T(8, false); break;
+    case BSQ_F64: BSQ_PB8_T(8, true); break;
+    default: return set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    }
 #undef BSQ_PB8_T
 #undef BSQ_PB8
     const hipError_t e = hipGetLastError();

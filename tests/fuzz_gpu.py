@@ -44,8 +44,7 @@ def run(budget=120.0, seed=1):
         capi.check(lib.bsq_tuning_set(b"tokens8", knobs[3]))
         capi.check(lib.bsq_tuning_set(b"tokens8_fast", int(rng.integers(0, 2))))
         capi.check(lib.bsq_tuning_set(b"raw_mode", int(rng.choice([0, 1, 4]))))
-        capi.check(lib.bsq_tuning_set(b"tokens_pb8", int(rng.choice([0, 0, 1]))))
-        capi.check(lib.bsq_tuning_set(b"pb8_tile", int(rng.integers(0, 2))))
+        capi.check(lib.bsq_tuning_set(b"tokens_pb8", int(rng.choice([0, 0, 1, 2]))))
         capi.check(lib.bsq_tuning_set(b"bcl_path", int(rng.integers(0, 4))))
         tok, ora = bsq.Tokenizer(key, eos, bos, pad), O.OracleTokenizer(key, eos, bos, pad)
         shift = int(rng.integers(0, 4))  # misaligned device views of the inputs
@@ -74,7 +73,7 @@ def run(budget=120.0, seed=1):
         except AssertionError as ex:
             raise AssertionError("MISMATCH %s %r" % (ex, desc))
         n += 1
-    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"pb8_tile", b"bcl_path", b"tokenize_tb"):
+    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"bcl_path", b"tokenize_tb"):
         capi.check(lib.bsq_tuning_set(name, 0))
     return n
 

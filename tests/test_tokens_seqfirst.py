@@ -1,6 +1,6 @@
 """The (P,B) int8 token matrix -- batch_tokenize's DEFAULT layout (batch_first=False, destchar 'B';
 /root/reference/src/tokenize.cpp:82-98, tokenize.h:454-479) -- from k_tokens_pb8_fast (round 3: register-transposed tiles of
-256 x 64 and 512 x 64, register or LDS alphabet table; 16-byte aligned rows) and from k_tokens_raw in value mode (every
+256 x 64, register or LDS alphabet table; 16-byte aligned rows) and from k_tokens_raw in value mode (every
 other case; both of its tile shapes), and as the expansion scratch of the two-pass one-hot.  Bit-exact against the oracle."""
 import ctypes
 import itertools
@@ -20,9 +20,7 @@ COMBOS = list(itertools.product([0, 1], repeat=3))  # (eos, bos, padchar)
 # k_tokens_raw by themselves), then k_tokens_raw alone with each of ITS tiles
 VARIANTS = {
     "auto": {},
-    "pb8-512x64": {"pb8_tile": 1},
     "pb8-ldslut": {"tokens8_lookup": 1},
-    "pb8-512x64-ldslut": {"pb8_tile": 1, "tokens8_lookup": 1},
     "raw-256x64": {"tokens_pb8": 1, "raw_mode": 1},
     "raw-1024x16": {"tokens_pb8": 1, "raw_mode": 4},
 }
@@ -35,7 +33,7 @@ def raw_mode(request):
     for name, v in VARIANTS[request.param].items():
         capi.check(lib.bsq_tuning_set(name.encode(), v))
     yield request.param
-    for name in ("tokens_pb8", "pb8_tile", "tokens8_lookup", "raw_mode"):
+    for name in ("tokens_pb8", "tokens8_lookup", "raw_mode"):
         capi.check(lib.bsq_tuning_set(name.encode(), 0))
 
 
@@ -145,3 +143,38 @@ def test_wider_types_any_batch_size_any_alignment(gpu, oracle, dc, B, P):
     finally:
         capi.check(lib.bsq_tuning_set(b"tokenize_path", 0))
         capi.check(lib.bsq_tuning_set(b"tokenize_tb", 0))
+
+
+@pytest.mark.parametrize("dc", list("hilfd"))
+@pytest.mark.parametrize("B,P", [(8, 5), (16, 64), (264, 100), (1000, 33), (4104, 70), (20000, 24), (4096, 129), (520, 1100)])
+def test_wider_types_aligned_rows_through_pb8(gpu, oracle, dc, B, P):
+    """(P,B) token matrices of 2- / 4- / 8-byte elements whose rows are 16-byte aligned: k_tokens_pb8_fast builds the tile in
+    bytes and widens on the way out (register and LDS alphabet table; knob tokens_pb8 = 2 takes it for the 4- / 8-byte types
+    too, where it is slower than k_tokenize_tile), against k_tokenize_tile (knob 1), the automatic choice and the oracle; nothing outside the matrix is written."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    chars, offs = nasty_batch(B * 3 + P, B, 0, P - 2)
+    dch = torch.from_numpy(np.concatenate([chars, np.zeros(1, np.uint8)])).to(gpu)
+    dof = torch.from_numpy(offs).to(gpu)
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(dc.encode(), ctypes.byref(dt)))
+    sz = lib.bsq_dtype_size(dt)
+    try:
+        for key, flags in (("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1)), ("SEB8", (1, 0, 0))):
+            want = oracle.OracleTokenizer(key, *flags).tokenize_packed(chars, offs, P, dc, False)
+            desc = capi.make_desc(key, *flags)
+            for pb8, lookup in ((2, 0), (2, 1), (0, 0), (1, 0)):
+                capi.check(lib.bsq_tuning_set(b"tokens_pb8", pb8))
+                capi.check(lib.bsq_tuning_set(b"tokens8_lookup", lookup))
+                buf = torch.full(((P * B + 32) * sz,), 0x5A, dtype=torch.uint8, device=gpu)
+                lo = 16
+                capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 0, dt,
+                                                   buf.data_ptr() + lo, None))
+                torch.cuda.synchronize()
+                host = buf.cpu().numpy()
+                assert (host[:lo] == 0x5A).all() and (host[lo + P * B * sz:] == 0x5A).all(), "wrote outside the matrix"
+                assert host[lo:lo + P * B * sz].tobytes() == want.tobytes(), (key, flags, dc, pb8, lookup)
+    finally:
+        capi.check(lib.bsq_tuning_set(b"tokens_pb8", 0))
+        capi.check(lib.bsq_tuning_set(b"tokens8_lookup", 0))
