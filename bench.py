@@ -496,7 +496,8 @@ def main():
                 traffic = None
         kernel_name = (lib.bsq_onehot_kernel_name(ctypes.byref(desc), n, P, dt_code).decode() if op == "onehot"
                        else (("k_tokens_bp8" if sz == 1 and P >= 128 and P % 16 == 0 else "k_tokenize_chunks")
-                             if batch_first else ("k_tokens_raw<value>" if sz == 1 else "k_tokenize_tile")))
+                             if batch_first else ("k_tokens_pb8_fast" if sz <= 2 and (n * sz) % 16 == 0 and os.environ.get("BSQ_TOKENS_PB8", "0") != "1"
+                                                 else ("k_tokens_raw<value>" if sz == 1 else "k_tokenize_tile"))))
         if op == "augment+tokenize":
             kernel_name = "k_augment_groups+" + kernel_name
         if op == "onehot_bcl":

@@ -2237,6 +2237,8 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
         if (rb >= 4 && (mode == 2 || mode == 9)) return "k_tokens_raw+k_expand_small";
 #endif
         (void)rb;
+        // (unmasked: the raw-id pass runs in k_tokens_pb8_fast unless a knob keeps it in k_tokens_raw -- see launch_tokens_raw)
+        if (bsq_internal::tuning().raw_mode == 0 && bsq_internal::tuning().tokens_pb8 != 1) return "k_tokens_pb8_fast<raw>+k_expand_chunks";
         return "k_tokens_raw+k_expand_chunks";
     }
     case 3: return "k_onehot_chunks";
