@@ -71,6 +71,9 @@ struct AugTable {
     double self[kRows];        // normrows[r][r]: probability that a draw from row r repeats the residue (row X: 0)
     uint8_t row_of[256];       // byte -> row (20 = 'X' row for everything unknown)
     uint8_t letter[kCols];
+    uint32_t accept_le[kRows];  // a position whose residue is of row r is accepted iff lo32 <= accept_le[r]: the integer form of
+                                // `double(lo32) * 2^-32 < 1.0 - self[r]` (both sides exact doubles: the same truth value for every lo32)
+    uint32_t pad_[4];
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -86,6 +89,11 @@ __device__ __forceinline__ uint64_t rnd(uint64_t seed, uint64_t seq, uint64_t i)
 }
 #endif
 __device__ __forceinline__ double unit(uint64_t x) { return static_cast<double>(x >> 11) * 0x1.0p-53; }
+// floor(r * len / 2^64) for len < 2^32: two 32 x 32 multiplies instead of the four of __umul64hi (quarter-rate instructions)
+__device__ __forceinline__ uint64_t mulhi_64x32(uint64_t r, uint32_t len) {
+    const uint64_t lo = static_cast<uint64_t>(static_cast<uint32_t>(r)) * len;
+    return (static_cast<uint64_t>(static_cast<uint32_t>(r >> 32)) * len + (lo >> 32)) >> 32;
+}
 
 constexpr int kMaxAttempts = 1 << 14;  // the reference's `while inchar == outchar` is unbounded (an all-W sequence accepts with p = 0.006 per try)
 
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const in
         // attempts of a sequence instead of A.  K = 1 is the round-2 kernel; results do not depend on K (the first accepted
         // attempt in counter order wins either way).  The kernel is latency-bound (59 % of its wave cycles are waits,
         // profiles/r03/augment_groups_pmc.txt): K = 4 takes the typical wave from 3-4 dependent rounds to 2, 21.8 -> 17.3-18.2 us.
+        const bool long_len = __builtin_amdgcn_ballot_w64((static_cast<uint64_t>(L) >> 32) != 0) != 0;  // wave-uniform, never in practice
         uint64_t r[K];
         int64_t idx[K];
         uint8_t ch[K];
@@ -239,15 +248,19 @@ __global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const in
         for (int k = 0; k < K; ++k) {
             const uint32_t j = static_cast<uint32_t>(k * A + a);
             r[k] = mix64(h0 + 0xD1342543DE82EF95ull * (static_cast<uint64_t>(ctr0 + j) + 1));
-            idx[k] = static_cast<int64_t>(__umul64hi(r[k], static_cast<uint64_t>(L)));  // uniform in [0, L)
+            idx[k] = static_cast<int64_t>(mulhi_64x32(r[k], static_cast<uint32_t>(L)));  // uniform in [0, L)
             valid[k] = have && tries + static_cast<int32_t>(j) < kMaxAttempts;         // (attempts beyond the cap of this mutation are not made)
+        }
+        if (long_len) {  // a sequence of 2^32 characters or more in the wave: the full 64 x 64 multiply
+#pragma unroll
+            for (int k = 0; k < K; ++k) idx[k] = static_cast<int64_t>(__umul64hi(r[k], static_cast<uint64_t>(L)));
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) ch[k] = valid[k] ? chars[start + idx[k]] : uint8_t(0);
         int win_k = -1, win_a = 0;  // group-uniform: the first accepted attempt in counter order
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const bool accepted = valid[k] && static_cast<double>(static_cast<uint32_t>(r[k])) * 0x1.0p-32 < 1.0 - s_tab.self[s_tab.row_of[ch[k]]];
+            const bool accepted = valid[k] && static_cast<uint32_t>(r[k]) <= s_tab.accept_le[s_tab.row_of[ch[k]]];  // = double(lo32) * 2^-32 < 1 - p_self
             const uint64_t acc = __builtin_amdgcn_ballot_w64(accepted);
             const uint64_t mine = (acc >> (g << shiftA)) & (A == 64 ? ~uint64_t(0) : ((uint64_t(1) << A) - 1));  // this group's attempts
             if (win_k < 0 && mine != 0) {
@@ -268,12 +281,13 @@ __global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const in
                     const double pself = s_tab.self[row];
                     const double *cdf = s_tab.cdf[row];
                     const double u = unit(mix64(h0 + 0xD1342543DE82EF95ull * (static_cast<uint64_t>(c) + 2))) * (cdf[kCols - 1] - pself);
-                    int pick = -1;
-                    for (int q = 0; q < kCols; ++q) {
-                        if (q == row) continue;
-                        pick = q;
-                        if (u < cdf[q] - (q > row ? pself : 0.0)) break;
-                    }
+                    // first q != row with u < cdf[q] - (q > row ? pself : 0), else the last q != row: all twenty comparisons at once
+                    // (the early-exit loop paid one LDS round trip per step)
+                    uint32_t below = 0;
+#pragma unroll
+                    for (int q = 0; q < kCols; ++q) below |= static_cast<uint32_t>(q != row && u < cdf[q] - (q > row ? pself : 0.0)) << q;
+                    const int last = row == kCols - 1 ? kCols - 2 : kCols - 1;
+                    const int pick = below ? __builtin_ctz(below) : last;
                     chars[start + iw] = s_tab.letter[pick];
                     s_ctr[wave][sidx] = c + 2;
                     s_rem[wave][sidx] -= 1;
@@ -313,7 +327,12 @@ bsq_status device_table(AugTable **out) {
                 h.cdf[r][c] = acc;
             }
             h.self[r] = r < kCols ? nr[r * kCols + r] : 0.0;
+            // lo * 2^-32 < t  <=>  lo < t * 2^32 (exact: scaling by a power of two)  <=>  lo <= ceil(t * 2^32) - 1
+            const double t32 = std::ldexp(1.0 - h.self[r], 32);
+            const double c = std::ceil(t32);
+            h.accept_le[r] = c >= 4294967296.0 ? 0xFFFFFFFFu : static_cast<uint32_t>(static_cast<uint64_t>(c) - 1);  // (t > 0 always)
         }
+        h.pad_[0] = h.pad_[1] = h.pad_[2] = h.pad_[3] = 0;
         std::memset(h.row_of, kRows - 1, sizeof(h.row_of));
         for (int c = 0; c < kCols; ++c) {
             h.row_of[static_cast<unsigned char>(kLetters[c])] = static_cast<uint8_t>(c);
