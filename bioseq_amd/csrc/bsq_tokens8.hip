@@ -573,7 +573,10 @@ __device__ __forceinline__ uint4 widen_tokens(const uint8_t *src) {
     }
 }
 
-template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false>
+// UA: rows (pitch * SZ bytes) or the output are only element-aligned -- any batch size.  The 16-byte stores go out unaligned
+// (gfx950 splits them in hardware), the pieces that cross the end of a row as single elements, and every XCD walks its own
+// CONTIGUOUS range of sequence tiles: the memory sectors that two neighbouring tiles share are then written through ONE L2.
+template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false, bool UA = false>
 __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                               uint8_t *__restrict__ out, int64_t pitch, uint32_t B, uint32_t P,
                                                               uint32_t ntb, uint32_t ntt, uint32_t magic, uint32_t shift, int32_t room,
@@ -586,7 +589,13 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t cls = blockIdx.x & 7u, i = blockIdx.x >> 3;
     const uint32_t tbl = (magic ? __umulhi(i, magic) : i) >> shift;  // i / ntt (magic 0: ntt is a power of two)
-    const uint32_t tt = i - tbl * ntt, tb = tbl * 8u + cls;
+    const uint32_t tt = i - tbl * ntt;
+    uint32_t tb = tbl * 8u + cls;
+    if constexpr (UA) {
+        const uint32_t per = (ntb + 7u) / 8u;  // sequence tiles per XCD
+        if (tbl >= per) return;
+        tb = cls * per + tbl;
+    }
     if (tb >= ntb) return;
     const uint32_t bos = packed & 1u, none_v = (packed & 2u) ? 0xFFu : 0u;
     const uint32_t bos_id = (packed >> 8) & 0xFFu;
@@ -709,8 +718,21 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
         const int rr = f / PPR, piece = f % PPR;           // physical row rr holds position 16 (rr % 4) + rr / 4
         const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
         const int64_t col = static_cast<int64_t>(tb) * TB + piece * N;
-        if (t < static_cast<int32_t>(P) && col < pitch)
-            store16<NT>(out + (static_cast<int64_t>(t) * pitch + col) * SZ, widen_tokens<SZ, FLT>(s_t + rr * STRIDE + piece * N));
+        if (t < static_cast<int32_t>(P) && col < pitch) {
+            uint8_t *dst = out + (static_cast<int64_t>(t) * pitch + col) * SZ;
+            const uint8_t *src = s_t + rr * STRIDE + piece * N;
+            if constexpr (!UA) {
+                store16<NT>(dst, widen_tokens<SZ, FLT>(src));
+            } else if (col + N <= pitch) {
+                store16_unaligned<NT>(dst, widen_tokens<SZ, FLT>(src));
+            } else {  // the piece that crosses the end of the row (one per row, in the last tile): element stores
+                static_assert(!UA || (SZ <= 2 && !FLT), "unaligned rows: 1- and 2-byte integers");
+                for (int k = 0; k < static_cast<int>(pitch - col); ++k) {
+                    if constexpr (SZ == 1) dst[k] = src[k];
+                    else reinterpret_cast<uint16_t *>(dst)[k] = src[k];
+                }
+            }
+        }
     }
 }
 
@@ -860,8 +882,19 @@ bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
     // 4- and 8-byte elements: measured SLOWER than k_tokenize_tile (cfg2: int32 53 vs 48 us, 8-byte 111 vs 103;
     // profiles/r03/pb8_wider_types.txt) -- taken only under knob tokens_pb8 = 2 (tests, measurement)
     if (sz > 2 && tuning().tokens_pb8 != 2) return false;
+    // rows / outputs that are only element-aligned: the UA form.  Taken for int8 rows that are not even 8-byte aligned, where it
+    // beats k_tokens_raw's 4-byte / byte stores (65 537 x 1024: 30.7 vs 43.0 us, 250 001 x 256: 31.2 vs 40.6); with 8-byte aligned
+    // rows k_tokens_raw is as fast (65 000 x 1024: 30.8 vs 31.8), and for int16 k_tokenize_tile is faster (42 vs 51 us):
+    // profiles/r03/pb8_unaligned_rows.txt.  Knob tokens_pb8 = 3: aligned shapes only; 4: the UA form wherever it applies.
+    const bool aligned = (pitch * sz) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+    if (!aligned) {
+        const int knob = tuning().tokens_pb8;
+        if (sz > 2 || knob == 3 || reinterpret_cast<uintptr_t>(out) % uintptr_t(sz) != 0) return false;
+        const bool wins = sz == 1 && (pitch % 8 != 0 || reinterpret_cast<uintptr_t>(out) % 8 != 0);
+        if (!wins && knob != 4) return false;
+    }
     return B > 0 && P >= 1 && P <= (int64_t(1) << 30) && B < (int64_t(1) << 31) - 4096 && pitch >= B && pitch < (int64_t(1) << 31) &&
-           (pitch * sz) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && bsq_alphabet_size(d) <= 250;
+           bsq_alphabet_size(d) <= 250;
 }
 
 bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
@@ -902,10 +935,20 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     uint32_t magic = 0, shift = 0, pow2 = 0;
     div_constants(uint32_t(ntt), &magic, &shift, &pow2);
     if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)
-#define BSQ_PB8(NTV, LKV, SZV, FLTV)                                                                                              \
-    hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, 256, LKV, SZV, FLTV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,  \
+    const bool ua = !((pitch * int64_t(bsq_dtype_size(t))) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0);
+#define BSQ_PB8U(NTV, LKV, SZV, FLTV, UAV)                                                                                             \
+    hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, 256, LKV, SZV, FLTV, UAV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,  \
                        static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift,    \
                        room, packed, tab, rules, lut)
+#define BSQ_PB8(NTV, LKV, SZV, FLTV)                                       \
+    do {                                                                   \
+        if constexpr (SZV <= 2 && !FLTV) {                                 \
+            if (ua) BSQ_PB8U(NTV, LKV, SZV, FLTV, true);                   \
+            else BSQ_PB8U(NTV, LKV, SZV, FLTV, false);                     \
+        } else {                                                           \
+            BSQ_PB8U(NTV, LKV, SZV, FLTV, false);                          \
+        }                                                                  \
+    } while (0)
 #define BSQ_PB8_T(SZV, FLTV)                                                                   \
     do {                                                                                       \
         if (lk == 2) { if (nt) BSQ_PB8(true, 1, SZV, FLTV); else BSQ_PB8(false, 1, SZV, FLTV); } \
@@ -922,6 +965,7 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     }
 #undef BSQ_PB8_T
 #undef BSQ_PB8
+#undef BSQ_PB8U
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_hip_error("k_tokens_pb8_fast", e);
     return BSQ_OK;

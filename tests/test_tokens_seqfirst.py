@@ -21,6 +21,8 @@ COMBOS = list(itertools.product([0, 1], repeat=3))  # (eos, bos, padchar)
 VARIANTS = {
     "auto": {},
     "pb8-ldslut": {"tokens8_lookup": 1},
+    "pb8-aligned-only": {"tokens_pb8": 3},
+    "pb8-unaligned-everywhere": {"tokens_pb8": 4},
     "raw-256x64": {"tokens_pb8": 1, "raw_mode": 1},
     "raw-1024x16": {"tokens_pb8": 1, "raw_mode": 4},
 }
@@ -129,9 +131,11 @@ def test_wider_types_any_batch_size_any_alignment(gpu, oracle, dc, B, P):
         for key, flags in (("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1))):
             want = oracle.OracleTokenizer(key, *flags).tokenize_packed(chars, offs, P, dc, False)
             desc = capi.make_desc(key, *flags)
-            for path, tb, shift in ((0, 0, 0), (0, 0, 1), (0, 64, 3), (0, 256, 1), (2, 0, 1), (0, 128, 2)):
+            # (the last two: int16 through the unaligned-row form of k_tokens_pb8_fast, knob tokens_pb8 = 4)
+            for path, tb, shift, pb8 in ((0, 0, 0, 0), (0, 0, 1, 0), (0, 64, 3, 0), (0, 256, 1, 0), (2, 0, 1, 0), (0, 128, 2, 0), (0, 0, 1, 4), (0, 0, 0, 4)):
                 capi.check(lib.bsq_tuning_set(b"tokenize_path", path))
                 capi.check(lib.bsq_tuning_set(b"tokenize_tb", tb))
+                capi.check(lib.bsq_tuning_set(b"tokens_pb8", pb8))
                 buf = torch.full(((P * B + 24) * sz,), 0x5A, dtype=torch.uint8, device=gpu)
                 lo = shift * sz
                 capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 0, dt,
@@ -139,10 +143,11 @@ def test_wider_types_any_batch_size_any_alignment(gpu, oracle, dc, B, P):
                 torch.cuda.synchronize()
                 host = buf.cpu().numpy()
                 assert (host[:lo] == 0x5A).all() and (host[lo + P * B * sz:] == 0x5A).all(), "wrote outside the matrix"
-                assert host[lo:lo + P * B * sz].tobytes() == want.tobytes(), (key, flags, dc, path, tb, shift)
+                assert host[lo:lo + P * B * sz].tobytes() == want.tobytes(), (key, flags, dc, path, tb, shift, pb8)
     finally:
         capi.check(lib.bsq_tuning_set(b"tokenize_path", 0))
         capi.check(lib.bsq_tuning_set(b"tokenize_tb", 0))
+        capi.check(lib.bsq_tuning_set(b"tokens_pb8", 0))
 
 
 @pytest.mark.parametrize("dc", list("hilfd"))
