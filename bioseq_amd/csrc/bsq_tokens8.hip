@@ -588,13 +588,16 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     __shared__ __align__(16) uint8_t s_t[TT * STRIDE];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t cls = blockIdx.x & 7u, i = blockIdx.x >> 3;
-    const uint32_t tbl = (magic ? __umulhi(i, magic) : i) >> shift;  // i / ntt (magic 0: ntt is a power of two)
-    const uint32_t tt = i - tbl * ntt;
-    uint32_t tb = tbl * 8u + cls;
-    if constexpr (UA) {
-        const uint32_t per = (ntb + 7u) / 8u;  // sequence tiles per XCD
-        if (tbl >= per) return;
-        tb = cls * per + tbl;
+    const uint32_t quo = (magic ? __umulhi(i, magic) : i) >> shift;  // i / ntt (magic 0: a power of two); contiguous form: i / per
+    uint32_t tt = i - quo * ntt, tb = quo * 8u + cls;
+    if (UA || (packed & 4u)) {
+        // Rows that are not 64-byte aligned: neighbouring sequence tiles share memory sectors.  Every XCD walks its own CONTIGUOUS
+        // range of `per` sequence tiles, sequence tile fastest: the two halves of a shared sector are written back to back through
+        // ONE L2 (the host passes the division constants of `per` instead of ntt).
+        const uint32_t per = (ntb + 7u) / 8u;
+        tt = quo;
+        tb = cls * per + (i - quo * per);
+        if (tt >= ntt) return;
     }
     if (tb >= ntb) return;
     const uint32_t bos = packed & 1u, none_v = (packed & 2u) ? 0xFFu : 0u;
@@ -712,22 +715,60 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     constexpr int N = 16 / SZ;     // tokens per 16-byte store
     constexpr int PPR = TB / N;    // stores per tile row
     static_assert((TT * PPR) % kThreads == 0 && (PPR & (PPR - 1)) == 0, "row walk");
+    if constexpr (!UA) {
 #pragma unroll
-    for (int f0 = 0; f0 < TT * PPR; f0 += kThreads) {
-        const int f = f0 + tid;
-        const int rr = f / PPR, piece = f % PPR;           // physical row rr holds position 16 (rr % 4) + rr / 4
-        const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
-        const int64_t col = static_cast<int64_t>(tb) * TB + piece * N;
-        if (t < static_cast<int32_t>(P) && col < pitch) {
-            uint8_t *dst = out + (static_cast<int64_t>(t) * pitch + col) * SZ;
-            const uint8_t *src = s_t + rr * STRIDE + piece * N;
-            if constexpr (!UA) {
-                store16<NT>(dst, widen_tokens<SZ, FLT>(src));
-            } else if (col + N <= pitch) {
-                store16_unaligned<NT>(dst, widen_tokens<SZ, FLT>(src));
-            } else {  // the piece that crosses the end of the row (one per row, in the last tile): element stores
-                static_assert(!UA || (SZ <= 2 && !FLT), "unaligned rows: 1- and 2-byte integers");
-                for (int k = 0; k < static_cast<int>(pitch - col); ++k) {
+        for (int f0 = 0; f0 < TT * PPR; f0 += kThreads) {
+            const int f = f0 + tid;
+            const int rr = f / PPR, piece = f % PPR;           // physical row rr holds position 16 (rr % 4) + rr / 4
+            const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
+            const int64_t col = static_cast<int64_t>(tb) * TB + piece * N;
+            if (t < static_cast<int32_t>(P) && col < pitch)
+                store16<NT>(out + (static_cast<int64_t>(t) * pitch + col) * SZ, widen_tokens<SZ, FLT>(s_t + rr * STRIDE + piece * N));
+        }
+    } else {
+        // Rows that are only element-aligned: the row segment of the tile is cut at the 16-byte lines of the OUTPUT.  Slot 0 = the
+        // head (the elements up to the first line: a neighbouring tile writes the rest of that line), slots 1 .. PPR = whole aligned
+        // lines -- 16-byte nt stores as in the aligned case, their tokens read from the tile at a BYTE offset (three 8-byte LDS
+        // reads + v_alignbyte) --, the last one the tail; heads and tails leave as single elements.
+        static_assert(!UA || (SZ <= 2 && !FLT), "unaligned rows: 1- and 2-byte integers");
+        constexpr int SLOTS = PPR + 1;
+        const int64_t c_tile = static_cast<int64_t>(tb) * TB;
+        const int32_t nb = pitch - c_tile < TB ? static_cast<int32_t>(pitch - c_tile) : TB;  // elements of the tile's row segment
+        for (int f = tid; f < TT * SLOTS; f += kThreads) {
+            const int rr = f / SLOTS, slot = f % SLOTS;
+            const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
+            if (t >= static_cast<int32_t>(P)) continue;
+            const int64_t e0 = static_cast<int64_t>(t) * pitch + c_tile;  // element index of the segment's first element
+            const uint32_t mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(out) + static_cast<uint64_t>(e0) * SZ) & 15u;
+            const int32_t head = static_cast<int32_t>(((16u - mis) & 15u) / SZ);  // elements up to the first 16-byte line
+            const int32_t c0 = slot == 0 ? 0 : head + (slot - 1) * N;
+            const int32_t left = nb - c0;
+            const int32_t cnt = slot == 0 ? (head < left ? head : left) : (left > N ? N : left);
+            if (cnt <= 0) continue;
+            const uint8_t *src = s_t + rr * STRIDE + c0;
+            uint8_t *dst = out + (e0 + c0) * SZ;
+            if (cnt == N) {  // a whole line: N token bytes from the byte offset c0 of the tile row (rows are 8-byte aligned, 8 bytes of padding behind)
+                const uint32_t sh = static_cast<uint32_t>(c0) & 7u;
+                const uint2 *q = reinterpret_cast<const uint2 *>(src - sh);
+                const uint2 q0 = q[0], q1 = q[1];
+                uint32_t d0 = q0.x, d1 = q0.y, d2 = q1.x, d3 = q1.y, d4 = 0;
+                if constexpr (SZ == 1) {
+                    const uint2 q2 = q[2];
+                    d4 = q2.x;
+                    if (sh & 4u) d0 = d1, d1 = d2, d2 = d3, d3 = d4, d4 = q2.y;
+                } else {
+                    if (sh & 4u) d0 = d1, d1 = d2, d2 = d3;
+                }
+                const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh & 3u), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh & 3u);
+                if constexpr (SZ == 1) {
+                    const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, sh & 3u), w3 = __builtin_amdgcn_alignbyte(d4, d3, sh & 3u);
+                    store16<NT>(dst, uint4{w0, w1, w2, w3});
+                } else {
+                    store16<NT>(dst, uint4{__builtin_amdgcn_perm(0u, w0, 0x0c010c00u), __builtin_amdgcn_perm(0u, w0, 0x0c030c02u),
+                                           __builtin_amdgcn_perm(0u, w1, 0x0c010c00u), __builtin_amdgcn_perm(0u, w1, 0x0c030c02u)});
+                }
+            } else {
+                for (int k = 0; k < cnt; ++k) {
                     if constexpr (SZ == 1) dst[k] = src[k];
                     else reinterpret_cast<uint16_t *>(dst)[k] = src[k];
                 }
@@ -882,17 +923,11 @@ bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
     // 4- and 8-byte elements: measured SLOWER than k_tokenize_tile (cfg2: int32 53 vs 48 us, 8-byte 111 vs 103;
     // profiles/r03/pb8_wider_types.txt) -- taken only under knob tokens_pb8 = 2 (tests, measurement)
     if (sz > 2 && tuning().tokens_pb8 != 2) return false;
-    // rows / outputs that are only element-aligned: the UA form.  Taken for int8 rows that are not even 8-byte aligned, where it
-    // beats k_tokens_raw's 4-byte / byte stores (65 537 x 1024: 30.7 vs 43.0 us, 250 001 x 256: 31.2 vs 40.6); with 8-byte aligned
-    // rows k_tokens_raw is as fast (65 000 x 1024: 30.8 vs 31.8), and for int16 k_tokenize_tile is faster (42 vs 51 us):
-    // profiles/r03/pb8_unaligned_rows.txt.  Knob tokens_pb8 = 3: aligned shapes only; 4: the UA form wherever it applies.
+    // rows / outputs that are only element-aligned: the UA form (1- and 2-byte integers; its stores are cut at the output's
+    // 16-byte lines).  65 537 x 1024 int8 42.8 -> 27.5 us, 65 000 x 1024 int8 30.2 -> 25.0, 100 001 x 512 int16 34.0 -> 28.8
+    // (profiles/r03/pb8_unaligned_rows.txt).  Knob tokens_pb8 = 3: aligned shapes only.
     const bool aligned = (pitch * sz) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
-    if (!aligned) {
-        const int knob = tuning().tokens_pb8;
-        if (sz > 2 || knob == 3 || reinterpret_cast<uintptr_t>(out) % uintptr_t(sz) != 0) return false;
-        const bool wins = sz == 1 && (pitch % 8 != 0 || reinterpret_cast<uintptr_t>(out) % 8 != 0);
-        if (!wins && knob != 4) return false;
-    }
+    if (!aligned && (sz > 2 || tuning().tokens_pb8 == 3 || reinterpret_cast<uintptr_t>(out) % uintptr_t(sz) != 0)) return false;
     return B > 0 && P >= 1 && P <= (int64_t(1) << 30) && B < (int64_t(1) << 31) - 4096 && pitch >= B && pitch < (int64_t(1) << 31) &&
            bsq_alphabet_size(d) <= 250;
 }
@@ -924,7 +959,10 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     build_rules(fill, at_len, rules);
     const int64_t room64 = P - d->bos - d->eos;
     const int32_t room = int32_t(room64 < 0 ? 0 : room64);
-    const uint32_t packed = uint32_t(d->bos != 0) | (raw ? 2u : 0u) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
+    // bit 2: every XCD walks its own contiguous range of sequence tiles (rows that are not 64-byte aligned: the sectors two
+    // neighbouring tiles share are then merged in ONE L2 -- 65 000 x 1024 int16: 49.6 -> 38.9 us, profiles/r03/pb8_unaligned_rows.txt)
+    const bool contig = (pitch * int64_t(bsq_dtype_size(t))) % 64 != 0 || reinterpret_cast<uintptr_t>(out) % 64 != 0;
+    const uint32_t packed = uint32_t(d->bos != 0) | (raw ? 2u : 0u) | (contig ? 4u : 0u) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
     const bool nt = nontemporal_stores() && !raw;  // the raw matrix is re-read by the expansion right away
     // one tile shape: 256 sequences x 64 positions (512 x 64 and 512 x 32 were built and measured slower:
     // profiles/r03/pb8_coalesced_ab.txt, pb8_512x32_tile_lost.txt)
@@ -932,10 +970,10 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     const int64_t ntb = (B + TB - 1) / TB, ntt = (P + TT - 1) / TT;
     const int64_t blocks = (ntb + 7) / 8 * 8 * ntt;
     if (blocks >= (int64_t(1) << 31)) return set_error(BSQ_ERR_INVALID_ARG, "output too large");
-    uint32_t magic = 0, shift = 0, pow2 = 0;
-    div_constants(uint32_t(ntt), &magic, &shift, &pow2);
-    if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)
     const bool ua = !((pitch * int64_t(bsq_dtype_size(t))) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    uint32_t magic = 0, shift = 0, pow2 = 0;
+    div_constants((contig || ua) ? uint32_t((ntb + 7) / 8) : uint32_t(ntt), &magic, &shift, &pow2);  // the divisor of the block index
+    if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)
 #define BSQ_PB8U(NTV, LKV, SZV, FLTV, UAV)                                                                                             \
     hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, 256, LKV, SZV, FLTV, UAV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,  \
                        static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift,    \

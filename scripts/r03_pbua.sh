@@ -16,7 +16,7 @@ for B, P in ((65536, 1024), (65000, 1024), (65000, 1001), (65537, 1024), (100001
         dt = ctypes.c_int(0); capi.check(lib.bsq_dtype_from_destchar(dc.encode(), ctypes.byref(dt))); sz = lib.bsq_dtype_size(dt)
         out = torch.empty(B * P * sz + 64, dtype=torch.uint8, device=dev)
         res = []
-        for knob in (3, 0):
+        for knob in (3, 4):
             capi.check(lib.bsq_tuning_set(b"tokens_pb8", knob))
             def run(): capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 0, dt, out.data_ptr(), None))
             for _ in range(20): run()

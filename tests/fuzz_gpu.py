@@ -44,7 +44,7 @@ def run(budget=120.0, seed=1):
         capi.check(lib.bsq_tuning_set(b"tokens8", knobs[3]))
         capi.check(lib.bsq_tuning_set(b"tokens8_fast", int(rng.integers(0, 2))))
         capi.check(lib.bsq_tuning_set(b"raw_mode", int(rng.choice([0, 1, 4]))))
-        capi.check(lib.bsq_tuning_set(b"tokens_pb8", int(rng.choice([0, 0, 1, 2, 3, 4]))))
+        capi.check(lib.bsq_tuning_set(b"tokens_pb8", int(rng.choice([0, 0, 0, 1, 2, 3]))))
         capi.check(lib.bsq_tuning_set(b"bcl_path", int(rng.integers(0, 4))))
         tok, ora = bsq.Tokenizer(key, eos, bos, pad), O.OracleTokenizer(key, eos, bos, pad)
         shift = int(rng.integers(0, 4))  # misaligned device views of the inputs

@@ -22,7 +22,6 @@ VARIANTS = {
     "auto": {},
     "pb8-ldslut": {"tokens8_lookup": 1},
     "pb8-aligned-only": {"tokens_pb8": 3},
-    "pb8-unaligned-everywhere": {"tokens_pb8": 4},
     "raw-256x64": {"tokens_pb8": 1, "raw_mode": 1},
     "raw-1024x16": {"tokens_pb8": 1, "raw_mode": 4},
 }
@@ -131,8 +130,8 @@ def test_wider_types_any_batch_size_any_alignment(gpu, oracle, dc, B, P):
         for key, flags in (("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1))):
             want = oracle.OracleTokenizer(key, *flags).tokenize_packed(chars, offs, P, dc, False)
             desc = capi.make_desc(key, *flags)
-            # (the last two: int16 through the unaligned-row form of k_tokens_pb8_fast, knob tokens_pb8 = 4)
-            for path, tb, shift, pb8 in ((0, 0, 0, 0), (0, 0, 1, 0), (0, 64, 3, 0), (0, 256, 1, 0), (2, 0, 1, 0), (0, 128, 2, 0), (0, 0, 1, 4), (0, 0, 0, 4)):
+            # (tokens_pb8 = 3: k_tokenize_tile for every unaligned shape; 0: int16 through the unaligned-row form of k_tokens_pb8_fast)
+            for path, tb, shift, pb8 in ((0, 0, 0, 3), (0, 0, 1, 3), (0, 64, 3, 3), (0, 256, 1, 3), (2, 0, 1, 3), (0, 128, 2, 3), (0, 0, 1, 0), (0, 0, 0, 0), (0, 0, 3, 0)):
                 capi.check(lib.bsq_tuning_set(b"tokenize_path", path))
                 capi.check(lib.bsq_tuning_set(b"tokenize_tb", tb))
                 capi.check(lib.bsq_tuning_set(b"tokens_pb8", pb8))
