@@ -55,7 +55,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   pattern_wait          bsq_fill_pattern_device: n > 0 = s_waitcnt vmcnt(n - 1) after every row of a wave
 //   host_copy_threads     worker threads of the pipelined device -> host result copy (0: 8)
 //   tokens_pb8            1: never use k_tokens_pb8_fast for the (P,B) token matrices (k_tokens_raw / k_tokenize_tile instead), 2: also
-//                         for 4- / 8-byte elements (automatic: 1- and 2-byte elements), 3: only when rows and output are 16-byte aligned;
+//                         for 4-byte elements (automatic: 1-, 2- and 8-byte elements), 3: only when rows and output are 16-byte aligned;
 //                         its lookup follows tokens8_lookup
 //   augment_k             attempts per lane and round of the augmentation kernel: 0 automatic (4), 1 (the round-2 form), 2
 // The knobs are ONE plain struct, published as an immutable snapshot: a launcher reads it with a single atomic load

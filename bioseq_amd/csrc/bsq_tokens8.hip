@@ -920,9 +920,9 @@ bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
     if (tuning().tokens_pb8 == 1) return false;
     const int64_t sz = int64_t(bsq_dtype_size(t));
     if (sz == 0) return false;
-    // 4- and 8-byte elements: measured SLOWER than k_tokenize_tile (cfg2: int32 53 vs 48 us, 8-byte 111 vs 103;
-    // profiles/r03/pb8_wider_types.txt) -- taken only under knob tokens_pb8 = 2 (tests, measurement)
-    if (sz > 2 && tuning().tokens_pb8 != 2) return false;
+    // 4-byte elements: measured slower than k_tokenize_tile (cfg2: 51 vs 48-50 us), 8-byte elements 3-4 % faster (100 vs 103.5 us) once the
+    // blocks walk sequence tiles fastest (profiles/r03/pb8_wider_types.txt) -- 4-byte types only under knob tokens_pb8 = 2 (tests, measurement)
+    if (sz == 4 && tuning().tokens_pb8 != 2) return false;
     // rows / outputs that are only element-aligned: the UA form (1- and 2-byte integers; its stores are cut at the output's
     // 16-byte lines).  65 537 x 1024 int8 42.8 -> 27.5 us, 65 000 x 1024 int8 30.2 -> 25.0, 100 001 x 512 int16 34.0 -> 28.8
     // (profiles/r03/pb8_unaligned_rows.txt).  Knob tokens_pb8 = 3: aligned shapes only.
@@ -961,7 +961,8 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     const int32_t room = int32_t(room64 < 0 ? 0 : room64);
     // bit 2: every XCD walks its own contiguous range of sequence tiles (rows that are not 64-byte aligned: the sectors two
     // neighbouring tiles share are then merged in ONE L2 -- 65 000 x 1024 int16: 49.6 -> 38.9 us, profiles/r03/pb8_unaligned_rows.txt)
-    const bool contig = (pitch * int64_t(bsq_dtype_size(t))) % 64 != 0 || reinterpret_cast<uintptr_t>(out) % 64 != 0;
+    // (also for 4- / 8-byte elements: with the position tiles of a sequence tile back to back they took 53 / 111 us instead of 51 / 100)
+    const bool contig = (pitch * int64_t(bsq_dtype_size(t))) % 64 != 0 || reinterpret_cast<uintptr_t>(out) % 64 != 0 || bsq_dtype_size(t) >= 4;
     const uint32_t packed = uint32_t(d->bos != 0) | (raw ? 2u : 0u) | (contig ? 4u : 0u) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
     const bool nt = nontemporal_stores() && !raw;  // the raw matrix is re-read by the expansion right away
     // one tile shape: 256 sequences x 64 positions (512 x 64 and 512 x 32 were built and measured slower:
