@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 closing evidence on ONE box: full GPU suite, randomised harness, un-profiled bench lines of every workload, then
 # rocprofv3 kernel stats + WRITE/FETCH passes of every workload and SQ/TCC counters of the token / tile kernels
-OUT=gpurun_out/r03f; mkdir -p $OUT
+OUT=gpurun_out/${OUTDIR:-r03f}; mkdir -p $OUT
 ( time timeout 3000 python -m pytest tests -m gpu -q ) > $OUT/gputest.txt 2>&1
 grep -E "passed|failed|error" $OUT/gputest.txt | tail -2
 timeout 1200 python tests/fuzz_gpu.py ${1:-600} 77 2>&1 | tail -2 | tee $OUT/fuzz.txt
