@@ -58,7 +58,8 @@ def dev_tokens_pb(lib, capi, desc, chars, offs, P, gpu, shift=0, out_shift=0):
                                        (2047, 100, 300, 302), (70000, 0, 20, 24),
                                        # 16-byte aligned rows (k_tokens_pb8_fast): one piece, ragged tiles, padlen around 16 / 32 / 64
                                        (16, 0, 9, 11), (48, 0, 40, 41), (512, 0, 62, 64), (528, 10, 63, 65), (1040, 0, 127, 129),
-                                       (4112, 0, 299, 301), (16400, 0, 30, 31), (272, 700, 1100, 1111)])
+                                       (4112, 0, 299, 301), (16400, 0, 30, 31), (272, 700, 1100, 1111),
+                                       (48, 0, 69990, 70001), (17, 30000, 66000, 66001)])  # long padlen: > 1000 position tiles
 def test_shapes_vs_oracle(gpu, oracle, raw_mode, B, lo, hi, P):
     """Single sequences, ragged tails of the sequence tile (B not a multiple of 16 / 256 / 1024), padlen that is not a
     multiple of the tile's 16 / 64 positions, empty sequences, every byte value; output rows at every alignment the
