@@ -202,12 +202,59 @@ __global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const in
             const bool pick = L > 0 && (!(frac < 1.0) || unit(mix64(h0 + 0xD1342543DE82EF95ull)) < frac);
             rem = pick ? chain_len : 0;
         }
+        // FIRST ROUND, in the home lane itself (round 3): the K attempts with counters 1 .. K of the first mutation, their gathers
+        // in flight together, straight out of registers.  An attempt is accepted with probability 1 - p_self (~0.75 on the
+        // average protein), so K = 4 settle 99.6 % of the mutations here and the typical wave never enters the group machinery
+        // below -- no state round trip through LDS, no second pass over the loop (cycle-counter timeline of the kernel:
+        // profiles/r03/augment_timeline.txt).  Attempts are consumed in counter order as everywhere: same results.
+        uint32_t ctr = 1;
+        int32_t tries = 0;
+        const bool long_len0 = __builtin_amdgcn_ballot_w64((static_cast<uint64_t>(L) >> 32) != 0) != 0;
+        if (rem > 0 && !long_len0) {
+            uint64_t r[K];
+            int64_t idx[K];
+            uint8_t ch[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                r[k] = mix64(h0 + 0xD1342543DE82EF95ull * (static_cast<uint64_t>(ctr + k) + 1));
+                idx[k] = static_cast<int64_t>(mulhi_64x32(r[k], static_cast<uint32_t>(L)));
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) ch[k] = chars[start + idx[k]];
+            int win = -1;
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k)
+                if (static_cast<uint32_t>(r[k]) <= s_tab.accept_le[s_tab.row_of[ch[k]]]) win = k;  // the FIRST accepted attempt
+            if (win >= 0) {
+                int64_t iw = idx[0];
+                uint8_t cw = ch[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k)
+                    if (win == k) iw = idx[k], cw = ch[k];
+                const uint32_t c = ctr + static_cast<uint32_t>(win);
+                const int row = s_tab.row_of[cw];
+                const double pself = s_tab.self[row];
+                const double *cdf = s_tab.cdf[row];
+                const double u = unit(mix64(h0 + 0xD1342543DE82EF95ull * (static_cast<uint64_t>(c) + 2))) * (cdf[kCols - 1] - pself);
+                uint32_t below = 0;
+#pragma unroll
+                for (int q = 0; q < kCols; ++q) below |= static_cast<uint32_t>(q != row && u < cdf[q] - (q > row ? pself : 0.0)) << q;
+                const int last = row == kCols - 1 ? kCols - 2 : kCols - 1;
+                chars[start + iw] = s_tab.letter[below ? __builtin_ctz(below) : last];
+                ctr = c + 2;
+                rem -= 1;
+            } else {
+                ctr += K;
+                tries = K;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(rem > 0) == 0) return;  // wave-uniform: every mutation of the wave is made
         s_start[wave][lane] = start;
         s_len[wave][lane] = L;
         s_h0[wave][lane] = h0;
-        s_ctr[wave][lane] = 1;
+        s_ctr[wave][lane] = ctr;
         s_rem[wave][lane] = rem;
-        s_tries[wave][lane] = 0;
+        s_tries[wave][lane] = tries;
     }
     __shared__ int32_t s_sel[4][kSeqPerWave];
     for (;;) {
