@@ -286,7 +286,10 @@ def main():
     def step():
         if op == "augment+tokenize":  # AugmentedSeqDataset defaults (loaders.py:117-119): chain_len 1, frac 0.5
             aug_seed[0] += 1
-            capi.check(lib.bsq_augment_device(d_chars.data_ptr(), d_offs.data_ptr(), n, 1, 0.5, aug_seed[0], sh))
+            # one C-ABI call = bsq_augment_device, then bsq_tokenize_device (one launch where the fast token kernel applies)
+            capi.check(lib.bsq_augment_tokenize_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), n, P,
+                                                       int(batch_first), dt_code, out.data_ptr(), 1, 0.5, aug_seed[0], sh))
+            return
         if op == "onehot":
             st = lib.bsq_onehot_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), None, n, P,
                                        dt_code, out.data_ptr(), sh)
@@ -508,7 +511,8 @@ def main():
                              if batch_first else ("k_tokens_pb8_fast" if sz <= 2 and (n * sz) % 16 == 0 and os.environ.get("BSQ_TOKENS_PB8", "0") != "1"
                                                  else ("k_tokens_raw<value>" if sz == 1 else "k_tokenize_tile"))))
         if op == "augment+tokenize":
-            kernel_name = "k_augment_groups+" + kernel_name
+            kernel_name = ("k_augment_tokens_fused(k_augment_groups -> k_tokens_bp8_fast)" if os.environ.get("BSQ_AUGMENT_FUSED", "0") != "1"
+                           else "k_augment_groups+" + kernel_name)
         if op == "onehot_bcl":
             kernel_name = "k_tokens_bp8<raw>+k_expand_bcl" if (P >= 128 and P % 16 == 0 and out_bytes >= (256 << 20)) else "k_tokenize_chunks<onehot bcl>"
         res = {

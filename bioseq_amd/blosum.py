@@ -80,4 +80,38 @@ def augment_packed(chars, offsets, chain_len=1, augment_frac=1.0, seed=0):
     return chars
 
 
-__all__ = ["aa_array", "substitute", "normrows", "probdict", "augment_seq", "augment_packed"]
+def augment_tokenize_packed(tokenizer, chars, offsets, padlen, destchar="b", batch_first=True, chain_len=1, augment_frac=1.0,
+                            seed=0, out=None):
+    """`augment_packed` followed by `tokenizer.tokenize_packed` -- what the reference's loaders do per item
+    (bioseq/loaders.py:83-84: `augment_seq`, then `batch_tokenize`) -- with exactly their results: `chars` is mutated in
+    place, the token matrix of the mutated batch is returned.  For `(B,P)` int8 matrices of the fast token kernel it is ONE
+    launch (`bsq_augment_tokenize_device`); other shapes run the two launches.  Sequences longer than
+    padlen - bos - eos must have been rejected by the caller (as `tokenize_packed(validate=True)` does)."""
+    import torch
+    if not (chars.is_cuda and offsets.is_cuda):
+        raise ValueError("augment_tokenize_packed works on device tensors (use .to('cuda'))")
+    if chars.dtype != torch.uint8 or offsets.dtype != torch.int64 or not chars.is_contiguous() or not offsets.is_contiguous():
+        raise ValueError("chars must be contiguous uint8 and offsets contiguous int64")
+    B = offsets.numel() - 1
+    dt = ctypes.c_int(0)
+    capi.check(_lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt)))
+    tdt = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[_lib.bsq_dtype_size(dt)]
+    if destchar[0].lower() == "f":
+        tdt = torch.float32
+    elif destchar[0].lower() == "d":
+        tdt = torch.float64
+    shape = (B, padlen) if batch_first else (padlen, B)
+    if out is None:
+        out = torch.empty(shape, dtype=tdt, device=chars.device)
+    elif tuple(out.shape) != shape or out.dtype != tdt or not out.is_contiguous() or out.device != chars.device:
+        raise ValueError("out must be a contiguous %s tensor of shape %r on the device of chars" % (tdt, shape))
+    desc = capi.make_desc(tokenizer.key, tokenizer.includes_eos(), tokenizer.includes_bos(), tokenizer.is_padded())
+    with torch.cuda.device(chars.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        capi.check(_lib.bsq_augment_tokenize_device(ctypes.byref(desc), chars.data_ptr(), offsets.data_ptr(), B, int(padlen),
+                                                    int(bool(batch_first)), dt, out.data_ptr(), int(chain_len), float(augment_frac),
+                                                    ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), stream))
+    return out
+
+
+__all__ = ["aa_array", "substitute", "normrows", "probdict", "augment_seq", "augment_packed", "augment_tokenize_packed"]

@@ -55,6 +55,7 @@ def load():
         "bsq_tuning_set": (i32, [ctypes.c_char_p, i32]),
         "bsq_tuning_get": (i32, [ctypes.c_char_p]),
         "bsq_host_upload_bytes": (ctypes.c_uint64, []),
+        "bsq_fused_wait_failures": (ctypes.c_uint32, []),
         "bsq_num_keys": (i32, []),
         "bsq_key_name": (ctypes.c_char_p, [i32]),
         "bsq_lut_get": (i32, [ctypes.c_char_p, vp, ctypes.POINTER(i32)]),
@@ -89,6 +90,7 @@ def load():
         "bsq_gather_packed_device": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, vp]),
         "bsq_blosum62_normrows": (i32, [vp]),
         "bsq_augment_device": (i32, [vp, vp, i64, i32, ctypes.c_double, ctypes.c_uint64, vp]),
+        "bsq_augment_tokenize_device": (i32, [vp, vp, vp, i64, i64, i32, i32, vp, i32, ctypes.c_double, ctypes.c_uint64, vp]),
         "bsq_tokenize_host": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, c_int, vp, i64p]),
         "bsq_onehot_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),
         "bsq_onehot_bcl_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),

@@ -2535,6 +2535,31 @@ bsq_status bsq_onehot_device_generic(const bsq_desc *d, const uint8_t *chars, co
     return check_launch("k_onehot_generic");
 }
 
+bsq_status bsq_augment_tokenize_device(const bsq_desc *d, uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
+                                       int32_t batch_first, bsq_dtype t, void *out, int32_t chain_len, double frac, uint64_t seed,
+                                       void *hip_stream) {
+    KParams k;
+    bsq_status st = fill_common(k, d, chars, offsets, nullptr, B, P, out);
+    if (st != BSQ_OK) return st;
+    if (chain_len < 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bad augment arguments");
+    if (B == 0) return BSQ_OK;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    // one launch where bsq_tokenize_device would take the fast form of k_tokens_bp8 (same conditions as there)
+    if (chain_len > 0 && frac > 0.0 && chars && batch_first && t == BSQ_I8 && k.C <= 250 && B < (int64_t(1) << 31) - 1024 &&
+        bsq_internal::tuning().tokenize_path != 1 && bsq_internal::tuning().tokens8 != 1 && bsq_internal::tokens_bp8_applicable(d, B, P, out)) {
+        bsq_internal::FusedAugRequest fr{chars, chain_len, frac, seed};
+        bool taken = false;
+        st = bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, out, s, false, nullptr, &fr, &taken);
+        if (st != BSQ_OK) return st;
+        if (taken) return BSQ_OK;
+    }
+    st = bsq_augment_device(chars, offsets, B, chain_len, frac, seed, hip_stream);
+    if (st != BSQ_OK) return st;
+    return bsq_tokenize_device(d, chars, offsets, B, P, batch_first, t, out, hip_stream);
+}
+
+uint32_t bsq_fused_wait_failures(void) { return bsq_internal::fused_wait_failures(); }
+
 bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                        int64_t B, int64_t P, int32_t batch_first, bsq_dtype t, void *out,
                                        void *hip_stream) {

@@ -20,8 +20,10 @@
 
 #include <climits>
 #include <cstdint>
+#include <mutex>
 
 #include "bsq.h"
+#include "bsq_augment_dev.h"
 #include "bsq_device.h"
 #include "bsq_internal.h"
 
@@ -386,16 +388,44 @@ struct T8Rules {
     uint4 keep[18];
     uint4 cst[18];
 };
-template <bool NT>
-__global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
-                                                              uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
-                                                              uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
-                                                              T8Tab tab, T8Rules rules) {
+// (the body as a device function of a VIRTUAL block index: the fused augmentation + token launch below runs it behind its
+//  augmentation blocks; FLAGS: wait for the augmentation of the chunk's rows first, see k_augment_tokens_fused)
+template <bool NT, bool FLAGS>
+__device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
+                                                 uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR, uint32_t magic,
+                                                 uint32_t shift, int32_t room, uint32_t packed, const T8Tab &tab, const T8Rules &rules,
+                                                 const uint32_t *flags, uint32_t epoch, uint32_t *wait_failures) {
     __shared__ __align__(16) uint4 s_rule[4][2][18];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t wave_s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(wave));
-    const uint32_t k0 = (blockIdx.x & 7u) + 8u * ((blockIdx.x >> 3) * 4u + wave_s);  // class = blockIdx % 8 (XCD-pinned)
+    const uint32_t k0 = (vblock & 7u) + 8u * ((vblock >> 3) * 4u + wave_s);  // class = block % 8 (XCD-pinned)
     if (k0 >= nchunks) return;
+    if constexpr (FLAGS) {
+        // the rows of this chunk: bc .. bc + nr (nr <= 32).  Their sequences were augmented by the waves (row / 64) of the
+        // augmentation blocks, which are dispatched BEFORE every token block (lower block indices: the dispatcher hands blocks out
+        // in order, as the decoupled look-back scans of rocPRIM rely on) and never wait for anything.  A bounded spin, so that a
+        // broken assumption shows up as a counted failure and wrong output, not as a hung device.
+        const uint32_t g0f = k0 * (kChunk / 16);
+        const uint32_t bcf = __umulhi(g0f, magic) >> shift;
+        const uint32_t tcf = g0f - bcf * PPR;
+        const uint32_t nrf = __umulhi(tcf + (kChunk / 16 - 1), magic) >> shift;
+        const uint32_t lastrow = bcf + nrf < B ? bcf + nrf : B - 1;
+        const uint32_t f0 = bcf / 64u, f1 = lastrow / 64u;  // f1 - f0 <= 1
+        bool ok = true;
+        if (static_cast<uint32_t>(lane) <= f1 - f0) {
+            ok = false;
+            for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+                if (__hip_atomic_load(flags + f0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+                    ok = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) atomicAdd(wait_failures, 1u);
+        }
+        // (no cache-wide acquire: the characters are read with agent-scope loads below, which find what those waves wrote through)
+        __builtin_amdgcn_wave_barrier();
+    }
     auto div_p = [&](uint32_t n) { return __umulhi(n, magic) >> shift; };
     const uint32_t bos = packed & 1u, none_v = (packed & 2u) ? 0xFFu : 0u;
     const uint32_t bos_id = (packed >> 8) & 0xFFu;
@@ -465,8 +495,21 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
     u32x4u cw[4];
     if (can_vec) {
         const uint8_t *cbase = chars + (off0 + lo_b);  // wave-uniform, inside the buffer
+        if constexpr (FLAGS) {
+            // agent-scope loads (sc1: not served from this XCD's L2 or the CU's L1, where a line may predate the mutation of a
+            // NEIGHBOURING sequence group).  One asm block with its own wait: the compiler must not touch the registers in between.
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                         "global_load_dwordx4 %1, %5, off sc1\n\t"
+                         "global_load_dwordx4 %2, %6, off sc1\n\t"
+                         "global_load_dwordx4 %3, %7, off sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(cw[0]), "=&v"(cw[1]), "=&v"(cw[2]), "=&v"(cw[3])
+                         : "v"(cbase + uoff[0]), "v"(cbase + uoff[1]), "v"(cbase + uoff[2]), "v"(cbase + uoff[3])
+                         : "memory");
+        } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cw[u] = *reinterpret_cast<const u32x4u *>(cbase + uoff[u]);
+            for (int u = 0; u < 4; ++u) cw[u] = *reinterpret_cast<const u32x4u *>(cbase + uoff[u]);
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) cw[u] = u32x4u{0x41434447u, 0x61636474u, 0x4B4C4D4Eu, 0x50515253u};
@@ -489,7 +532,8 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i)
                     if (j0[u] + i >= 0 && j0[u] + i < L[u])
-                        w[i >> 2] |= static_cast<uint32_t>(chars[start + j0[u] + i]) << (8 * (i & 3));
+                        w[i >> 2] |= static_cast<uint32_t>(FLAGS ? __hip_atomic_load(chars + start + j0[u] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                                 : chars[start + j0[u] + i]) << (8 * (i & 3));
                 cw[u] = u32x4u{w[0], w[1], w[2], w[3]};
             }
         }
@@ -519,6 +563,51 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
         if (j0[u] < 0) o.x = (o.x & ~0xFFu) | bos_id;  // position 0 with BOS
         if (live[u]) store16<NT>(dst + u * 1024, o);
     }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
+                                                              uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
+                                                              uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
+                                                              T8Tab tab, T8Rules rules) {
+    tokens_fast_body<NT, false>(blockIdx.x, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, nullptr, 0u, nullptr);
+}
+
+// BASELINE config 5 as ONE launch (round 3): BLOSUM62 augmentation (bsq_augment.hip) and the (B,P) int8 token matrix.  The first
+// `aug_blocks` workgroups (a multiple of 8, so that the token role's chunk classes stay pinned to their XCDs) are k_augment_groups
+// on 256 sequences each; every one of their waves, once its 64 sequences are mutated, RELEASES at agent scope and publishes the
+// launch's epoch in flags[wave].  The workgroups behind them are k_tokens_bp8_fast; a chunk wave waits for the (one or two) flags
+// of its rows, ACQUIRES, and runs as usual.  The augmentation is one generation of waves that lives ~7 us; as its own launch it
+// cost 16.4 us on cfg5 -- launch latency and completion of a kernel this small are exposed, and the token kernel could not start
+// before them (profiles/r03/augment_timeline.txt).  Results are those of the two launches, bit for bit.
+struct FusedAug {
+    uint8_t *chars;  // the same buffer the token role reads
+    int64_t B;
+    const bsq_aug::AugTable *tab;
+    double frac;
+    uint64_t seed;
+    int32_t chain_len;
+    uint32_t aug_blocks;
+    uint32_t *flags;          // aug_blocks * 4 words (one per augmentation wave)
+    uint32_t *failures;       // chunk waves that gave up waiting (expected: never)
+    uint32_t epoch;
+};
+template <bool NT, int K>
+__global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t *__restrict__ offsets, const uint8_t *chars,
+                                                                   uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
+                                                                   uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
+                                                                   T8Tab tab, T8Rules rules, FusedAug fa) {
+    if (blockIdx.x < fa.aug_blocks) {
+        bsq_aug::augment_groups_body<K, true>(blockIdx.x, fa.chars, offsets, fa.B, fa.chain_len, fa.frac, fa.seed, fa.tab);
+        // this wave's character stores (agent scope: written through) have been acknowledged ... (no cache-wide release: a
+        // buffer_wbl2 per wave made the launch take 326 us instead of 49)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0)                          // ... before its flag is published
+            __hip_atomic_store(fa.flags + blockIdx.x * 4u + (threadIdx.x >> 6), fa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    tokens_fast_body<NT, true>(blockIdx.x - fa.aug_blocks, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules,
+                               fa.flags, fa.epoch, fa.failures);
 }
 
 // k_tokens_pb8_fast: the (P,B) int8 token matrix -- batch_tokenize's DEFAULT layout (batch_first=False,
@@ -845,8 +934,62 @@ bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
     return B > 0 && P >= 128 && P <= (int64_t(1) << 30) && bsq_alphabet_size(d) <= 250 && B * P < (int64_t(1) << 51);
 }
 
+// Per (device, stream) flag words of the fused augmentation + token launch: zeroed once, then every launch publishes its own epoch.
+struct FusedFlags {
+    int dev;
+    hipStream_t stream;
+    uint32_t *buf;
+    size_t words;
+    uint32_t epoch;
+};
+static FusedFlags g_fused_flags[16] = {};
+static std::mutex g_fused_mu;
+static bsq_status fused_flags_acquire(hipStream_t s, size_t words, uint32_t **buf, uint32_t **failures, uint32_t *epoch) {
+    std::lock_guard<std::mutex> lock(g_fused_mu);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_hip_error("hipGetDevice", e);
+    FusedFlags *slot = nullptr;
+    for (FusedFlags &f : g_fused_flags)
+        if (f.buf && f.dev == dev && f.stream == s) slot = &f;
+    if (!slot)
+        for (FusedFlags &f : g_fused_flags)
+            if (!f.buf) { slot = &f; break; }
+    if (!slot) return set_error(BSQ_ERR_INVALID_ARG, "too many streams use the fused augmentation launch");
+    if (!slot->buf || slot->words < words || slot->epoch == 0xFFFFFFFFu) {
+        if (slot->buf) (void)hipFree(slot->buf);  // (synchronises the device: nothing in flight still reads it)
+        slot->buf = nullptr;
+        const size_t cap = words < 4096 ? 4096 : words;
+        e = hipMalloc(reinterpret_cast<void **>(&slot->buf), cap * sizeof(uint32_t));
+        if (e != hipSuccess) return set_hip_error("hipMalloc(fused flags)", e);
+        e = hipMemset(slot->buf, 0, cap * sizeof(uint32_t));
+        if (e != hipSuccess) return set_hip_error("hipMemset(fused flags)", e);
+        slot->dev = dev;
+        slot->stream = s;
+        slot->words = cap;
+        slot->epoch = 0;
+    }
+    *buf = slot->buf;
+    *failures = slot->buf + slot->words - 1;  // the last word of the buffer
+    *epoch = ++slot->epoch;
+    return BSQ_OK;
+}
+
+uint32_t fused_wait_failures() {  // diagnostic: chunk waves of fused launches that gave up waiting (expected: 0); synchronises
+    std::lock_guard<std::mutex> lock(g_fused_mu);
+    uint32_t total = 0;
+    for (FusedFlags &f : g_fused_flags) {
+        if (!f.buf) continue;
+        (void)hipDeviceSynchronize();
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (hipMemcpy(v, f.buf + f.words - 1, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) total += v[0];
+    }
+    return total;
+}
+
 bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
-                             void *out, hipStream_t s, bool raw, const uint8_t *mask) {
+                             void *out, hipStream_t s, bool raw, const uint8_t *mask, const FusedAugRequest *fuse, bool *fused_taken) {
+    if (fused_taken) *fused_taken = false;
     if (mask && (!raw || P % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0))
         return set_error(BSQ_ERR_INVALID_ARG, "k_tokens_bp8: a mask needs raw-id mode and an aligned shape");
     T8Params c;
@@ -895,6 +1038,43 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
         for (int i = 0; i < 8; ++i) tab.t[i] = c.tab[i];
         T8Rules rules;
         build_rules(c.fill_v, c.at_len_v, rules);
+        if (fuse && fused_taken && tuning().augment_fused != 1 && pad == 0) {  // augmentation in the same launch (see k_augment_tokens_fused)
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s, &cap);
+            const int64_t aug_blocks = ((B + 255) / 256 + 7) / 8 * 8;
+            if (cap == hipStreamCaptureStatusNone && aug_blocks + int64_t(grid.x) < (int64_t(1) << 31)) {  // (a replayed graph would replay the epoch)
+                const void *atab = nullptr;
+                bsq_status st = augment_device_table(&atab);
+                if (st != BSQ_OK) return st;
+                uint32_t *flags = nullptr, *failures = nullptr, epoch = 0;
+                const size_t words = size_t(aug_blocks) * 4 + 1;
+                st = fused_flags_acquire(s, words, &flags, &failures, &epoch);
+                if (st != BSQ_OK) return st;
+                FusedAug fa;
+                fa.chars = fuse->chars;
+                fa.B = B;
+                fa.tab = static_cast<const bsq_aug::AugTable *>(atab);
+                fa.frac = fuse->frac;
+                fa.seed = fuse->seed;
+                fa.chain_len = fuse->chain_len;
+                fa.aug_blocks = uint32_t(aug_blocks);
+                fa.flags = flags;
+                fa.failures = failures;
+                fa.epoch = epoch;
+                const dim3 fgrid(unsigned(aug_blocks + int64_t(grid.x)));
+                if (nt)
+                    hipLaunchKernelGGL((k_augment_tokens_fused<true, 4>), fgrid, dim3(kThreads), 0, s, offsets, chars, c.out, uint32_t(c.nchunks),
+                                       uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules, fa);
+                else
+                    hipLaunchKernelGGL((k_augment_tokens_fused<false, 4>), fgrid, dim3(kThreads), 0, s, offsets, chars, c.out, uint32_t(c.nchunks),
+                                       uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules, fa);
+                const hipError_t eff = hipGetLastError();
+                if (eff != hipSuccess) return set_hip_error("k_augment_tokens_fused", eff);
+                *fused_taken = true;
+                return BSQ_OK;
+            }
+        }
+        if (fuse) return BSQ_OK;  // the caller runs the two launches (fused_taken stays false; nothing was launched)
         if (nt)
             hipLaunchKernelGGL((k_tokens_bp8_fast<true>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks),
                                uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules);
@@ -905,6 +1085,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
         if (ef != hipSuccess) return set_hip_error("k_tokens_bp8_fast", ef);
         return BSQ_OK;
     }
+    if (fuse) return BSQ_OK;  // no fused form for this shape: the caller runs the two launches
 #define BSQ_T8(NTV, LKV) launch_variant<NTV, LKV>(c, grid, pad, s)
     if (lk == 2) { if (nt) BSQ_T8(true, 1); else BSQ_T8(false, 1); }
     else { if (nt) BSQ_T8(true, 0); else BSQ_T8(false, 0); }

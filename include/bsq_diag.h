@@ -21,6 +21,9 @@ int32_t bsq_tuning_get(const char *name);
 /* Bytes the *_host entry points have copied host -> device since the library was loaded (the device entry points copy
  * nothing).  The loader tests assert that a shuffled epoch over a resident FlatFile leaves it unchanged. */
 uint64_t bsq_host_upload_bytes(void);
+/* chunk waves of fused augmentation + token launches (bsq_augment_tokenize_device) that gave up waiting for their rows'
+ * augmentation -- expected: 0, ever; synchronises the device */
+uint32_t bsq_fused_wait_failures(void);
 
 /* Streaming fill of nbytes (multiple of 16, 16-byte aligned) with a 32-bit pattern: the
  * write-bandwidth yardstick bench.py reports next to the encode kernels. */

@@ -10,7 +10,7 @@ os.makedirs(dst, exist_ok=True)
 traffic = {"_note": "HBM bytes per step from separate rocprofv3 --pmc passes (WRITE_SIZE, FETCH_SIZE; units KB), summed over the "
                     "kernels of one bench step. FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (an upper "
                     "bound). Sources: profiles/%s/<workload>_summary.json (scripts/evidence_all.sh + scripts/make_traffic.py)." % tag}
-STEP_KERNELS = ("k_tokens_pb8", "k_tokens_raw", "k_expand_chunks", "k_expand_small", "k_expand_bcl", "k_onehot_tile", "k_onehot_chunks", "k_tokenize_chunks", "k_tokens_bp8",
+STEP_KERNELS = ("k_augment_tokens_fused", "k_tokens_pb8", "k_tokens_raw", "k_expand_chunks", "k_expand_small", "k_expand_bcl", "k_onehot_tile", "k_onehot_chunks", "k_tokenize_chunks", "k_tokens_bp8",
                 "k_augment", "k_tokenize_rows", "k_tokenize_tile", "k_onehot_rows")
 def short(name):
     for k in STEP_KERNELS:

@@ -316,3 +316,72 @@ def test_chain_of_mutations_follows_the_law_step_by_step(gpu):
     same = float((nd <= 1).sum())                # same position twice: one visible change (or none: mutated back)
     sd = np.sqrt(n * p_same * (1 - p_same))
     assert abs(same - n * p_same) < 6 * sd, (same, n * p_same)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key,flags", [("SEB8", (0, 0, 0)), ("AMINO20", (1, 1, 1)), ("SEB14", (1, 0, 0)), ("BYTES", (0, 0, 0))])
+@pytest.mark.parametrize("B,P,lo,hi", [(1, 128, 5, 100), (300, 128, 0, 126), (4096, 512, 50, 510), (20000, 256, 1, 254),
+                                       (5000, 250, 0, 248), (70000, 160, 100, 158), (777, 1024, 900, 1022)])
+def test_fused_augment_tokenize_equals_the_two_calls(gpu, bsq, oracle, key, flags, B, P, lo, hi):
+    """bsq_augment_tokenize_device (ONE launch for (B,P) int8 where the fast token kernel applies: augmentation workgroups
+    ahead of token workgroups that wait for their rows' flags) == bsq_augment_device, then bsq_tokenize_device: the same
+    mutated characters, the same tokens (== the oracle's encode of the mutated bytes), for chains and fractions, layouts
+    and types that fuse and that do not, and with the fusion switched off; no chunk wave ever gave up waiting."""
+    import torch
+    from bioseq_amd import blosum, capi, synth
+    lib = capi.load()
+    eos, bos, pad = flags
+    hi = min(hi, P - eos - bos)
+    lo = min(lo, hi)
+    chars, offs = synth.synth_packed(B * 7 + P, B, lo, hi, synth.AA)
+    dof = torch.from_numpy(offs).to(gpu)
+    tok = bsq.Tokenizer(key, eos, bos, pad)
+    ora = oracle.OracleTokenizer(key, eos, bos, pad)
+    for chain_len, frac, dc, bf, knob in ((1, 0.5, "b", True, 0), (3, 1.0, "b", True, 0), (2, 0.7, "b", True, 1), (1, 0.5, "b", False, 0),
+                                          (1, 1.0, "i", True, 0), (0, 1.0, "b", True, 0)):
+        if key == "BYTES" and dc == "b":
+            continue  # ids up to 255 need a wider type
+        capi.check(lib.bsq_tuning_set(b"augment_fused", knob))
+        try:
+            ref = torch.from_numpy(chars).to(gpu)
+            blosum.augment_packed(ref, dof, chain_len=chain_len, augment_frac=frac, seed=99 + chain_len)
+            want_chars = ref.cpu().numpy()
+            want = ora.tokenize_packed(want_chars, offs, P, dc, bf)
+            got_chars = torch.from_numpy(chars).to(gpu)
+            got = blosum.augment_tokenize_packed(tok, got_chars, dof, P, dc, bf, chain_len=chain_len, augment_frac=frac, seed=99 + chain_len)
+            assert got_chars.cpu().numpy().tobytes() == want_chars.tobytes(), (key, flags, B, P, chain_len, frac, dc, bf, knob)
+            assert got.cpu().numpy().tobytes() == want.tobytes(), (key, flags, B, P, chain_len, frac, dc, bf, knob)
+        finally:
+            capi.check(lib.bsq_tuning_set(b"augment_fused", 0))
+    assert lib.bsq_fused_wait_failures() == 0
+
+
+@pytest.mark.gpu
+def test_fused_augment_tokenize_many_launches_two_streams(gpu, bsq, oracle):
+    """Back-to-back fused launches on two streams (each has its own flag words and epochs), re-using the buffers: every
+    result equals the two-call form."""
+    import torch
+    from bioseq_amd import blosum, capi, synth
+    lib = capi.load()
+    B, P = 30000, 256
+    chars, offs = synth.synth_packed(4242, B, 10, 254, synth.AA)
+    dof = torch.from_numpy(offs).to(gpu)
+    tok = bsq.Tokenizer("SEB8")
+    ora = oracle.OracleTokenizer("SEB8")
+    streams = [torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)]
+    bufs = [torch.from_numpy(chars).to(gpu) for _ in streams]
+    outs = [None, None]
+    torch.cuda.synchronize()
+    for it in range(12):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[k] = blosum.augment_tokenize_packed(tok, bufs[k], dof, P, "b", True, chain_len=1, augment_frac=0.5, seed=1000 * k + it)
+    torch.cuda.synchronize()
+    for k in range(2):
+        ref = torch.from_numpy(chars).to(gpu)
+        for it in range(12):
+            blosum.augment_packed(ref, dof, chain_len=1, augment_frac=0.5, seed=1000 * k + it)
+        want_chars = ref.cpu().numpy()
+        assert bufs[k].cpu().numpy().tobytes() == want_chars.tobytes(), k
+        assert outs[k].cpu().numpy().tobytes() == ora.tokenize_packed(want_chars, offs, P, "b", True).tobytes(), k
+    assert lib.bsq_fused_wait_failures() == 0
