@@ -955,7 +955,10 @@ static bsq_status fused_flags_acquire(hipStream_t s, size_t words, uint32_t **bu
     if (!slot)
         for (FusedFlags &f : g_fused_flags)
             if (!f.buf) { slot = &f; break; }
-    if (!slot) return set_error(BSQ_ERR_INVALID_ARG, "too many streams use the fused augmentation launch");
+    if (!slot) {  // more (device, stream) pairs than slots: the caller runs the two launches
+        *buf = nullptr;
+        return BSQ_OK;
+    }
     if (!slot->buf || slot->words < words || slot->epoch == 0xFFFFFFFFu) {
         if (slot->buf) (void)hipFree(slot->buf);  // (synchronises the device: nothing in flight still reads it)
         slot->buf = nullptr;
@@ -1050,6 +1053,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
                 const size_t words = size_t(aug_blocks) * 4 + 1;
                 st = fused_flags_acquire(s, words, &flags, &failures, &epoch);
                 if (st != BSQ_OK) return st;
+                if (!flags) return BSQ_OK;  // (fused_taken stays false)
                 FusedAug fa;
                 fa.chars = fuse->chars;
                 fa.B = B;

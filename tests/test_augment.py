@@ -385,3 +385,61 @@ def test_fused_augment_tokenize_many_launches_two_streams(gpu, bsq, oracle):
         assert bufs[k].cpu().numpy().tobytes() == want_chars.tobytes(), k
         assert outs[k].cpu().numpy().tobytes() == ora.tokenize_packed(want_chars, offs, P, "b", True).tobytes(), k
     assert lib.bsq_fused_wait_failures() == 0
+
+
+@pytest.mark.gpu
+def test_fused_augment_tokenize_more_streams_than_flag_slots(gpu, bsq, oracle):
+    """20 streams: the fused launch keeps flag words for 16 (device, stream) pairs; the others run the two launches -- same results."""
+    import torch
+    from bioseq_amd import blosum, synth
+    B, P = 2000, 128
+    chars, offs = synth.synth_packed(77, B, 5, 126, synth.AA)
+    dof = torch.from_numpy(offs).to(gpu)
+    tok = bsq.Tokenizer("SEB8")
+    ora = oracle.OracleTokenizer("SEB8")
+    ref = torch.from_numpy(chars).to(gpu)
+    blosum.augment_packed(ref, dof, chain_len=1, augment_frac=0.5, seed=5)
+    want_chars = ref.cpu().numpy()
+    want = ora.tokenize_packed(want_chars, offs, P, "b", True)
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(20)]
+    res = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            buf = torch.from_numpy(chars).to(gpu)
+            res.append((buf, blosum.augment_tokenize_packed(tok, buf, dof, P, "b", True, chain_len=1, augment_frac=0.5, seed=5)))
+    torch.cuda.synchronize()
+    for buf, out in res:
+        assert buf.cpu().numpy().tobytes() == want_chars.tobytes() and out.cpu().numpy().tobytes() == want.tobytes()
+
+
+@pytest.mark.gpu
+def test_fused_entry_under_graph_capture_runs_the_two_launches(gpu, bsq, oracle):
+    """A stream under capture cannot take the fused launch (a replayed graph would replay its epoch): the entry point records
+    the two launches instead; capture, two replays == the two calls applied twice."""
+    import torch
+    from bioseq_amd import blosum, synth
+    B, P = 5000, 256
+    chars, offs = synth.synth_packed(31, B, 10, 254, synth.AA)
+    dof = torch.from_numpy(offs).to(gpu)
+    tok = bsq.Tokenizer("SEB8")
+    ora = oracle.OracleTokenizer("SEB8")
+    buf = torch.from_numpy(chars).to(gpu)
+    out = torch.empty((B, P), dtype=torch.int8, device=gpu)
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up outside capture (tables, flag words)
+        blosum.augment_tokenize_packed(tok, torch.from_numpy(chars).to(gpu), dof, P, "b", True, chain_len=1, augment_frac=0.5, seed=8, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        blosum.augment_tokenize_packed(tok, buf, dof, P, "b", True, chain_len=1, augment_frac=0.5, seed=8, out=out)
+    buf.copy_(torch.from_numpy(chars).to(gpu))
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(chars).to(gpu)
+    blosum.augment_packed(ref, dof, chain_len=1, augment_frac=0.5, seed=8)
+    blosum.augment_packed(ref, dof, chain_len=1, augment_frac=0.5, seed=8)
+    want_chars = ref.cpu().numpy()
+    assert buf.cpu().numpy().tobytes() == want_chars.tobytes()
+    assert out.cpu().numpy().tobytes() == ora.tokenize_packed(want_chars, offs, P, "b", True).tobytes()
