@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSQ_ABI_VERSION 3
+#define BSQ_ABI_VERSION 4
 
 typedef int32_t bsq_status;
 enum {
