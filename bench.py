@@ -320,6 +320,17 @@ def main():
             expect = P * n
         if not os.environ.get("BSQ_BENCH_SKIP_SANITY"):
             assert ones == expect, ("one-hot sanity failed", ones, expect)
+    if op == "augment+tokenize":
+        # the step mutated d_chars and wrote the tokens of the MUTATED batch (one launch): a plain tokenise of what is in d_chars
+        # now must give the same matrix, and about half of the sequences must differ from the pristine batch in one residue
+        check = torch.empty_like(out)
+        capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), n, P, int(batch_first), dt_code,
+                                           check.data_ptr(), sh))
+        torch.cuda.synchronize()
+        assert torch.equal(check, out), "augment+tokenize sanity failed: tokens are not those of the mutated characters"
+        changed = int((d_chars != torch.from_numpy(chars).to(d_chars.device)).sum().item())
+        assert 0.4 * n < changed < 0.6 * n, ("augment+tokenize sanity failed: mutations", changed, n)
+        del check
 
     # write-bandwidth yardstick: a plain fill (one 1-KiB store per wave, one aligned 4-KiB chunk per workgroup, blocks in
     # address order) over the same output buffer, in its BEST-KNOWN configuration: 3 resident workgroups per CU (unused
