@@ -73,6 +73,8 @@ def augment_packed(chars, offsets, chain_len=1, augment_frac=1.0, seed=0):
     if chars.dtype != torch.uint8 or offsets.dtype != torch.int64 or not chars.is_contiguous() or not offsets.is_contiguous():
         raise ValueError("chars must be contiguous uint8 and offsets contiguous int64")
     B = offsets.numel() - 1
+    if chars.numel() == 0:
+        return chars  # a batch of empty sequences: nothing to mutate
     with torch.cuda.device(chars.device):
         stream = torch.cuda.current_stream().cuda_stream
         capi.check(_lib.bsq_augment_device(chars.data_ptr(), offsets.data_ptr(), B, int(chain_len), float(augment_frac),
@@ -109,7 +111,7 @@ def augment_tokenize_packed(tokenizer, chars, offsets, padlen, destchar="b", bat
     with torch.cuda.device(chars.device):
         stream = torch.cuda.current_stream().cuda_stream
         capi.check(_lib.bsq_augment_tokenize_device(ctypes.byref(desc), chars.data_ptr(), offsets.data_ptr(), B, int(padlen),
-                                                    int(bool(batch_first)), dt, out.data_ptr(), int(chain_len), float(augment_frac),
+                                                    int(bool(batch_first)), dt, out.data_ptr(), int(chain_len) if chars.numel() else 0, float(augment_frac),
                                                     ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), stream))
     return out
 

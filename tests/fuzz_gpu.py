@@ -65,6 +65,15 @@ def run(budget=120.0, seed=1):
             assert g.dtype == e.dtype and g.shape == e.shape and g.tobytes() == e.tobytes(), "onehot"
             g = tok.onehot_packed(dch, dof, P, d, mask=dm, layout="bcl").cpu().numpy()
             assert g.tobytes() == np.ascontiguousarray(e.transpose(1, 2, 0)).tobytes(), "onehot bcl"
+            if rng.random() < 0.3:  # augmentation + tokens in one call == the two calls (fused launch or not, any shape / type / layout)
+                from bioseq_amd import blosum
+                cl, fr, sd = int(rng.integers(0, 4)), float(rng.choice([0.3, 0.5, 1.0])), int(rng.integers(1 << 30))
+                capi.check(lib.bsq_tuning_set(b"augment_fused", int(rng.integers(0, 2))))
+                a1, a2 = dch.clone(), dch.clone()
+                blosum.augment_packed(a1, dof, cl, fr, sd)
+                t1 = tok.tokenize_packed(a1, dof, P, d, bf, validate=False)
+                t2 = blosum.augment_tokenize_packed(tok, a2, dof, P, d, bf, chain_len=cl, augment_frac=fr, seed=sd)
+                assert torch.equal(a1, a2) and u64(t1.cpu().numpy()).tobytes() == u64(t2.cpu().numpy()).tobytes(), ("augment+tokenize", cl, fr, bf)
             if B * P < 400_000:  # host entry points (list of bytes -> numpy)
                 seqs = synth.unpack(chars, offs)
                 ml = None if mask is None else [mask[offs[i]:offs[i + 1]].copy() for i in range(B)]
@@ -73,7 +82,8 @@ def run(budget=120.0, seed=1):
         except AssertionError as ex:
             raise AssertionError("MISMATCH %s %r" % (ex, desc))
         n += 1
-    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"bcl_path", b"tokenize_tb"):
+    assert lib.bsq_fused_wait_failures() == 0, "a chunk wave of a fused augmentation launch gave up waiting"
+    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"augment_fused", b"bcl_path", b"tokenize_tb"):
         capi.check(lib.bsq_tuning_set(name, 0))
     return n
 
