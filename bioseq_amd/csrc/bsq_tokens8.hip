@@ -394,7 +394,7 @@ template <bool NT, bool FLAGS>
 __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                  uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR, uint32_t magic,
                                                  uint32_t shift, int32_t room, uint32_t packed, const T8Tab &tab, const T8Rules &rules,
-                                                 const uint32_t *flags, uint32_t epoch, uint32_t *wait_failures) {
+                                                 const uint32_t *flags, uint32_t epoch, uint32_t *wait_failures, uint32_t naps = 60) {
     __shared__ __align__(16) uint4 s_rule[4][2][18];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t wave_s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(wave));
@@ -414,12 +414,14 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
         bool ok = true;
         if (static_cast<uint32_t>(lane) <= f1 - f0) {
             ok = false;
-            for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+            for (uint32_t spin = 0; spin < (1u << 18); ++spin) {  // (bounded: ~1 s)
                 if (__hip_atomic_load(flags + f0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
                     ok = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                // ~3.5 us between polls: 8192 resident chunk waves polling every ~60 ns slowed the augmentation's own memory
+                // operations down (cfg5aug 45.2 us; 60 naps: 42.8-43.1; one long nap, then short ones: 44-45 -- profiles/r03/augment_fused_flags_ab.txt)
+                for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(2);
             }
             if (!ok) atomicAdd(wait_failures, 1u);
         }
@@ -591,6 +593,7 @@ struct FusedAug {
     uint32_t *flags;          // aug_blocks * 4 words (one per augmentation wave)
     uint32_t *failures;       // chunk waves that gave up waiting (expected: never)
     uint32_t epoch;
+    uint32_t naps;            // s_sleep(2) per poll of a waiting chunk wave
 };
 template <bool NT, int K>
 __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t *__restrict__ offsets, const uint8_t *chars,
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t
         return;
     }
     tokens_fast_body<NT, true>(blockIdx.x - fa.aug_blocks, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules,
-                               fa.flags, fa.epoch, fa.failures);
+                               fa.flags, fa.epoch, fa.failures, fa.naps);
 }
 
 // k_tokens_pb8_fast: the (P,B) int8 token matrix -- batch_tokenize's DEFAULT layout (batch_first=False,
@@ -1065,6 +1068,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
                 fa.flags = flags;
                 fa.failures = failures;
                 fa.epoch = epoch;
+                fa.naps = 60;
                 const dim3 fgrid(unsigned(aug_blocks + int64_t(grid.x)));
                 if (nt)
                     hipLaunchKernelGGL((k_augment_tokens_fused<true, 4>), fgrid, dim3(kThreads), 0, s, offsets, chars, c.out, uint32_t(c.nchunks),
