@@ -613,8 +613,9 @@ __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t
                                fa.flags, fa.epoch, fa.failures, fa.naps);
 }
 
-// k_tokens_pb8_fast: the (P,B) int8 token matrix -- batch_tokenize's DEFAULT layout (batch_first=False,
-// tokenize.cpp:82-98) -- without a mask, rows (pitch) and output 16-byte aligned.  Round 3.
+// k_tokens_pb8_fast: the (P,B) token matrix -- batch_tokenize's DEFAULT layout (batch_first=False, tokenize.cpp:82-98) --
+// of 1-, 2- and 8-byte elements without a mask (SZ / FLT below; UA: rows that are only element-aligned), and the raw-id pass of
+// the two-pass one-hot.  Round 3.
 // k_tokens_raw (bsq_kernels.hip) spends ~40 vector and ~10.6 LDS instructions per word of four tokens (byte lookups
 // in an LDS table, four transposed ds_write_b8 per word, spans staged through LDS) and sits at 0.59 of the HBM roof on
 // cfg2's shape, bound by instruction issue in BOTH pipes (profiles/r02/cfg2sf_sq_tcc_counters.txt).  Here, on a tile of
@@ -630,7 +631,8 @@ __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t
 //     with position 16 piece + 4 k + a of the row's four sequences -- ONE ds_write_b32 per word;
 //   * LDS tile: position p lives in physical row 4 (p % 16) + p / 16, row stride TB + 8 bytes (2 banks): the 32 writes of a
 //     half-wave fall on 32 banks; the rows leave as 8-byte LDS reads -> 16-byte stores of TB-byte segments.
-// XCD-aware order: block b -> class b % 8 walks its own sequence tiles, the position tiles of a sequence tile back to back.
+// XCD-aware order: block b -> class b % 8 walks its own sequence tiles, the position tiles of a sequence tile back to back
+// (rows that are not 64-byte aligned, and 4- / 8-byte elements: XCD-contiguous ranges, sequence tile fastest -- see the kernel).
 struct T8Lut {
     uint32_t w[64];  // LK = 0: token VALUE of every byte (unmapped: none_v)
 };
