@@ -968,10 +968,23 @@ static bsq_status fused_flags_acquire(hipStream_t s, size_t words, uint32_t **bu
         if (slot->buf) (void)hipFree(slot->buf);  // (synchronises the device: nothing in flight still reads it)
         slot->buf = nullptr;
         const size_t cap = words < 4096 ? 4096 : words;
+        // (an allocation that is refused -- e.g. another thread's stream capture in global mode -- is not an error: two launches then)
         e = hipMalloc(reinterpret_cast<void **>(&slot->buf), cap * sizeof(uint32_t));
-        if (e != hipSuccess) return set_hip_error("hipMalloc(fused flags)", e);
-        e = hipMemset(slot->buf, 0, cap * sizeof(uint32_t));
-        if (e != hipSuccess) return set_hip_error("hipMemset(fused flags)", e);
+        if (e == hipSuccess) {
+            e = hipMemsetAsync(slot->buf, 0, cap * sizeof(uint32_t), s);  // on the launch's stream: ordered before its first use
+            if (e != hipSuccess) {
+                (void)hipFree(slot->buf);
+                slot->buf = nullptr;
+            }
+        } else {
+            slot->buf = nullptr;
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            slot->words = 0;
+            *buf = nullptr;
+            return BSQ_OK;
+        }
         slot->dev = dev;
         slot->stream = s;
         slot->words = cap;
