@@ -108,6 +108,7 @@ uint32_t fused_wait_failures();                          // bsq_tokens8.hip (dia
 // the (P,B) token matrix of any element type (pitch = elements between two position rows), no mask, 16-byte aligned rows
 bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out, int64_t pitch, bsq_dtype t = BSQ_I8);
 bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
-                             int64_t pitch, hipStream_t stream, bool raw = false, bsq_dtype t = BSQ_I8);
+                             int64_t pitch, hipStream_t stream, bool raw = false, bsq_dtype t = BSQ_I8,
+                             const struct FusedAugRequest *fuse = nullptr, bool *fused_taken = nullptr);
 
 }  // namespace bsq_internal

@@ -2553,6 +2553,15 @@ bsq_status bsq_augment_tokenize_device(const bsq_desc *d, uint8_t *chars, const 
         if (st != BSQ_OK) return st;
         if (taken) return BSQ_OK;
     }
+    // the (P,B) int8 matrix with 16-byte aligned rows: the fused form of k_tokens_pb8_fast (same conditions as bsq_tokenize_device)
+    if (chain_len > 0 && frac > 0.0 && chars && !batch_first && t == BSQ_I8 && k.C <= 250 && B < (int64_t(1) << 31) - 1024 && P <= kMaxTiledP &&
+        bsq_internal::tuning().tokenize_path != 1 && bsq_internal::tokens_pb8_applicable(d, B, P, out, B, t)) {
+        bsq_internal::FusedAugRequest fr{chars, chain_len, frac, seed};
+        bool taken = false;
+        st = bsq_internal::launch_tokens_pb8(d, chars, offsets, B, P, out, B, s, false, t, &fr, &taken);
+        if (st != BSQ_OK) return st;
+        if (taken) return BSQ_OK;
+    }
     st = bsq_augment_device(chars, offsets, B, chain_len, frac, seed, hip_stream);
     if (st != BSQ_OK) return st;
     return bsq_tokenize_device(d, chars, offsets, B, P, batch_first, t, out, hip_stream);

@@ -670,18 +670,33 @@ __device__ __forceinline__ uint4 widen_tokens(const uint8_t *src) {
 // UA: rows (pitch * SZ bytes) or the output are only element-aligned -- any batch size.  The 16-byte stores go out unaligned
 // (gfx950 splits them in hardware), the pieces that cross the end of a row as single elements, and every XCD walks its own
 // CONTIGUOUS range of sequence tiles: the memory sectors that two neighbouring tiles share are then written through ONE L2.
-template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false, bool UA = false>
+// FUSED (the (P,B) side of bsq_augment_tokenize_device; see k_augment_tokens_fused): the first fa.aug_blocks workgroups of the launch
+// are the BLOSUM62 augmentation; a tile waits for the flags of the four augmentation waves that own its 256 sequences and reads its
+// characters with agent-scope loads.
+template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false, bool UA = false, bool FUSED = false>
 __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                               uint8_t *__restrict__ out, int64_t pitch, uint32_t B, uint32_t P,
                                                               uint32_t ntb, uint32_t ntt, uint32_t magic, uint32_t shift, int32_t room,
-                                                              uint32_t packed, T8Tab tab, T8Rules rules, T8Lut lut) {
+                                                              uint32_t packed, T8Tab tab, T8Rules rules, T8Lut lut, FusedAug fa) {
     constexpr int TT = 64, STRIDE = TB + 8, PASSES = TB / 64;
     static_assert(TB % 64 == 0 && (STRIDE / 4) % 32 == 2, "tile shape");
     __shared__ __align__(16) uint4 s_rule[2][18];
     __shared__ __align__(16) uint8_t s_lut[LK == 0 ? 256 : 16];
     __shared__ __align__(16) uint8_t s_t[TT * STRIDE];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t cls = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    uint32_t vblock = blockIdx.x;
+    if constexpr (FUSED) {
+        static_assert(!FUSED || (TB == 256 && SZ == 1 && !UA), "fused form: aligned int8 tiles of 256 sequences");
+        if (vblock < fa.aug_blocks) {  // the augmentation role (see k_augment_tokens_fused)
+            bsq_aug::augment_groups_body<4, true>(vblock, fa.chars, offsets, fa.B, fa.chain_len, fa.frac, fa.seed, fa.tab);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((threadIdx.x & 63) == 0)
+                __hip_atomic_store(fa.flags + vblock * 4u + (threadIdx.x >> 6), fa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        vblock -= fa.aug_blocks;
+    }
+    const uint32_t cls = vblock & 7u, i = vblock >> 3;
     const uint32_t quo = (magic ? __umulhi(i, magic) : i) >> shift;  // i / ntt (magic 0: a power of two); contiguous form: i / per
     uint32_t tt = i - quo * ntt, tb = quo * 8u + cls;
     if (UA || (packed & 4u)) {
@@ -725,14 +740,32 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     }
     __syncthreads();
 
+    if constexpr (FUSED) {  // the tile's 256 sequences belong to the augmentation waves 4 tb .. 4 tb + 3 (bounded spin; see tokens_fast_body)
+        if (lane < 4) {
+            bool ok = false;
+            for (uint32_t spin = 0; spin < (1u << 18); ++spin) {
+                if (__hip_atomic_load(fa.flags + tb * 4u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fa.epoch) {
+                    ok = true;
+                    break;
+                }
+                for (uint32_t z = 0; z < fa.naps; ++z) __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) atomicAdd(fa.failures, 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     // ---- the characters: the piece of every pass in flight together ----
     const int pc = (la & 1) ? 3 - lb : lb;  // the lane's piece: reversed in odd a, so that row_half_mirror pairs a with a ^ 1 on the SAME piece
     const int32_t j0 = t0 + 16 * pc - static_cast<int32_t>(bos);  // character index of the piece's first byte (>= -1)
     u32x4u cw[PASSES];
     int32_t Lr[PASSES];
     bool slow_any = false;
+    const uint8_t *fa_addr[PASSES];  // FUSED only
+    bool fa_fast[PASSES];
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
+        fa_addr[ps] = nullptr;
+        fa_fast[ps] = false;
         const uint32_t len = static_cast<uint32_t>(o1[ps] - o0[ps]);
         Lr[ps] = static_cast<int32_t>(len > static_cast<uint32_t>(room) ? static_cast<uint32_t>(room) : len);
         const int64_t a = o0[ps] + j0;
@@ -740,7 +773,30 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
         const bool fast = need && a >= 0 && a + 16 <= total_chars;  // never read outside the buffer
         slow_any |= need && !fast;
         cw[ps] = u32x4u{0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
-        if (fast) cw[ps] = *reinterpret_cast<const u32x4u *>(chars + a);
+        if constexpr (!FUSED) {
+            if (fast) cw[ps] = *reinterpret_cast<const u32x4u *>(chars + a);
+        } else {
+            fa_addr[ps] = fast ? chars + a : reinterpret_cast<const uint8_t *>(offsets);  // (a lane without characters reads the head of the offsets array)
+            fa_fast[ps] = fast;
+        }
+    }
+    if constexpr (FUSED) {
+        // agent-scope loads (sc1): a line in this XCD's L2 / this CU's L1 may predate the mutation of a neighbouring sequence group.
+        // One asm block with its own wait: the compiler must not touch the registers in between.
+        static_assert(!FUSED || PASSES == 4, "four pieces per lane");
+        u32x4u f0, f1, f2, f3;
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                     "global_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\t"
+                     "global_load_dwordx4 %3, %7, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)
+                     : "v"(fa_addr[0]), "v"(fa_addr[1]), "v"(fa_addr[2]), "v"(fa_addr[3])
+                     : "memory");
+        if (fa_fast[0]) cw[0] = f0;
+        if (fa_fast[1]) cw[1] = f1;
+        if (fa_fast[2]) cw[2] = f2;
+        if (fa_fast[3]) cw[3] = f3;
     }
     if (__builtin_amdgcn_ballot_w64(slow_any) != 0) {  // first / last bytes of the buffer (a handful of lanes per launch)
 #pragma unroll
@@ -750,7 +806,8 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
                 uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll 1
                 for (int k = 0; k < 16; ++k)
-                    if (j0 + k >= 0 && j0 + k < Lr[ps]) w[k >> 2] |= static_cast<uint32_t>(chars[a + k]) << (8 * (k & 3));
+                    if (j0 + k >= 0 && j0 + k < Lr[ps])
+                        w[k >> 2] |= static_cast<uint32_t>(FUSED ? __hip_atomic_load(chars + a + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : chars[a + k]) << (8 * (k & 3));
                 cw[ps] = u32x4u{w[0], w[1], w[2], w[3]};
             }
         }
@@ -1137,7 +1194,8 @@ bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
 }
 
 bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
-                             int64_t pitch, hipStream_t s, bool raw, bsq_dtype t) {
+                             int64_t pitch, hipStream_t s, bool raw, bsq_dtype t, const FusedAugRequest *fuse, bool *fused_taken) {
+    if (fused_taken) *fused_taken = false;
     const uint32_t none_v = raw ? 0xFFu : 0u;
     if (raw && t != BSQ_I8) return set_error(BSQ_ERR_INVALID_ARG, "raw ids are bytes");
     T8Tab tab;
@@ -1179,10 +1237,50 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     uint32_t magic = 0, shift = 0, pow2 = 0;
     div_constants((contig || ua) ? uint32_t((ntb + 7) / 8) : uint32_t(ntt), &magic, &shift, &pow2);  // the divisor of the block index
     if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)
+    FusedAug fa = {};
+    if (fuse) {  // the augmentation in the same launch (aligned int8 matrix, not under capture); else NOTHING is launched here
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        const int64_t aug_blocks = ((B + 255) / 256 + 7) / 8 * 8;
+        if (!fused_taken || raw || ua || t != BSQ_I8 || !nt || tuning().augment_fused == 1 || cap != hipStreamCaptureStatusNone ||
+            aug_blocks + blocks >= (int64_t(1) << 31))
+            return BSQ_OK;
+        const void *atab = nullptr;
+        bsq_status st = augment_device_table(&atab);
+        if (st != BSQ_OK) return st;
+        uint32_t *flags = nullptr, *failures = nullptr, epoch = 0;
+        st = fused_flags_acquire(s, size_t(aug_blocks) * 4 + 1, &flags, &failures, &epoch);
+        if (st != BSQ_OK) return st;
+        if (!flags) return BSQ_OK;
+        fa.chars = fuse->chars;
+        fa.B = B;
+        fa.tab = static_cast<const bsq_aug::AugTable *>(atab);
+        fa.frac = fuse->frac;
+        fa.seed = fuse->seed;
+        fa.chain_len = fuse->chain_len;
+        fa.aug_blocks = uint32_t(aug_blocks);
+        fa.flags = flags;
+        fa.failures = failures;
+        fa.epoch = epoch;
+        fa.naps = 60;
+        const dim3 fgrid(unsigned(aug_blocks + blocks));
+        if (lk == 2)
+            hipLaunchKernelGGL((k_tokens_pb8_fast<true, 256, 1, 1, false, false, true>), fgrid, dim3(kThreads), 0, s, offsets, chars,
+                               static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift, room,
+                               packed, tab, rules, lut, fa);
+        else
+            hipLaunchKernelGGL((k_tokens_pb8_fast<true, 256, 0, 1, false, false, true>), fgrid, dim3(kThreads), 0, s, offsets, chars,
+                               static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift, room,
+                               packed, tab, rules, lut, fa);
+        const hipError_t ef = hipGetLastError();
+        if (ef != hipSuccess) return set_hip_error("k_tokens_pb8_fast<fused>", ef);
+        *fused_taken = true;
+        return BSQ_OK;
+    }
 #define BSQ_PB8U(NTV, LKV, SZV, FLTV, UAV)                                                                                             \
     hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, 256, LKV, SZV, FLTV, UAV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,  \
                        static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift,    \
-                       room, packed, tab, rules, lut)
+                       room, packed, tab, rules, lut, fa)
 #define BSQ_PB8(NTV, LKV, SZV, FLTV)                                       \
     do {                                                                   \
         if constexpr (SZV <= 2 && !FLTV) {                                 \

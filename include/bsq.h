@@ -183,8 +183,8 @@ bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B,
                               uint64_t seed, void *hip_stream);
 /* bsq_augment_tokenize_device: bsq_augment_device followed by bsq_tokenize_device on the same packed batch -- what the reference's
  * loaders do per item (bioseq/loaders.py:83-84, :102-103: augment_seq, then batch_tokenize) -- with exactly their results
- * (`chars` mutated in place, `out` the token matrix of the mutated batch).  For (B,P) int8 matrices that the fast token kernel
- * takes it is ONE launch (the augmentation's workgroups run ahead of the token workgroups, which wait for their rows);
+ * (`chars` mutated in place, `out` the token matrix of the mutated batch).  For (B,P) and aligned (P,B) int8 matrices that the fast
+ * token kernels take it is ONE launch (the augmentation's workgroups run ahead of the token workgroups, which wait for their rows);
  * every other shape, and a stream under graph capture, runs the two launches. */
 bsq_status bsq_augment_tokenize_device(const bsq_desc *d, uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
                                        int32_t batch_first, bsq_dtype t, void *out, int32_t chain_len, double frac,
