@@ -56,6 +56,7 @@ def load():
         "bsq_tuning_get": (i32, [ctypes.c_char_p]),
         "bsq_host_upload_bytes": (ctypes.c_uint64, []),
         "bsq_fused_wait_failures": (ctypes.c_uint32, []),
+        "bsq_blosum62_accept_thresholds": (i32, [vp]),
         "bsq_num_keys": (i32, []),
         "bsq_key_name": (ctypes.c_char_p, [i32]),
         "bsq_lut_get": (i32, [ctypes.c_char_p, vp, ctypes.POINTER(i32)]),

@@ -68,6 +68,15 @@ void make_normrows(double out[kRows * kCols]) {
     }
 }
 
+// The position of a residue with self-probability p_self is accepted iff double(lo32) * 2^-32 < 1.0 - p_self (the twin's test).
+// Both sides are exact doubles (lo32 < 2^32, a power-of-two scaling), so with t = 1.0 - p_self:
+//   lo * 2^-32 < t  <=>  lo < t * 2^32  <=>  lo <= ceil(t * 2^32) - 1      (t > 0 always)
+// -- one integer compare against a per-row constant instead of a convert, a multiply, a subtract and a compare in FP64.
+uint32_t accept_threshold(double pself) {
+    const double c = std::ceil(std::ldexp(1.0 - pself, 32));
+    return c >= 4294967296.0 ? 0xFFFFFFFFu : static_cast<uint32_t>(static_cast<uint64_t>(c) - 1);
+}
+
 
 #ifdef BSQ_LABS  // round-1 form (knob augment_mode 1): kept for A/B runs in diagnostic builds only
 // One mutation = the reference's loop `repeat { idx = choice(L); new = choice(letters, p = row(seq[idx])) } until
@@ -161,10 +170,7 @@ bsq_status device_table(AugTable **out) {
                 h.cdf[r][c] = acc;
             }
             h.self[r] = r < kCols ? nr[r * kCols + r] : 0.0;
-            // lo * 2^-32 < t  <=>  lo < t * 2^32 (exact: scaling by a power of two)  <=>  lo <= ceil(t * 2^32) - 1
-            const double t32 = std::ldexp(1.0 - h.self[r], 32);
-            const double c = std::ceil(t32);
-            h.accept_le[r] = c >= 4294967296.0 ? 0xFFFFFFFFu : static_cast<uint32_t>(static_cast<uint64_t>(c) - 1);  // (t > 0 always)
+            h.accept_le[r] = accept_threshold(h.self[r]);
         }
         h.pad_[0] = h.pad_[1] = h.pad_[2] = h.pad_[3] = 0;
         std::memset(h.row_of, kRows - 1, sizeof(h.row_of));
@@ -195,6 +201,14 @@ bsq_status augment_device_table(const void **table) {
 }  // namespace bsq_internal
 
 extern "C" {
+
+bsq_status bsq_blosum62_accept_thresholds(uint32_t *out21) {
+    if (!out21) return BSQ_ERR_INVALID_ARG;
+    double nr[kRows * kCols];
+    make_normrows(nr);
+    for (int r = 0; r < kRows; ++r) out21[r] = accept_threshold(r < kCols ? nr[r * kCols + r] : 0.0);
+    return BSQ_OK;
+}
 
 bsq_status bsq_blosum62_normrows(double *out21x20) {
     if (!out21x20) return BSQ_ERR_INVALID_ARG;

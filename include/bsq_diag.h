@@ -24,6 +24,9 @@ uint64_t bsq_host_upload_bytes(void);
 /* chunk waves of fused augmentation + token launches (bsq_augment_tokenize_device) that gave up waiting for their rows'
  * augmentation -- expected: 0, ever; synchronises the device */
 uint32_t bsq_fused_wait_failures(void);
+/* the augmentation kernel's integer acceptance thresholds (row r of normrows: a position is accepted iff lo32 <= out21[r]);
+ * tests check them against the floating-point test of the numpy twin at every boundary */
+bsq_status bsq_blosum62_accept_thresholds(uint32_t *out21);
 
 /* Streaming fill of nbytes (multiple of 16, 16-byte aligned) with a 32-bit pattern: the
  * write-bandwidth yardstick bench.py reports next to the encode kernels. */

@@ -5,6 +5,8 @@ augment_frac) and reproduces normrows statistically (chi-square)."""
 import hashlib
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -443,3 +445,18 @@ def test_fused_entry_under_graph_capture_runs_the_two_launches(gpu, bsq, oracle)
     want_chars = ref.cpu().numpy()
     assert buf.cpu().numpy().tobytes() == want_chars.tobytes()
     assert out.cpu().numpy().tobytes() == ora.tokenize_packed(want_chars, offs, P, "b", True).tobytes()
+
+
+def test_integer_acceptance_thresholds_equal_the_twins_float_test():
+    """The kernel accepts a position iff lo32 <= threshold[row]; the twin (and the law) iff lo32 * 2**-32 < 1 - p_self.  Same truth
+    value for every 32-bit word: checked at and around every row's boundary and at the extremes (CPU, no GPU needed)."""
+    from bioseq_amd import blosum, capi
+    lib = capi.load()
+    thr = (ctypes.c_uint32 * 21)()
+    capi.check(lib.bsq_blosum62_accept_thresholds(thr))
+    for row in range(21):
+        pself = float(blosum.normrows[row, row]) if row < 20 else 0.0
+        t = int(thr[row])
+        probes = {0, 1, 2 ** 31, 2 ** 32 - 2, 2 ** 32 - 1} | {min(max(t + d, 0), 2 ** 32 - 1) for d in range(-3, 4)}
+        for lo in probes:
+            assert (lo <= t) == (lo * 2.0 ** -32 < 1.0 - pself), (row, lo, t)
