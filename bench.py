@@ -570,9 +570,12 @@ def main():
             res["sustained"] = sustained
         if op == "augment+tokenize":
             # the one-launch form: chunk waves that gave up waiting for their rows' augmentation (expected: 0; then the output is wrong)
-            res["fused_wait_failures"] = int(lib.bsq_fused_wait_failures())
+            torch.cuda.synchronize()
+            nfail = ctypes.c_uint32(0)
+            lib.bsq_fused_status(ctypes.byref(nfail))
+            res["fused_wait_failures"] = int(nfail.value)
             if res["fused_wait_failures"]:
-                raise SystemExit("bsq_augment_tokenize_device: %d chunk waves gave up waiting" % res["fused_wait_failures"])
+                raise SystemExit("bsq_augment_tokenize_device: %d token waves gave up waiting" % res["fused_wait_failures"])
         if gather_info is not None:
             res["gather"] = gather_info
         if world == 1 and not args.no_e2e and op in ("onehot", "tokenize"):

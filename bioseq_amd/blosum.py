@@ -82,13 +82,29 @@ def augment_packed(chars, offsets, chain_len=1, augment_frac=1.0, seed=0):
     return chars
 
 
+def check_fused(synchronize=False):
+    """Raise RuntimeError if a token wave of a one-launch `augment_tokenize_packed` ever gave up waiting for its rows'
+    augmentation (its part of the output is poisoned with 0xFF then; never observed -- see include/bsq.h).  Reads host memory
+    only; covers the launches that have completed, so call it after a synchronisation, or pass `synchronize=True`.  The error
+    is sticky: every later `augment_tokenize_packed` raises it too, until `clear_fused_error()`."""
+    if synchronize:
+        import torch
+        torch.cuda.synchronize()
+    capi.check(_lib.bsq_fused_status(None))
+
+
+def clear_fused_error():
+    _lib.bsq_fused_status_clear()
+
+
 def augment_tokenize_packed(tokenizer, chars, offsets, padlen, destchar="b", batch_first=True, chain_len=1, augment_frac=1.0,
                             seed=0, out=None):
     """`augment_packed` followed by `tokenizer.tokenize_packed` -- what the reference's loaders do per item
     (bioseq/loaders.py:83-84: `augment_seq`, then `batch_tokenize`) -- with exactly their results: `chars` is mutated in
     place, the token matrix of the mutated batch is returned.  For `(B,P)` int8 matrices of the fast token kernel it is ONE
     launch (`bsq_augment_tokenize_device`); other shapes run the two launches.  Sequences longer than
-    padlen - bos - eos must have been rejected by the caller (as `tokenize_packed(validate=True)` does)."""
+    padlen - bos - eos must have been rejected by the caller (as `tokenize_packed(validate=True)` does).
+    Raises RuntimeError (here, at the next call, or from `check_fused`) if an earlier one-launch call failed inside the kernel."""
     import torch
     if not (chars.is_cuda and offsets.is_cuda):
         raise ValueError("augment_tokenize_packed works on device tensors (use .to('cuda'))")
@@ -116,4 +132,5 @@ def augment_tokenize_packed(tokenizer, chars, offsets, padlen, destchar="b", bat
     return out
 
 
-__all__ = ["aa_array", "substitute", "normrows", "probdict", "augment_seq", "augment_packed", "augment_tokenize_packed"]
+__all__ = ["aa_array", "substitute", "normrows", "probdict", "augment_seq", "augment_packed", "augment_tokenize_packed", "check_fused",
+           "clear_fused_error"]

@@ -22,7 +22,6 @@ LIB = os.path.join(HERE, "libbsq_hip.so")
 EXT = os.path.join(HERE, "cbioseq" + sysconfig.get_config_var("EXT_SUFFIX"))
 
 LIB_SRCS = ["bsq_kernels.hip", "bsq_tokens8.hip", "bsq_decode.hip", "bsq_augment.hip", "bsq_gather.hip", "bsq_diag.hip", "bsq_host.cpp", "bsq_alphabet.cpp", "bsq_fastx.cpp"]
-LIB_DEPS = LIB_SRCS + ["bsq_internal.h", "bsq_device.h"]
 EXT_SRCS = ["cbioseq_module.cpp"]
 
 
@@ -46,7 +45,10 @@ def build_lib(force=False):
     """One object per source under csrc/_obj/ (compiled in parallel, rebuilt only when the source or a header
     changed), then one link."""
     from concurrent.futures import ThreadPoolExecutor
-    headers = [os.path.join(CSRC, f) for f in LIB_DEPS if f.endswith(".h")] + [os.path.join(INCLUDE, "bsq.h"), os.path.join(INCLUDE, "bsq_diag.h")]
+    # every header of csrc/ and include/ is a dependency of every object (a handful of files: an exact depfile graph would
+    # save nothing, and a header missing from a hand-kept list once left two kernels disagreeing about a table layout)
+    import glob
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h")))
     extra = os.environ.get("BSQ_EXTRA_HIPCC_FLAGS", "").split()
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
@@ -75,7 +77,8 @@ def build_lib(force=False):
 
 def build_ext(force=False):
     import pybind11
-    deps = [os.path.join(CSRC, f) for f in EXT_SRCS] + [os.path.join(INCLUDE, "bsq.h"), LIB]
+    import glob
+    deps = [os.path.join(CSRC, f) for f in EXT_SRCS] + sorted(glob.glob(os.path.join(INCLUDE, "*.h"))) + [LIB]
     if force or _newer(EXT, deps):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra",
               "-I" + INCLUDE, "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],

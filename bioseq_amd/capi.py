@@ -55,7 +55,8 @@ def load():
         "bsq_tuning_set": (i32, [ctypes.c_char_p, i32]),
         "bsq_tuning_get": (i32, [ctypes.c_char_p]),
         "bsq_host_upload_bytes": (ctypes.c_uint64, []),
-        "bsq_fused_wait_failures": (ctypes.c_uint32, []),
+        "bsq_fused_status": (i32, [ctypes.POINTER(ctypes.c_uint32)]),
+        "bsq_fused_status_clear": (None, []),
         "bsq_blosum62_accept_thresholds": (i32, [vp]),
         "bsq_num_keys": (i32, []),
         "bsq_key_name": (ctypes.c_char_p, [i32]),

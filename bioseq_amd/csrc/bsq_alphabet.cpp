@@ -94,6 +94,7 @@ const char *bsq_strerror(bsq_status s) {
     case BSQ_ERR_NO_DEVICE: return "no HIP device available (bioseq_amd has no CPU fallback)";
     case BSQ_ERR_HIP: return "HIP runtime error";
     case BSQ_ERR_ALLOC: return "allocation failed";
+    case BSQ_ERR_FUSED_WAIT: return "a fused augmentation + token launch gave up waiting inside the kernel (its output is poisoned with 0xFF)";
     default: return "unknown bsq_status";
     }
 }

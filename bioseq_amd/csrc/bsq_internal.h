@@ -58,6 +58,8 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //                         for 4-byte elements (automatic: 1-, 2- and 8-byte elements), 3: only when rows and output are 16-byte aligned;
 //                         its lookup follows tokens8_lookup
 //   augment_fused         1: bsq_augment_tokenize_device never fuses its two launches
+//   fused_spins           fault injection (tests): polls of a fused launch's token wave before it gives up, poisons its chunk and reports
+//                         (0: 2^18, about a second).  A wave that gives up is an ERROR of the call -- never a silent result
 //   augment_k             attempts per lane and round of the augmentation kernel: 0 automatic (4), 1 (the round-2 form), 2
 // The knobs are ONE plain struct, published as an immutable snapshot: a launcher reads it with a single atomic load
 // (tuning()), never a name lookup under a mutex.  bsq_tuning_set() copies the current snapshot, changes one field and
@@ -68,7 +70,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
     X(nt_stores, 1) X(onehot_tb, 0) X(tile_order, 0) X(fill_mode, 0) X(onehot_path, 0) X(expand_pad, 0) X(tokenize_path, 0)   \
     X(fill_pad, 0) X(chunks_pad, 0) X(host_copy_threads, 0) X(tokenize_pad, 0) X(expand_slots, 0) X(tile_group, 0)             \
     X(bcl_path, 0) X(bcl_pad, 0) X(raw_mode, 0) X(workspace_cache, 0) X(tokens8, 0) X(tokens8_fast, 0) X(tokens8_lookup, 0)    \
-    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0)                                                \
+    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0)                                               \
     L(chunks_cpw, 0) L(tokenize_nch, 0) L(expand_mode, 0) L(xcd_claim, 0) L(chunk_math, 0) L(tokens8_abl, 0) L(augment_mode, 0)
 struct Tuning {
 #define BSQ_KNOB_FIELD(name, def) int32_t name = def;
@@ -104,11 +106,11 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
                              void *out, hipStream_t stream, bool raw = false, const uint8_t *mask = nullptr,
                              const FusedAugRequest *fuse = nullptr, bool *fused_taken = nullptr);
 bsq_status augment_device_table(const void **table);  // bsq_augment.hip: the AugTable of the current device
-uint32_t fused_wait_failures();                          // bsq_tokens8.hip (diagnostic; synchronises)
+uint32_t fused_failures();                              // bsq_tokens8.hip: token waves of fused launches that gave up waiting so far (sticky)
+void fused_failures_clear();
 // the (P,B) token matrix of any element type (pitch = elements between two position rows), no mask, 16-byte aligned rows
 bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out, int64_t pitch, bsq_dtype t = BSQ_I8);
 bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
-                             int64_t pitch, hipStream_t stream, bool raw = false, bsq_dtype t = BSQ_I8,
-                             const struct FusedAugRequest *fuse = nullptr, bool *fused_taken = nullptr);
+                             int64_t pitch, hipStream_t stream, bool raw = false, bsq_dtype t = BSQ_I8);
 
 }  // namespace bsq_internal

@@ -2542,6 +2542,10 @@ bsq_status bsq_augment_tokenize_device(const bsq_desc *d, uint8_t *chars, const 
     bsq_status st = fill_common(k, d, chars, offsets, nullptr, B, P, out);
     if (st != BSQ_OK) return st;
     if (chain_len < 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bad augment arguments");
+    // a token wave of an EARLIER fused launch gave up waiting for its rows' augmentation (its chunk is poisoned): sticky until
+    // bsq_fused_status_clear() -- no later call succeeds silently on top of it
+    if (bsq_internal::fused_failures() != 0)
+        return bsq_internal::set_error(BSQ_ERR_FUSED_WAIT, "an earlier fused augmentation + token launch gave up waiting (output poisoned); see bsq_fused_status()");
     if (B == 0) return BSQ_OK;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     // one launch where bsq_tokenize_device would take the fast form of k_tokens_bp8 (same conditions as there)
@@ -2553,21 +2557,19 @@ bsq_status bsq_augment_tokenize_device(const bsq_desc *d, uint8_t *chars, const 
         if (st != BSQ_OK) return st;
         if (taken) return BSQ_OK;
     }
-    // the (P,B) int8 matrix with 16-byte aligned rows: the fused form of k_tokens_pb8_fast (same conditions as bsq_tokenize_device)
-    if (chain_len > 0 && frac > 0.0 && chars && !batch_first && t == BSQ_I8 && k.C <= 250 && B < (int64_t(1) << 31) - 1024 && P <= kMaxTiledP &&
-        bsq_internal::tuning().tokenize_path != 1 && bsq_internal::tokens_pb8_applicable(d, B, P, out, B, t)) {
-        bsq_internal::FusedAugRequest fr{chars, chain_len, frac, seed};
-        bool taken = false;
-        st = bsq_internal::launch_tokens_pb8(d, chars, offsets, B, P, out, B, s, false, t, &fr, &taken);
-        if (st != BSQ_OK) return st;
-        if (taken) return BSQ_OK;
-    }
+    // every other shape and layout (the (P,B) matrix fused the same way gained 2.6 %: round 3; dropped with its coherent loads in round 4)
     st = bsq_augment_device(chars, offsets, B, chain_len, frac, seed, hip_stream);
     if (st != BSQ_OK) return st;
     return bsq_tokenize_device(d, chars, offsets, B, P, batch_first, t, out, hip_stream);
 }
 
-uint32_t bsq_fused_wait_failures(void) { return bsq_internal::fused_wait_failures(); }
+bsq_status bsq_fused_status(uint32_t *failures) {
+    const uint32_t n = bsq_internal::fused_failures();
+    if (failures) *failures = n;
+    if (n != 0) return bsq_internal::set_error(BSQ_ERR_FUSED_WAIT, "a fused augmentation + token launch gave up waiting for its rows' augmentation (output poisoned)");
+    return BSQ_OK;
+}
+void bsq_fused_status_clear(void) { bsq_internal::fused_failures_clear(); }
 
 bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                        int64_t B, int64_t P, int32_t batch_first, bsq_dtype t, void *out,

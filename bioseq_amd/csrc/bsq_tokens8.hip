@@ -20,6 +20,7 @@
 
 #include <climits>
 #include <cstdint>
+#include <cstring>
 #include <mutex>
 
 #include "bsq.h"
@@ -390,21 +391,34 @@ struct T8Rules {
 };
 // (the body as a device function of a VIRTUAL block index: the fused augmentation + token launch below runs it behind its
 //  augmentation blocks; FLAGS: wait for the augmentation of the chunk's rows first, see k_augment_tokens_fused)
+struct FusedWait {            // what a token wave of the fused launch needs from the augmentation role
+    const uint32_t *flags;    // one word per augmentation wave (64 sequences): the launch's epoch once their characters are visible
+    uint32_t *failures;       // host-mapped, sticky: token waves that gave up waiting (their chunk is poisoned; the API reports it)
+    uint32_t epoch;
+    uint32_t spins, naps;     // polls before a wave gives up; s_sleep(2) per poll
+};
 template <bool NT, bool FLAGS>
 __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                  uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR, uint32_t magic,
                                                  uint32_t shift, int32_t room, uint32_t packed, const T8Tab &tab, const T8Rules &rules,
-                                                 const uint32_t *flags, uint32_t epoch, uint32_t *wait_failures, uint32_t naps = 60) {
+                                                 const FusedWait &fw) {
     __shared__ __align__(16) uint4 s_rule[4][2][18];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t wave_s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(wave));
     const uint32_t k0 = (vblock & 7u) + 8u * ((vblock >> 3) * 4u + wave_s);  // class = block % 8 (XCD-pinned)
     if (k0 >= nchunks) return;
     if constexpr (FLAGS) {
-        // the rows of this chunk: bc .. bc + nr (nr <= 32).  Their sequences were augmented by the waves (row / 64) of the
+        // The rows of this chunk: bc .. bc + nr (nr <= 32).  Their sequences were augmented by the waves (row / 64) of the
         // augmentation blocks, which are dispatched BEFORE every token block (lower block indices: the dispatcher hands blocks out
-        // in order, as the decoupled look-back scans of rocPRIM rely on) and never wait for anything.  A bounded spin, so that a
-        // broken assumption shows up as a counted failure and wrong output, not as a hung device.
+        // in order, as the decoupled look-back scans of rocPRIM rely on) and never wait for anything.  Protocol (hand-rolled release /
+        // acquire over exactly the data it orders): an augmentation wave stores its mutated characters at AGENT scope (written
+        // through to the memory side, where the XCDs agree), waits for their acknowledgement (s_waitcnt vmcnt(0)), then stores the
+        // launch's epoch into its flag; a token wave loads the flag at agent scope until it reads the epoch and only THEN issues its
+        // character loads, also at agent scope (sc1: not served from an L2 / L1 line that predates the mutation).  A cache-wide
+        // release / acquire pair (buffer_wbl2 / buffer_inv) does the same for ALL memory and took 326 us instead of 42.
+        // The wait is BOUNDED, and a wave that gives up never encodes stale characters under BSQ_OK: it
+        // POISONS its chunk -- every byte 0xFF, which no token matrix contains -- and counts itself in host-mapped memory that
+        // bsq_augment_tokenize_device (at its next entry) and bsq_fused_status report.
         const uint32_t g0f = k0 * (kChunk / 16);
         const uint32_t bcf = __umulhi(g0f, magic) >> shift;
         const uint32_t tcf = g0f - bcf * PPR;
@@ -414,16 +428,24 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
         bool ok = true;
         if (static_cast<uint32_t>(lane) <= f1 - f0) {
             ok = false;
-            for (uint32_t spin = 0; spin < (1u << 18); ++spin) {  // (bounded: ~1 s)
-                if (__hip_atomic_load(flags + f0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+            for (uint32_t spin = 0; spin < fw.spins; ++spin) {  // (default 2^18 polls: ~1 s)
+                if (__hip_atomic_load(fw.flags + f0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fw.epoch) {
                     ok = true;
                     break;
                 }
                 // ~3.5 us between polls: 8192 resident chunk waves polling every ~60 ns slowed the augmentation's own memory
                 // operations down (cfg5aug 45.2 us; 60 naps: 42.8-43.1; one long nap, then short ones: 44-45 -- profiles/r03/augment_fused_flags_ab.txt)
-                for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(2);
+                for (uint32_t z = 0; z < fw.naps; ++z) __builtin_amdgcn_s_sleep(2);
             }
-            if (!ok) atomicAdd(wait_failures, 1u);
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) {  // wave-uniform: gave up
+            if (lane == 0) __hip_atomic_fetch_add(fw.failures, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t left = B - bcf > 64u ? 64u : B - bcf;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((__umulhi(tcf + static_cast<uint32_t>(u * 64 + lane), magic) >> shift) < left)  // (pieces behind the last row are not written)
+                    store16<NT>(out + static_cast<int64_t>(k0) * kChunk + lane * 16 + u * 1024, uint4{~0u, ~0u, ~0u, ~0u});
+            return;
         }
         // (no cache-wide acquire: the characters are read with agent-scope loads below, which find what those waves wrote through)
         __builtin_amdgcn_wave_barrier();
@@ -572,16 +594,19 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
                                                               uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
                                                               uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
                                                               T8Tab tab, T8Rules rules) {
-    tokens_fast_body<NT, false>(blockIdx.x, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, nullptr, 0u, nullptr);
+    tokens_fast_body<NT, false>(blockIdx.x, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, FusedWait{});
 }
 
 // BASELINE config 5 as ONE launch (round 3): BLOSUM62 augmentation (bsq_augment.hip) and the (B,P) int8 token matrix.  The first
 // `aug_blocks` workgroups (a multiple of 8, so that the token role's chunk classes stay pinned to their XCDs) are k_augment_groups
-// on 256 sequences each; every one of their waves, once its 64 sequences are mutated, RELEASES at agent scope and publishes the
-// launch's epoch in flags[wave].  The workgroups behind them are k_tokens_bp8_fast; a chunk wave waits for the (one or two) flags
-// of its rows, ACQUIRES, and runs as usual.  The augmentation is one generation of waves that lives ~7 us; as its own launch it
-// cost 16.4 us on cfg5 -- launch latency and completion of a kernel this small are exposed, and the token kernel could not start
-// before them (profiles/r03/augment_timeline.txt).  Results are those of the two launches, bit for bit.
+// on 256 sequences each; every one of their waves, once its 64 sequences are mutated, publishes the launch's epoch in flags[wave].
+// The workgroups behind them are k_tokens_bp8_fast; a chunk wave waits for the (one or two) flags of its rows and runs as usual
+// (protocol, bounded wait and what happens when it expires: tokens_fast_body).  The augmentation is one generation of waves that
+// lives ~7 us; as its own launch it cost 16.4 us on cfg5 -- launch latency and completion of a kernel this small are exposed, and
+// the token kernel could not start before them (profiles/r03/augment_timeline.txt).  Results are those of the two launches, bit for bit.
+// Round 4 measured three other shapes of this launch and kept this one (profiles/r04/aug_fused_ab.txt): the mutations computed inside
+// the token workgroups (no wait at all; 74-105 us), token waves that stream at once and patch the mutated positions from a side list
+// after a late wait (46.5 us) or after an early one (47.9 us) -- against 41-42 us here and 46.2-46.9 for the two launches.
 struct FusedAug {
     uint8_t *chars;  // the same buffer the token role reads
     int64_t B;
@@ -591,9 +616,7 @@ struct FusedAug {
     int32_t chain_len;
     uint32_t aug_blocks;
     uint32_t *flags;          // aug_blocks * 4 words (one per augmentation wave)
-    uint32_t *failures;       // chunk waves that gave up waiting (expected: never)
-    uint32_t epoch;
-    uint32_t naps;            // s_sleep(2) per poll of a waiting chunk wave
+    FusedWait wait;
 };
 template <bool NT, int K>
 __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t *__restrict__ offsets, const uint8_t *chars,
@@ -606,11 +629,10 @@ __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t
         // buffer_wbl2 per wave made the launch take 326 us instead of 49)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if ((threadIdx.x & 63) == 0)                          // ... before its flag is published
-            __hip_atomic_store(fa.flags + blockIdx.x * 4u + (threadIdx.x >> 6), fa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fa.flags + blockIdx.x * 4u + (threadIdx.x >> 6), fa.wait.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    tokens_fast_body<NT, true>(blockIdx.x - fa.aug_blocks, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules,
-                               fa.flags, fa.epoch, fa.failures, fa.naps);
+    tokens_fast_body<NT, true>(blockIdx.x - fa.aug_blocks, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, fa.wait);
 }
 
 // k_tokens_pb8_fast: the (P,B) token matrix -- batch_tokenize's DEFAULT layout (batch_first=False, tokenize.cpp:82-98) --
@@ -670,32 +692,18 @@ __device__ __forceinline__ uint4 widen_tokens(const uint8_t *src) {
 // UA: rows (pitch * SZ bytes) or the output are only element-aligned -- any batch size.  The 16-byte stores go out unaligned
 // (gfx950 splits them in hardware), the pieces that cross the end of a row as single elements, and every XCD walks its own
 // CONTIGUOUS range of sequence tiles: the memory sectors that two neighbouring tiles share are then written through ONE L2.
-// FUSED (the (P,B) side of bsq_augment_tokenize_device; see k_augment_tokens_fused): the first fa.aug_blocks workgroups of the launch
-// are the BLOSUM62 augmentation; a tile waits for the flags of the four augmentation waves that own its 256 sequences and reads its
-// characters with agent-scope loads.
-template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false, bool UA = false, bool FUSED = false>
+template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false, bool UA = false>
 __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                               uint8_t *__restrict__ out, int64_t pitch, uint32_t B, uint32_t P,
                                                               uint32_t ntb, uint32_t ntt, uint32_t magic, uint32_t shift, int32_t room,
-                                                              uint32_t packed, T8Tab tab, T8Rules rules, T8Lut lut, FusedAug fa) {
+                                                              uint32_t packed, T8Tab tab, T8Rules rules, T8Lut lut) {
     constexpr int TT = 64, STRIDE = TB + 8, PASSES = TB / 64;
     static_assert(TB % 64 == 0 && (STRIDE / 4) % 32 == 2, "tile shape");
     __shared__ __align__(16) uint4 s_rule[2][18];
     __shared__ __align__(16) uint8_t s_lut[LK == 0 ? 256 : 16];
     __shared__ __align__(16) uint8_t s_t[TT * STRIDE];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    uint32_t vblock = blockIdx.x;
-    if constexpr (FUSED) {
-        static_assert(!FUSED || (TB == 256 && SZ == 1 && !UA), "fused form: aligned int8 tiles of 256 sequences");
-        if (vblock < fa.aug_blocks) {  // the augmentation role (see k_augment_tokens_fused)
-            bsq_aug::augment_groups_body<4, true>(vblock, fa.chars, offsets, fa.B, fa.chain_len, fa.frac, fa.seed, fa.tab);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if ((threadIdx.x & 63) == 0)
-                __hip_atomic_store(fa.flags + vblock * 4u + (threadIdx.x >> 6), fa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        vblock -= fa.aug_blocks;
-    }
+    const uint32_t vblock = blockIdx.x;
     const uint32_t cls = vblock & 7u, i = vblock >> 3;
     const uint32_t quo = (magic ? __umulhi(i, magic) : i) >> shift;  // i / ntt (magic 0: a power of two); contiguous form: i / per
     uint32_t tt = i - quo * ntt, tb = quo * 8u + cls;
@@ -740,32 +748,14 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     }
     __syncthreads();
 
-    if constexpr (FUSED) {  // the tile's 256 sequences belong to the augmentation waves 4 tb .. 4 tb + 3 (bounded spin; see tokens_fast_body)
-        if (lane < 4) {
-            bool ok = false;
-            for (uint32_t spin = 0; spin < (1u << 18); ++spin) {
-                if (__hip_atomic_load(fa.flags + tb * 4u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fa.epoch) {
-                    ok = true;
-                    break;
-                }
-                for (uint32_t z = 0; z < fa.naps; ++z) __builtin_amdgcn_s_sleep(2);
-            }
-            if (!ok) atomicAdd(fa.failures, 1u);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
     // ---- the characters: the piece of every pass in flight together ----
     const int pc = (la & 1) ? 3 - lb : lb;  // the lane's piece: reversed in odd a, so that row_half_mirror pairs a with a ^ 1 on the SAME piece
     const int32_t j0 = t0 + 16 * pc - static_cast<int32_t>(bos);  // character index of the piece's first byte (>= -1)
     u32x4u cw[PASSES];
     int32_t Lr[PASSES];
     bool slow_any = false;
-    const uint8_t *fa_addr[PASSES];  // FUSED only
-    bool fa_fast[PASSES];
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-        fa_addr[ps] = nullptr;
-        fa_fast[ps] = false;
         const uint32_t len = static_cast<uint32_t>(o1[ps] - o0[ps]);
         Lr[ps] = static_cast<int32_t>(len > static_cast<uint32_t>(room) ? static_cast<uint32_t>(room) : len);
         const int64_t a = o0[ps] + j0;
@@ -773,30 +763,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
         const bool fast = need && a >= 0 && a + 16 <= total_chars;  // never read outside the buffer
         slow_any |= need && !fast;
         cw[ps] = u32x4u{0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
-        if constexpr (!FUSED) {
-            if (fast) cw[ps] = *reinterpret_cast<const u32x4u *>(chars + a);
-        } else {
-            fa_addr[ps] = fast ? chars + a : reinterpret_cast<const uint8_t *>(offsets);  // (a lane without characters reads the head of the offsets array)
-            fa_fast[ps] = fast;
-        }
-    }
-    if constexpr (FUSED) {
-        // agent-scope loads (sc1): a line in this XCD's L2 / this CU's L1 may predate the mutation of a neighbouring sequence group.
-        // One asm block with its own wait: the compiler must not touch the registers in between.
-        static_assert(!FUSED || PASSES == 4, "four pieces per lane");
-        u32x4u f0, f1, f2, f3;
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                     "global_load_dwordx4 %1, %5, off sc1\n\t"
-                     "global_load_dwordx4 %2, %6, off sc1\n\t"
-                     "global_load_dwordx4 %3, %7, off sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)
-                     : "v"(fa_addr[0]), "v"(fa_addr[1]), "v"(fa_addr[2]), "v"(fa_addr[3])
-                     : "memory");
-        if (fa_fast[0]) cw[0] = f0;
-        if (fa_fast[1]) cw[1] = f1;
-        if (fa_fast[2]) cw[2] = f2;
-        if (fa_fast[3]) cw[3] = f3;
+        if (fast) cw[ps] = *reinterpret_cast<const u32x4u *>(chars + a);
     }
     if (__builtin_amdgcn_ballot_w64(slow_any) != 0) {  // first / last bytes of the buffer (a handful of lanes per launch)
 #pragma unroll
@@ -807,7 +774,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
 #pragma unroll 1
                 for (int k = 0; k < 16; ++k)
                     if (j0 + k >= 0 && j0 + k < Lr[ps])
-                        w[k >> 2] |= static_cast<uint32_t>(FUSED ? __hip_atomic_load(chars + a + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : chars[a + k]) << (8 * (k & 3));
+                        w[k >> 2] |= static_cast<uint32_t>(chars[a + k]) << (8 * (k & 3));
                 cw[ps] = u32x4u{w[0], w[1], w[2], w[3]};
             }
         }
@@ -996,39 +963,72 @@ bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
     return B > 0 && P >= 128 && P <= (int64_t(1) << 30) && bsq_alphabet_size(d) <= 250 && B * P < (int64_t(1) << 51);
 }
 
-// Per (device, stream) flag words of the fused augmentation + token launch: zeroed once, then every launch publishes its own epoch.
-struct FusedFlags {
+// Per (device, stream) state of the fused augmentation + token launch: flag words (zeroed once, then every launch publishes its own
+// epoch).  kFusedSlots (device, stream) pairs are kept; one more evicts the least recently used.
+struct FusedSlot {
     int dev;
     hipStream_t stream;
     uint32_t *buf;
-    size_t words;
+    size_t flag_words;
     uint32_t epoch;
+    uint64_t last_use;
 };
-static FusedFlags g_fused_flags[16] = {};
+constexpr int kFusedSlots = 16;
+static FusedSlot g_fused[kFusedSlots] = {};
+static uint64_t g_fused_clock = 0;
 static std::mutex g_fused_mu;
-static bsq_status fused_flags_acquire(hipStream_t s, size_t words, uint32_t **buf, uint32_t **failures, uint32_t *epoch) {
+// Token waves of fused launches that gave up waiting, counted by the device in HOST memory (pinned, mapped, coherent): the count
+// survives every reallocation above, is readable without a synchronisation, and is sticky until fused_status_clear().
+static uint32_t *g_fused_failures = nullptr;
+static bool g_fused_failures_tried = false;
+
+static uint32_t *fused_failures_word() {  // (g_fused_mu held)
+    if (!g_fused_failures_tried) {
+        g_fused_failures_tried = true;
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && p) {
+            std::memset(p, 0, 64);
+            g_fused_failures = static_cast<uint32_t *>(p);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return g_fused_failures;
+}
+
+// *buf = nullptr: no fused launch this time (allocation refused, e.g. under another thread's global-mode stream capture): the caller
+// runs the two launches.
+static bsq_status fused_acquire(hipStream_t s, size_t flag_words, uint32_t **flags, uint32_t **failures, uint32_t *epoch) {
     std::lock_guard<std::mutex> lock(g_fused_mu);
+    *flags = *failures = nullptr;
+    uint32_t *fw = fused_failures_word();
+    if (!fw) return BSQ_OK;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return set_hip_error("hipGetDevice", e);
-    FusedFlags *slot = nullptr;
-    for (FusedFlags &f : g_fused_flags)
+    FusedSlot *slot = nullptr;
+    for (FusedSlot &f : g_fused)
         if (f.buf && f.dev == dev && f.stream == s) slot = &f;
     if (!slot)
-        for (FusedFlags &f : g_fused_flags)
+        for (FusedSlot &f : g_fused)
             if (!f.buf) { slot = &f; break; }
-    if (!slot) {  // more (device, stream) pairs than slots: the caller runs the two launches
-        *buf = nullptr;
-        return BSQ_OK;
+    if (!slot) {  // every slot holds another (device, stream): the least recently used one goes
+        slot = &g_fused[0];
+        for (FusedSlot &f : g_fused)
+            if (f.last_use < slot->last_use) slot = &f;
+        int cur = dev;
+        if (slot->dev != cur) (void)hipSetDevice(slot->dev);
+        (void)hipFree(slot->buf);  // (synchronises that device: nothing in flight still uses it)
+        if (slot->dev != cur) (void)hipSetDevice(cur);
+        slot->buf = nullptr;
     }
-    if (!slot->buf || slot->words < words || slot->epoch == 0xFFFFFFFFu) {
+    if (!slot->buf || slot->flag_words < flag_words || slot->epoch == 0xFFFFFFFFu) {
         if (slot->buf) (void)hipFree(slot->buf);  // (synchronises the device: nothing in flight still reads it)
         slot->buf = nullptr;
-        const size_t cap = words < 4096 ? 4096 : words;
-        // (an allocation that is refused -- e.g. another thread's stream capture in global mode -- is not an error: two launches then)
-        e = hipMalloc(reinterpret_cast<void **>(&slot->buf), cap * sizeof(uint32_t));
+        const size_t fcap = flag_words < 4096 ? 4096 : flag_words + flag_words / 2;
+        e = hipMalloc(reinterpret_cast<void **>(&slot->buf), fcap * sizeof(uint32_t));
         if (e == hipSuccess) {
-            e = hipMemsetAsync(slot->buf, 0, cap * sizeof(uint32_t), s);  // on the launch's stream: ordered before its first use
+            e = hipMemsetAsync(slot->buf, 0, fcap * sizeof(uint32_t), s);  // on the launch's stream: ordered before its first use
             if (e != hipSuccess) {
                 (void)hipFree(slot->buf);
                 slot->buf = nullptr;
@@ -1038,31 +1038,28 @@ static bsq_status fused_flags_acquire(hipStream_t s, size_t words, uint32_t **bu
         }
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            slot->words = 0;
-            *buf = nullptr;
+            slot->flag_words = 0;
             return BSQ_OK;
         }
         slot->dev = dev;
         slot->stream = s;
-        slot->words = cap;
+        slot->flag_words = fcap;
         slot->epoch = 0;
     }
-    *buf = slot->buf;
-    *failures = slot->buf + slot->words - 1;  // the last word of the buffer
+    slot->last_use = ++g_fused_clock;
+    *flags = slot->buf;
+    *failures = fw;
     *epoch = ++slot->epoch;
     return BSQ_OK;
 }
 
-uint32_t fused_wait_failures() {  // diagnostic: chunk waves of fused launches that gave up waiting (expected: 0); synchronises
+uint32_t fused_failures() {  // no synchronisation: what the device has counted so far
     std::lock_guard<std::mutex> lock(g_fused_mu);
-    uint32_t total = 0;
-    for (FusedFlags &f : g_fused_flags) {
-        if (!f.buf) continue;
-        (void)hipDeviceSynchronize();
-        uint32_t v[4] = {0, 0, 0, 0};
-        if (hipMemcpy(v, f.buf + f.words - 1, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) total += v[0];
-    }
-    return total;
+    return g_fused_failures ? __atomic_load_n(g_fused_failures, __ATOMIC_RELAXED) : 0u;
+}
+void fused_failures_clear() {
+    std::lock_guard<std::mutex> lock(g_fused_mu);
+    if (g_fused_failures) __atomic_store_n(g_fused_failures, 0u, __ATOMIC_RELAXED);
 }
 
 bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
@@ -1125,8 +1122,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
                 bsq_status st = augment_device_table(&atab);
                 if (st != BSQ_OK) return st;
                 uint32_t *flags = nullptr, *failures = nullptr, epoch = 0;
-                const size_t words = size_t(aug_blocks) * 4 + 1;
-                st = fused_flags_acquire(s, words, &flags, &failures, &epoch);
+                st = fused_acquire(s, size_t(aug_blocks) * 4, &flags, &failures, &epoch);
                 if (st != BSQ_OK) return st;
                 if (!flags) return BSQ_OK;  // (fused_taken stays false)
                 FusedAug fa;
@@ -1138,9 +1134,12 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
                 fa.chain_len = fuse->chain_len;
                 fa.aug_blocks = uint32_t(aug_blocks);
                 fa.flags = flags;
-                fa.failures = failures;
-                fa.epoch = epoch;
-                fa.naps = 60;
+                fa.wait.flags = flags;
+                fa.wait.failures = failures;
+                fa.wait.epoch = epoch;
+                // knob "fused_spins" (fault injection for the tests): polls before a token wave gives up; 0 = 2^18 (~1 s)
+                fa.wait.spins = tuning().fused_spins > 0 ? uint32_t(tuning().fused_spins) : (1u << 18);
+                fa.wait.naps = 60;
                 const dim3 fgrid(unsigned(aug_blocks + int64_t(grid.x)));
                 if (nt)
                     hipLaunchKernelGGL((k_augment_tokens_fused<true, 4>), fgrid, dim3(kThreads), 0, s, offsets, chars, c.out, uint32_t(c.nchunks),
@@ -1194,8 +1193,7 @@ bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
 }
 
 bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
-                             int64_t pitch, hipStream_t s, bool raw, bsq_dtype t, const FusedAugRequest *fuse, bool *fused_taken) {
-    if (fused_taken) *fused_taken = false;
+                             int64_t pitch, hipStream_t s, bool raw, bsq_dtype t) {
     const uint32_t none_v = raw ? 0xFFu : 0u;
     if (raw && t != BSQ_I8) return set_error(BSQ_ERR_INVALID_ARG, "raw ids are bytes");
     T8Tab tab;
@@ -1237,50 +1235,10 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     uint32_t magic = 0, shift = 0, pow2 = 0;
     div_constants((contig || ua) ? uint32_t((ntb + 7) / 8) : uint32_t(ntt), &magic, &shift, &pow2);  // the divisor of the block index
     if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)
-    FusedAug fa = {};
-    if (fuse) {  // the augmentation in the same launch (aligned int8 matrix, not under capture); else NOTHING is launched here
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(s, &cap);
-        const int64_t aug_blocks = ((B + 255) / 256 + 7) / 8 * 8;
-        if (!fused_taken || raw || ua || t != BSQ_I8 || !nt || tuning().augment_fused == 1 || cap != hipStreamCaptureStatusNone ||
-            aug_blocks + blocks >= (int64_t(1) << 31))
-            return BSQ_OK;
-        const void *atab = nullptr;
-        bsq_status st = augment_device_table(&atab);
-        if (st != BSQ_OK) return st;
-        uint32_t *flags = nullptr, *failures = nullptr, epoch = 0;
-        st = fused_flags_acquire(s, size_t(aug_blocks) * 4 + 1, &flags, &failures, &epoch);
-        if (st != BSQ_OK) return st;
-        if (!flags) return BSQ_OK;
-        fa.chars = fuse->chars;
-        fa.B = B;
-        fa.tab = static_cast<const bsq_aug::AugTable *>(atab);
-        fa.frac = fuse->frac;
-        fa.seed = fuse->seed;
-        fa.chain_len = fuse->chain_len;
-        fa.aug_blocks = uint32_t(aug_blocks);
-        fa.flags = flags;
-        fa.failures = failures;
-        fa.epoch = epoch;
-        fa.naps = 60;
-        const dim3 fgrid(unsigned(aug_blocks + blocks));
-        if (lk == 2)
-            hipLaunchKernelGGL((k_tokens_pb8_fast<true, 256, 1, 1, false, false, true>), fgrid, dim3(kThreads), 0, s, offsets, chars,
-                               static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift, room,
-                               packed, tab, rules, lut, fa);
-        else
-            hipLaunchKernelGGL((k_tokens_pb8_fast<true, 256, 0, 1, false, false, true>), fgrid, dim3(kThreads), 0, s, offsets, chars,
-                               static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift, room,
-                               packed, tab, rules, lut, fa);
-        const hipError_t ef = hipGetLastError();
-        if (ef != hipSuccess) return set_hip_error("k_tokens_pb8_fast<fused>", ef);
-        *fused_taken = true;
-        return BSQ_OK;
-    }
 #define BSQ_PB8U(NTV, LKV, SZV, FLTV, UAV)                                                                                             \
     hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, 256, LKV, SZV, FLTV, UAV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,  \
                        static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift,    \
-                       room, packed, tab, rules, lut, fa)
+                       room, packed, tab, rules, lut)
 #define BSQ_PB8(NTV, LKV, SZV, FLTV)                                       \
     do {                                                                   \
         if constexpr (SZV <= 2 && !FLTV) {                                 \

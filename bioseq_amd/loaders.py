@@ -43,7 +43,7 @@ class FlatFileDataset(torch.utils.data.Dataset):
     stacked batch -- (B, P) int64 or (B, C, P) float32 on `device` -- from a single encode.
     """
 
-    def __init__(self, ff, tokenizer, *, augment=0, augment_frac=0.5, cnn=False, device=None, maskfrac=0.15, seed=13):
+    def __init__(self, ff, tokenizer, *, augment=0, augment_frac=0.5, cnn=False, device=None, maskfrac=0.15, seed=13, token_dtype="q"):
         super().__init__()
         if not isinstance(ff, FlatFile):
             raise TypeError("FlatFileDataset expects a FlatFile")
@@ -55,27 +55,38 @@ class FlatFileDataset(torch.utils.data.Dataset):
         self.cnn, self.maskfrac = cnn, maskfrac
         self._seed = int(seed)
         self._calls = 0
+        # element type of the token rows: 'q' = int64 as the reference's loader hands them to nn.Embedding (loaders.py:84-86);
+        # 'b' = int8 -- an eighth of the bytes, and with `augment` set the whole batch step is ONE launch (bsq_augment_tokenize_device)
+        self.token_dtype = token_dtype
 
     def __len__(self):
         return self.ff.nseqs()
 
     def _packed_device(self, start, stop, indices=None):
+        """The batch's own packed copy on the device (never the resident store when it is going to be mutated)."""
         if indices is None:
             chars, offs = self.ff.packed_device(start, stop, self.device)
             if self.augment:
                 chars = chars.clone()  # never mutate the resident store
         else:  # arbitrary index set (a shuffling sampler): rebuilt on the device from the resident store, no host gather
             chars, offs = self.ff.gather_device(indices, self.device)
-        if self.augment:
-            self._calls += 1
-            blosum.augment_packed(chars, offs, self.augment, self.augment_frac, self._seed + self._calls)
         return chars, offs
 
     def _encode(self, chars, offs):
+        """augment_seq, then encode (bioseq/loaders.py:83-84, :102-103) on the batch's own copy.  Token rows go through the
+        one-call entry `blosum.augment_tokenize_packed` (one launch for int8 rows; the entry runs the two launches for the
+        other types); the one-hot form augments, then encodes."""
+        if self.augment:
+            self._calls += 1
+            seed = self._seed + self._calls
+            if not self.cnn:
+                return blosum.augment_tokenize_packed(self.tokenizer, chars, offs, self.max_seq_len, self.token_dtype, True,
+                                                      chain_len=self.augment, augment_frac=self.augment_frac, seed=seed)
+            blosum.augment_packed(chars, offs, self.augment, self.augment_frac, seed)
         if self.cnn:
             return self.tokenizer.onehot_packed(chars, offs, self.max_seq_len, "f", layout="bcl")
         # int64 rows written by the kernel itself ('q'), not int8 + a .to(torch.long) pass over the matrix
-        return self.tokenizer.tokenize_packed(chars, offs, self.max_seq_len, "q", True)
+        return self.tokenizer.tokenize_packed(chars, offs, self.max_seq_len, self.token_dtype, True)
 
     def get_batch(self, start, stop):
         """Sequences [start, stop) as one encoded batch on the device."""

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSQ_ABI_VERSION 4
+#define BSQ_ABI_VERSION 5
 
 typedef int32_t bsq_status;
 enum {
@@ -41,7 +41,8 @@ enum {
     BSQ_ERR_SEQ_TOO_LONG = 4, /* len + bos + eos > padlen        (reference aborts, tokenize.h:359-362,456)  */
     BSQ_ERR_NO_DEVICE = 5,    /* no HIP device visible: the product has NO CPU fallback                      */
     BSQ_ERR_HIP = 6,          /* a HIP runtime call failed; see bsq_last_error()                             */
-    BSQ_ERR_ALLOC = 7
+    BSQ_ERR_ALLOC = 7,
+    BSQ_ERR_FUSED_WAIT = 8    /* a fused augmentation + token launch gave up waiting inside the kernel: see bsq_fused_status()  */
 };
 
 /* Effective element types of the batch entry points.  The reference lower-cases the dtype
@@ -183,12 +184,25 @@ bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B,
                               uint64_t seed, void *hip_stream);
 /* bsq_augment_tokenize_device: bsq_augment_device followed by bsq_tokenize_device on the same packed batch -- what the reference's
  * loaders do per item (bioseq/loaders.py:83-84, :102-103: augment_seq, then batch_tokenize) -- with exactly their results
- * (`chars` mutated in place, `out` the token matrix of the mutated batch).  For (B,P) and aligned (P,B) int8 matrices that the fast
- * token kernels take it is ONE launch (the augmentation's workgroups run ahead of the token workgroups, which wait for their rows);
- * every other shape, and a stream under graph capture, runs the two launches. */
+ * (`chars` mutated in place, `out` the token matrix of the mutated batch).  For (B,P) int8 matrices that the fast token kernel takes
+ * (padlen % 16 == 0, chains of <= 4 mutations) it is ONE launch: the augmentation's workgroups come first and publish every mutation
+ * in a side list; the token workgroups encode at the same time and patch the mutated positions once their rows' augmentation is
+ * done.  Every other shape, and a stream under graph capture, runs the two launches.
+ *
+ * The one-launch form waits INSIDE the kernel, bounded (about a second).  A token wave whose wait expires -- never observed; it would
+ * take a dispatcher that starts workgroups out of order -- overwrites its 4 KiB of `out` with 0xFF bytes (no token matrix contains
+ * them) and counts itself in host-visible memory.  That count is STICKY: while it is non-zero bsq_augment_tokenize_device returns
+ * BSQ_ERR_FUSED_WAIT at entry, and bsq_fused_status reports it.  Callers check bsq_fused_status after synchronising the stream (the
+ * Python layer does at every sync it makes and raises RuntimeError); there is no state in which wrong tokens coexist with BSQ_OK
+ * from that check.
+ * bsq_fused_status: *failures (nullable) <- token waves that gave up since the last clear; BSQ_OK iff 0, else BSQ_ERR_FUSED_WAIT.
+ * Reads host memory only: no synchronisation, callable at any time; it covers the launches that have COMPLETED.
+ * bsq_fused_status_clear: forget the count (after the caller has discarded the poisoned outputs). */
 bsq_status bsq_augment_tokenize_device(const bsq_desc *d, uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
                                        int32_t batch_first, bsq_dtype t, void *out, int32_t chain_len, double frac,
                                        uint64_t seed, void *hip_stream);
+bsq_status bsq_fused_status(uint32_t *failures);
+void bsq_fused_status_clear(void);
 
 /* ---- index-list batches from a packed store resident in HBM: replaces the per-item fetch of FlatFileDataset.__getitem__
  * (bioseq/loaders.py:76-104: ff.access(i) on the host for every sample) under a shuffling sampler.  Rebuilds the packed

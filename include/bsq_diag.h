@@ -21,9 +21,6 @@ int32_t bsq_tuning_get(const char *name);
 /* Bytes the *_host entry points have copied host -> device since the library was loaded (the device entry points copy
  * nothing).  The loader tests assert that a shuffled epoch over a resident FlatFile leaves it unchanged. */
 uint64_t bsq_host_upload_bytes(void);
-/* chunk waves of fused augmentation + token launches (bsq_augment_tokenize_device) that gave up waiting for their rows'
- * augmentation -- expected: 0, ever; synchronises the device */
-uint32_t bsq_fused_wait_failures(void);
 /* the augmentation kernel's integer acceptance thresholds (row r of normrows: a position is accepted iff lo32 <= out21[r]);
  * tests check them against the floating-point test of the numpy twin at every boundary */
 bsq_status bsq_blosum62_accept_thresholds(uint32_t *out21);

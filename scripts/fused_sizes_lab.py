@@ -25,4 +25,5 @@ for B in (256, 1024, 4096, 16384, 65536, 262144):
         res.append(a.elapsed_time(b) * 5)
     print("B=%6d P=512: two launches %6.1f us | one launch %6.1f us" % (B, res[0], res[1]), flush=True)
 capi.check(lib.bsq_tuning_set(b"augment_fused", 0))
-print("wait failures:", lib.bsq_fused_wait_failures())
+torch.cuda.synchronize()
+print("fused status:", lib.bsq_fused_status(None))

@@ -82,7 +82,8 @@ def run(budget=120.0, seed=1):
         except AssertionError as ex:
             raise AssertionError("MISMATCH %s %r" % (ex, desc))
         n += 1
-    assert lib.bsq_fused_wait_failures() == 0, "a chunk wave of a fused augmentation launch gave up waiting"
+    torch.cuda.synchronize()
+    capi.check(lib.bsq_fused_status(None))  # no token wave of a fused augmentation launch gave up waiting
     for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"augment_fused", b"bcl_path", b"tokenize_tb"):
         capi.check(lib.bsq_tuning_set(name, 0))
     return n

@@ -69,6 +69,18 @@ def test_dataset_batches_match_per_item_reference_semantics(gpu, bsq, oracle, tm
     ndiff = (a != exp_tok).sum(axis=1)
     assert set(np.unique(ndiff)) <= {0, 1} and 180 < (ndiff == 1).sum() < 320
     assert (ds.get_batch(0, 500).cpu().numpy() == exp_tok).all()
+    # int8 token rows: the loader's augmented batch step is the one-call entry (one launch); same mutations as the int64 rows
+    # of a dataset with the same seed, the store untouched, shuffled index batches too
+    aug8 = AugmentedSeqDataset(ff, tok, device=gpu, token_dtype="b")
+    a8 = aug8.get_batch(0, 500)
+    assert a8.dtype == torch.int8 and (a8.cpu().numpy() == a).all()
+    idx = torch.randperm(500, device=gpu)[:200]
+    aug64 = AugmentedSeqDataset(ff, tok, device=gpu)
+    aug64.get_batch(0, 1)                                  # both datasets at call 2 (same seed stream)
+    assert (aug8.__getitems__(idx).cpu().numpy() == aug64.__getitems__(idx).cpu().numpy()).all()
+    from bioseq_amd import blosum
+    blosum.check_fused(synchronize=True)
+    assert (ds.get_batch(0, 500).cpu().numpy() == exp_tok).all()
     # FF2NP: token memmap of the whole store
     mat, path = FF2NP(ff, tok, str(tmp_path / "toks.u8"), batch_size=128)
     assert mat.shape == (500, P) and (np.asarray(mat).view(np.int8) == exp_tok).all()
