@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4f|cfg4b|cfg5]
-                    [--scaling weak|strong] [--gather K]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg2sf|cfg3b|cfg4f|cfg4b|cfg5|cfg5aug]
+                    [--configs all|none|a,b,c] [--scaling weak|strong] [--gather K]
 
 A "step" is ONE pass of the hot path over one batch of synthetic input that is already resident
 in HBM (packed chars + offsets on the device, output preallocated): for the default workload
@@ -23,6 +23,12 @@ Rank 0 prints ONE JSON line.  Extra objects:
   cpu_baseline  the reference's CPU path on this box's host cores, same batch (N=1, rank 0 only):
                 oracle/_ref (the reference's own C++ compiled in place, kind "reference") when that
                 prebuilt module is present, else the C port in oracle/ (kind "port").
+  configs       (N = 1, default workload only; --configs) every OTHER BASELINE workload in the same run -- cfg2, cfg2sf, cfg3b,
+                cfg4f, cfg4b, cfg5, cfg5aug -- each with ms_per_step / frac (K steps between one pair of events), frac_sustained
+                (>= 0.25 s), traffic, kernel, an untimed `check` of its full-size output against the committed folds of the
+                REFERENCE's output (tests/golden/bench_folds.json -- never a comparison with the product's own kernels), and
+                for the token workloads `cold`: the same step cycling over distinct resident batches whose inputs add up to
+                more than 512 MiB (past the 256-MiB Infinity Cache -- a training loop never encodes one batch twice).
 """
 import argparse
 import json
@@ -36,10 +42,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+M64 = (1 << 64) - 1
 
 WORKLOADS = {
     #        synth config, op, destchar, batch_first
     "cfg3": ("cfg3", "onehot", "f", False),
+    "cfg3b": ("cfg3", "onehot", "B", False),      # the reference's DEFAULT call batch_onehot_encode(seqs, padlen): destchar 'B' -> int8 (tokenize.cpp:81)
     "cfg3bcl": ("cfg3", "onehot_bcl", "f", False),  # channels-first (B,C,P) written directly (loader layout)
     "cfg1oh": ("cfg1", "onehot", "f", False),     # BASELINE configs[0]'s batch as a one-hot: tiny, for smoke runs of the N > 1 path
     "cfg2": ("cfg2", "tokenize", "B", True),
@@ -49,6 +57,7 @@ WORKLOADS = {
     "cfg5": ("cfg5", "tokenize", "B", True),
     "cfg5aug": ("cfg5", "augment+tokenize", "B", True),  # BASELINE config 5: BLOSUM62 augmentation, then SEB8 tokens
 }
+DEFAULT_CONFIGS = ["cfg2", "cfg2sf", "cfg3b", "cfg4f", "cfg4b", "cfg5", "cfg5aug"]  # beside the headline cfg3, in the driver's line
 
 
 def baseline_metric():
@@ -192,12 +201,364 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def fold_device(t):
+    """(xor, sum, wsum) of a device tensor's bytes as tests/golden/make_bench_folds.py defines them, computed ON the device
+    with torch integer arithmetic (int64 wraps like uint64); returns three hex strings."""
+    import torch
+    b = t.contiguous().view(torch.uint8).reshape(-1)
+    if b.numel() % 8:
+        b = torch.cat([b, torch.zeros(8 - b.numel() % 8, dtype=torch.uint8, device=b.device)])
+    w = b.view(torch.int64)
+    x = s = ws = 0
+    step = 1 << 26
+    for i in range(0, w.numel(), step):
+        c = w[i:i + step]
+        s = (s + int(c.sum().item())) & M64
+        k = torch.arange(i, i + c.numel(), dtype=torch.int64, device=c.device) * 2 + 1
+        ws = (ws + int((c * k).sum().item())) & M64
+        del k
+        y = c
+        carry = torch.zeros(1, dtype=torch.int64, device=c.device)
+        while y.numel() > 1:  # xor of all words by halving
+            h = y.numel() // 2
+            if y.numel() & 1:
+                carry = carry ^ y[-1:]
+            y = y[:h] ^ y[h:2 * h]
+        x ^= int((y ^ carry).item()) & M64 if y.numel() else int(carry.item()) & M64
+    return "%016x" % (x & M64), "%016x" % s, "%016x" % ws
+
+
+_FOLDS = None
+
+
+def golden_folds():
+    global _FOLDS
+    if _FOLDS is None:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "bench_folds.json")) as f:
+                _FOLDS = json.load(f)
+        except Exception:
+            _FOLDS = {}
+    return _FOLDS
+
+
+class Batch:
+    """One workload's batch resident in HBM + its step through the C ABI."""
+
+    def __init__(self, name, lib, dev, stream, n=None, first=0):
+        import ctypes
+        import torch
+        from bioseq_amd import capi, synth
+        self.name, self.lib, self.dev, self.stream = name, lib, dev, stream
+        self.cfg_name, self.op, self.destchar, self.batch_first = WORKLOADS[name]
+        self.cfg = cfg = synth.CONFIGS[self.cfg_name]
+        self.P = cfg["padlen"]
+        self.n = cfg["n"] if n is None else n
+        self.full_size = self.n == cfg["n"] and first == 0
+        self.chars, self.offsets = synth.synth_packed(cfg["seed"], self.n, cfg["lo"], cfg["hi"], cfg["letters"], first=first)
+        self.total = int(self.offsets[-1])
+        self.desc = capi.make_desc(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
+        self.C = lib.bsq_alphabet_size(ctypes.byref(self.desc))
+        self.dt_code = ctypes.c_int(0)
+        capi.check(lib.bsq_dtype_from_destchar(self.destchar.encode(), ctypes.byref(self.dt_code)))
+        self.sz = lib.bsq_dtype_size(self.dt_code)
+        self.tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[self.dt_code.value]
+        self.d_chars = torch.from_numpy(self.chars).to(dev)
+        self.d_offs = torch.from_numpy(self.offsets).to(dev)
+        self.out = torch.empty(self.out_shape(self.n), dtype=self.tdt, device=dev)
+        self.out_bytes = self.out.numel() * self.sz
+        # SURVEY.md section 8d: chars + offsets read once, output written once
+        self.algo_bytes = self.total + 8 * (self.n + 1) + self.out_bytes
+        self.sh = ctypes.c_void_p(stream.cuda_stream)
+        self.aug_seed = 0
+        self.step_calls = 0
+
+    def out_shape(self, n):
+        P, C = self.P, self.C
+        if self.op == "onehot":
+            return (P, n, C)
+        if self.op == "onehot_bcl":
+            return (n, C, P)
+        return (n, P) if self.batch_first else (P, n)
+
+    def run(self, d_chars, d_offs, out, n):
+        """one pass of the hot path over (d_chars, d_offs) into `out` through the C ABI"""
+        import ctypes
+        from bioseq_amd import capi
+        lib, desc = self.lib, self.desc
+        if self.op == "augment+tokenize":  # AugmentedSeqDataset defaults (loaders.py:117-119): chain_len 1, frac 0.5
+            self.aug_seed += 1
+            st = lib.bsq_augment_tokenize_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), n, self.P, int(self.batch_first),
+                                                 self.dt_code, out.data_ptr(), 1, 0.5, self.aug_seed, self.sh)
+        elif self.op == "onehot":
+            st = lib.bsq_onehot_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), None, n, self.P, self.dt_code, out.data_ptr(), self.sh)
+        elif self.op == "onehot_bcl":
+            st = lib.bsq_onehot_bcl_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), None, n, self.P, self.dt_code, out.data_ptr(), self.sh)
+        else:
+            st = lib.bsq_tokenize_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), n, self.P, int(self.batch_first), self.dt_code,
+                                         out.data_ptr(), self.sh)
+        if st:
+            capi.check(st)
+
+    def step(self):
+        self.step_calls += 1
+        self.run(self.d_chars, self.d_offs, self.out, self.n)
+
+    def check(self):
+        """Untimed: one step into a buffer filled with 7, then (a) a size-independent property, (b) at full size the folds of the
+        output against those of the REFERENCE's output (tests/golden/bench_folds.json; cfg5aug: the reference's tokens of the numpy
+        twin's mutated batch, seed 1, and the fold of the mutated characters themselves).  Raises on any mismatch."""
+        import ctypes
+        import torch
+        from bioseq_amd import capi
+        lib, desc, n, P = self.lib, self.desc, self.n, self.P
+        bad = ctypes.c_int64(-1)
+        capi.check(lib.bsq_validate_lengths_device(self.d_offs.data_ptr(), n, P, desc.bos, desc.eos, ctypes.byref(bad), self.sh))
+        res = {}
+        self.out.fill_(7)
+        self.aug_seed = 0
+        self.step()
+        torch.cuda.synchronize()
+        if self.op in ("onehot", "onehot_bcl"):
+            ones = int(self.out.sum(dtype=torch.float64).item())
+            expect = P * n if desc.padchar else self.total + (n if desc.bos else 0) + (n if desc.eos else 0)
+            if not os.environ.get("BSQ_BENCH_SKIP_SANITY"):
+                assert ones == expect, ("one-hot sanity failed", ones, expect)
+            res["ones"] = ones
+        if self.op == "augment+tokenize":
+            # the step mutated d_chars (seed 1) and wrote the tokens of the MUTATED batch: the generic token kernel on what is in d_chars
+            # now must give the same matrix, and about half of the sequences must differ from the pristine batch in one residue
+            chk = torch.empty_like(self.out)
+            capi.check(lib.bsq_tokenize_device_generic(ctypes.byref(desc), self.d_chars.data_ptr(), self.d_offs.data_ptr(), n, P,
+                                                       int(self.batch_first), self.dt_code, chk.data_ptr(), self.sh))
+            torch.cuda.synchronize()
+            assert torch.equal(chk, self.out), "augment+tokenize sanity failed: tokens are not those of the mutated characters"
+            del chk
+            changed = int((self.d_chars != torch.from_numpy(self.chars).to(self.dev)).sum().item())
+            assert 0.4 * n < changed < 0.6 * n, ("augment+tokenize sanity failed: mutations", changed, n)
+            res["mutated_sequences"] = changed
+            capi.check(lib.bsq_fused_status(None))
+        g = golden_folds().get(self.name)
+        if self.full_size and g:
+            x, sm, ws = fold_device(self.out)
+            ok = (x, sm, ws) == (g["xor"], g["sum"], g["wsum"]) and self.out_bytes == g["nbytes"]
+            assert ok, ("output differs from the reference's (folds)", self.name, (x, sm, ws), g)
+            res.update({"vs": "tests/golden/bench_folds.json (folds of the reference's output at full size)", "xor": x, "sum": sm, "wsum": ws, "ok": True})
+            if self.op == "augment+tokenize":
+                gm = g["mutated_chars"]
+                xm = fold_device(self.d_chars)
+                assert xm == (gm["xor"], gm["sum"], gm["wsum"]), ("mutated characters differ from the numpy twin's (folds)", xm, gm)
+                assert res["mutated_sequences"] == g["mutated_sequences"]
+                res["mutated_chars_ok"] = True
+        else:
+            res.update({"vs": "size-independent property only (not the full-size single-rank batch)", "ok": True})
+        if self.op == "augment+tokenize":  # back to the pristine batch
+            self.d_chars.copy_(torch.from_numpy(self.chars).to(self.dev))
+        return res
+
+    def kernel_name(self):
+        import ctypes
+        n, P, sz, op = self.n, self.P, self.sz, self.op
+        if op == "onehot":
+            return self.lib.bsq_onehot_kernel_name(ctypes.byref(self.desc), n, P, self.dt_code).decode()
+        if op == "onehot_bcl":
+            return "k_tokens_bp8<raw>+k_expand_bcl" if (P >= 128 and P % 16 == 0 and self.out_bytes >= (256 << 20)) else "k_tokenize_chunks<onehot bcl>"
+        if self.batch_first:
+            name = "k_tokens_bp8_fast" if sz == 1 and P >= 128 and P % 16 == 0 else "k_tokenize_chunks"
+        else:
+            name = "k_tokens_pb8_fast" if sz <= 2 and (n * sz) % 16 == 0 else ("k_tokens_raw<value>" if sz == 1 else "k_tokenize_tile")
+        if op == "augment+tokenize":
+            return "k_augment_tokens_fused(k_augment_groups -> k_tokens_bp8_fast)" if name == "k_tokens_bp8_fast" else "k_augment_groups+" + name
+        return name
+
+    def describe(self):
+        cfg = self.cfg
+        return "%s: %s %s, %d seqs/GPU len~U(%d,%d), padlen %d, C=%d, %s output %s" % (
+            self.name, cfg["key"], {"onehot": "batch_onehot_encode", "tokenize": "batch_tokenize",
+                                    "onehot_bcl": "batch_onehot_encode(layout=bcl)"}.get(self.op, "BLOSUM62 augment + batch_tokenize"),
+            self.n, cfg["lo"], cfg["hi"], self.P, self.C, str(self.tdt).replace("torch.", ""),
+            "(P,B,C)" if self.op == "onehot" else "(B,C,P)" if self.op == "onehot_bcl" else ("(B,P)" if self.batch_first else "(P,B)"))
+
+
+def timed_loop(fn, n, warm, stream):
+    import torch
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(n):
+        fn()
+    b.record(stream)
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n  # ms
+
+
+def ramp(step, stream):
+    """Short steps (the 17-55 us token workloads): a few warm-up launches are less than a millisecond of GPU time, not enough to
+    lift the clocks out of idle after a host-side pause; run the step for ~30 ms first (untimed)."""
+    est_ms = timed_loop(step, 5, 2, stream)
+    if est_ms < 1.0:
+        for _ in range(min(20000, int(30.0 / max(est_ms, 1e-3)))):
+            step()
+    return est_ms
+
+
+def sustained_loop(b, min_s, steps_floor, loop_ms, stream):
+    """The same step looped for at least `min_s` seconds of wall clock (clocks, thermals)."""
+    import torch
+    n_sus = max(steps_floor, int(min_s * 1.05 / max(loop_ms * 1e-3, 1e-6)))
+    sa, sb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # augmentation mutates the batch in place: looped 20 000 times on ONE buffer the sequences drift to the chain's stationary
+    # composition (residues with a high self-probability), rejections multiply and the kernel measures that drift, not a fresh
+    # batch.  The pristine characters are copied back every 64 steps, INSIDE the timed region (~0.5 us per step).
+    pristine = b.d_chars.clone() if b.op == "augment+tokenize" else None
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    sa.record(stream)
+    for it in range(n_sus):
+        if pristine is not None and it % 64 == 63:
+            b.d_chars.copy_(pristine)
+        b.step()
+    sb.record(stream)
+    torch.cuda.synchronize()
+    sus_wall = time.perf_counter() - w0
+    sus_ms = sa.elapsed_time(sb) / n_sus
+    out = {"steps": n_sus, "wall_s": sus_wall, "ms_per_step": sus_wall / n_sus * 1e3, "kernel_avg_ms": sus_ms,
+           "frac": b.algo_bytes / (sus_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "frac_wall": b.algo_bytes / (sus_wall / n_sus) / 1e9 / HBM_PEAK_GBPS}
+    if pristine is not None:
+        out["restore_every"] = 64  # the batch is reset to its pristine characters every 64 steps, inside the timed region
+        b.d_chars.copy_(pristine)
+    return out
+
+
+def cold_regime(b, steps, min_s, stream):
+    """The token workloads with NOTHING of the batch resident in a cache: the same step cycling over NB distinct batches (inputs and
+    outputs in their own buffers) whose inputs add up to more than 512 MiB -- twice the 256-MiB Infinity Cache -- so that every
+    character and offset comes from HBM, as in a training loop that never encodes one batch twice (bioseq/loaders.py:76-104).
+    Batch k is the workload's batch with its sequences rotated by k * 4099 positions (built on the device); after the measurement
+    every output is checked against the rotated output of batch 0 (itself checked against the reference's folds).  The copy-mix
+    yardstick (the kernel's stream shape with none of its work) is run the same way."""
+    import torch
+    from bioseq_amd import capi
+    n, dev = b.n, b.dev
+    in_bytes = b.total + 8 * (n + 1)
+    nb = max(8, -(-(513 << 20) // in_bytes))
+    offs = b.d_offs
+    batches = []
+    for k in range(nb):
+        r = (k * 4099) % n
+        c0 = int(b.offsets[r])
+        ch = torch.cat([b.d_chars[c0:], b.d_chars[:c0]]) if r else b.d_chars.clone()
+        lens = offs[1:] - offs[:-1]
+        lens = torch.cat([lens[r:], lens[:r]])
+        of = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        of[1:] = torch.cumsum(lens, 0)
+        batches.append((ch, of, torch.empty_like(b.out), r))
+    pristine = [c.clone() for c, _, _, _ in batches] if b.op == "augment+tokenize" else None
+    seeds = [0] * nb
+
+    def one(k, it):
+        ch, of, out, _ = batches[k]
+        b.run(ch, of, out, n)
+        if pristine is not None and (it // nb) % 64 == 63:
+            ch.copy_(pristine[k])  # right after use: seven other batches pass before it is read again
+
+    it = [0]
+
+    def step():
+        one(it[0] % nb, it[0])
+        it[0] += 1
+
+    ramp(step, stream)
+    loop_ms = timed_loop(step, max(steps, 2 * nb), 2 * nb, stream)
+    n_sus = max(steps, int(min_s * 1.05 / max(loop_ms * 1e-3, 1e-6)))
+    sus_ms = timed_loop(step, n_sus, 0, stream)
+    res = {"batches": nb, "input_bytes_total": nb * in_bytes, "output_bytes_total": nb * b.out_bytes,
+           "ms_per_step": loop_ms, "frac": b.algo_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "sustained_steps": n_sus, "sustained_ms_per_step": sus_ms,
+           "frac_sustained": b.algo_bytes / (sus_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    # untimed: every batch once more from its pristine characters, compared with batch 0's output rotated
+    if b.op != "augment+tokenize":
+        for k in range(nb):
+            one(k, 0)
+        torch.cuda.synchronize()
+        base = batches[0][2]
+        axis = 0 if b.batch_first else 1
+        for k in range(1, nb):
+            assert torch.equal(batches[k][2], torch.roll(base, -batches[k][3], dims=axis)), ("cold batch differs", b.name, k)
+        res["check"] = "every batch's output == the reference-checked output of batch 0, rotated"
+    else:
+        capi.check(b.lib.bsq_fused_status(None))
+        res["check"] = "bsq_fused_status ok (the mutated batches are checked on batch 0 by `check`)"
+    if b.batch_first and b.sz == 1 and b.out_bytes % 4096 == 0 and b.total >= 16:
+        src_bytes = (b.total // 16) * 16
+
+        def mix():
+            ch, _, out, _ = batches[it[0] % nb]
+            capi.check(b.lib.bsq_copy_mix_device(out.data_ptr(), b.out_bytes, ch.data_ptr(), src_bytes, 1, 1, b.sh))
+            it[0] += 1
+
+        mix_ms = timed_loop(mix, max(200, 4 * nb), 2 * nb, stream)
+        res["copy_mix_ms"] = mix_ms
+        res["frac_of_copy_mix"] = mix_ms / sus_ms
+    del batches, pristine
+    torch.cuda.empty_cache()
+    return res
+
+
+def traffic_of(workload):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            return json.load(open(tpath)).get(workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def run_config(name, lib, dev, stream, steps, warmup):
+    """One of the OTHER BASELINE workloads inside the default run (N = 1): check, K-step loop, >= 0.25 s sustained, cold regime."""
+    import torch
+    t0 = time.perf_counter()
+    b = Batch(name, lib, dev, stream)
+    res = {"workload": b.describe(), "kernel": b.kernel_name(), "algorithmic_bytes_per_launch": b.algo_bytes}
+    res["check"] = b.check()
+    ramp(b.step, stream)
+    loop_ms = timed_loop(b.step, steps, warmup, stream)
+    if b.op == "augment+tokenize":
+        b.d_chars.copy_(torch.from_numpy(b.chars).to(dev))
+    res["ms_per_step"] = loop_ms
+    res["frac"] = b.algo_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    sus = sustained_loop(b, 0.25, steps, loop_ms, stream)
+    res["frac_sustained"] = sus["frac"]
+    res["sustained"] = sus
+    res["gseq_chars_per_s"] = b.total / (loop_ms * 1e-3) / 1e9
+    res["gb_per_s_written"] = b.out_bytes / (loop_ms * 1e-3) / 1e9
+    res["traffic"] = traffic_of(name)
+    if b.op in ("tokenize", "augment+tokenize"):
+        res["cold"] = cold_regime(b, steps, 0.5, stream)
+    if b.op == "augment+tokenize":
+        from bioseq_amd import capi
+        torch.cuda.synchronize()
+        capi.check(lib.bsq_fused_status(None))
+    res["seconds"] = time.perf_counter() - t0
+    del b
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)  # the first ~10 launches after idle run 3-8 % slow (clock ramp)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--configs", default=None,
+                    help="N = 1: other workloads measured in the same run and reported under `configs`: 'all' (the default for the "
+                         "default workload: %s), 'none', or a comma-separated list" % ",".join(DEFAULT_CONFIGS))
+    ap.add_argument("--no-configs", action="store_true", help="same as --configs none")
+    ap.add_argument("--cold", action="store_true", help="N = 1: add the cold-input regime of THIS workload (token workloads) as `cold`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive timings of the Python surface (N = 1 only)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 1 s sustained loop (N = 1 only)")
@@ -257,80 +618,22 @@ def main():
         n = cfg["n"]
         n_job = n * world
         first = rank * n
-    chars, offsets = synth.synth_packed(cfg["seed"], n, cfg["lo"], cfg["hi"], cfg["letters"], first=first)
-    total = int(offsets[-1])
 
     lib = capi.load()
-    desc = capi.make_desc(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
-    C = lib.bsq_alphabet_size(ctypes.byref(desc))
-    dt_code = ctypes.c_int(0)
-    capi.check(lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt_code)))
-    sz = lib.bsq_dtype_size(dt_code)
-    tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt_code.value]
-
-    d_chars = torch.from_numpy(chars).to(dev)
-    d_offs = torch.from_numpy(offsets).to(dev)
-    if op in ("onehot", "onehot_bcl"):
-        out = torch.empty((P, n, C) if op == "onehot" else (n, C, P), dtype=tdt, device=dev)
-        out_bytes = P * n * C * sz
-    else:
-        out = torch.empty((n, P) if batch_first else (P, n), dtype=tdt, device=dev)
-        out_bytes = P * n * sz
-    algo_bytes = total + 8 * (n + 1) + out_bytes  # chars + offsets read once, output written once
-
     stream = torch.cuda.current_stream()
-    sh = ctypes.c_void_p(stream.cuda_stream)
-
-    aug_seed = [0]
-
-    def step():
-        if op == "augment+tokenize":  # AugmentedSeqDataset defaults (loaders.py:117-119): chain_len 1, frac 0.5
-            aug_seed[0] += 1
-            # one C-ABI call = bsq_augment_device, then bsq_tokenize_device (one launch where the fast token kernel applies)
-            capi.check(lib.bsq_augment_tokenize_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), n, P,
-                                                       int(batch_first), dt_code, out.data_ptr(), 1, 0.5, aug_seed[0], sh))
-            return
-        if op == "onehot":
-            st = lib.bsq_onehot_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), None, n, P,
-                                       dt_code, out.data_ptr(), sh)
-        elif op == "onehot_bcl":
-            st = lib.bsq_onehot_bcl_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), None, n, P,
-                                           dt_code, out.data_ptr(), sh)
-        else:
-            st = lib.bsq_tokenize_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), n, P,
-                                         int(batch_first), dt_code, out.data_ptr(), sh)
-        if st:
-            capi.check(st)
+    b = Batch(args.workload, lib, dev, stream, n=n, first=first)
+    chars, offsets, total = b.chars, b.offsets, b.total
+    desc, C, dt_code, sz, tdt = b.desc, b.C, b.dt_code, b.sz, b.tdt
+    d_chars, d_offs, out, out_bytes, algo_bytes, sh = b.d_chars, b.d_offs, b.out, b.out_bytes, b.algo_bytes, b.sh
+    step = b.step
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed sanity: validate lengths, run once, check a size-independent property
-    bad = ctypes.c_int64(-1)
-    capi.check(lib.bsq_validate_lengths_device(d_offs.data_ptr(), n, P, desc.bos, desc.eos, ctypes.byref(bad), sh))
-    out.fill_(7)
-    step()
-    torch.cuda.synchronize()
-    if op in ("onehot", "onehot_bcl"):
-        ones = int(out.sum(dtype=torch.float64).item())
-        expect = total + (n if desc.bos else 0) + (n if desc.eos else 0)
-        if desc.padchar:
-            expect = P * n
-        if not os.environ.get("BSQ_BENCH_SKIP_SANITY"):
-            assert ones == expect, ("one-hot sanity failed", ones, expect)
-    if op == "augment+tokenize":
-        # the step mutated d_chars and wrote the tokens of the MUTATED batch (one launch): a plain tokenise of what is in d_chars
-        # now must give the same matrix, and about half of the sequences must differ from the pristine batch in one residue
-        check = torch.empty_like(out)
-        capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr(), n, P, int(batch_first), dt_code,
-                                           check.data_ptr(), sh))
-        torch.cuda.synchronize()
-        assert torch.equal(check, out), "augment+tokenize sanity failed: tokens are not those of the mutated characters"
-        changed = int((d_chars != torch.from_numpy(chars).to(d_chars.device)).sum().item())
-        assert 0.4 * n < changed < 0.6 * n, ("augment+tokenize sanity failed: mutations", changed, n)
-        del check
+    # untimed: validate lengths, run once, check a size-independent property and (full-size single-rank batches) the reference's folds
+    check = b.check()
 
     # write-bandwidth yardstick: a plain fill (one 1-KiB store per wave, one aligned 4-KiB chunk per workgroup, blocks in
     # address order) over the same output buffer, in its BEST-KNOWN configuration: 3 resident workgroups per CU (unused
@@ -338,22 +641,10 @@ def main():
     # Measured BEFORE the warm-up steps: its launches also lift the clocks out of idle.
     capi.check(lib.bsq_tuning_set(b"fill_mode", 1))
     fill_bytes = (out_bytes // 16) * 16
-
-    def timed_loop(fn, n, warm):
-        for _ in range(warm):
-            fn()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(stream)
-        for _ in range(n):
-            fn()
-        b.record(stream)
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / n  # ms
-
     fill_gbps = {}
     for name, pad in (("uncapped", 0), ("3_workgroups_per_cu", 53000)):
         capi.check(lib.bsq_tuning_set(b"fill_pad", pad))
-        fill_gbps[name] = fill_bytes / (timed_loop(lambda: capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh)), 5, 10) * 1e-3) / 1e9
+        fill_gbps[name] = fill_bytes / (timed_loop(lambda: capi.check(lib.bsq_fill_device(out.data_ptr(), fill_bytes, 0, sh)), 5, 10, stream) * 1e-3) / 1e9
     capi.check(lib.bsq_tuning_set(b"fill_pad", 0))
     fill_best = max(fill_gbps.values())
     # read + write yardstick of the token workloads: the kernel's stream shape (one wave = one aligned 4-KiB chunk of the
@@ -361,31 +652,27 @@ def main():
     mix_gbps = None
     if op in ("tokenize", "augment+tokenize") and batch_first and sz == 1 and out_bytes % 4096 == 0 and total >= 16:
         src_bytes = (total // 16) * 16
-        mix_ms = timed_loop(lambda: capi.check(lib.bsq_copy_mix_device(out.data_ptr(), out_bytes, d_chars.data_ptr(), src_bytes, 1, 1, sh)), 20, 10)
+        mix_ms = timed_loop(lambda: capi.check(lib.bsq_copy_mix_device(out.data_ptr(), out_bytes, d_chars.data_ptr(), src_bytes, 1, 1, sh)), 20, 10, stream)
         mix_gbps = (src_bytes + out_bytes) / (mix_ms * 1e-3) / 1e9
     # what one event pair around ONE tiny launch reads: the floor under every per-step event time below
     tiny = torch.empty(4096, dtype=torch.uint8, device=dev)
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-    for a, b in pairs:
-        a.record(stream)
+    for ea, eb in pairs:
+        ea.record(stream)
         capi.check(lib.bsq_fill_device(tiny.data_ptr(), 4096, 0, sh))
-        b.record(stream)
+        eb.record(stream)
     torch.cuda.synchronize()
-    event_floor_ms = float(np.median([a.elapsed_time(b) for a, b in pairs]))
+    event_floor_ms = float(np.median([ea.elapsed_time(eb) for ea, eb in pairs]))
 
-    # Short steps (the 17-55 us token workloads): --warmup W of them is less than a millisecond of GPU time, not enough to lift
-    # the clocks out of idle after the host-side pauses above; run the step for ~30 ms first (untimed, like the yardsticks).
-    est_ms = timed_loop(step, 5, 2)
-    if est_ms < 1.0:
-        for _ in range(min(20000, int(30.0 / max(est_ms, 1e-3)))):
-            step()
+    ramp(step, stream)
     for _ in range(args.warmup):
         step()
     # THE timed region: exactly K steps between barriers.  One pair of HIP events around the same K launches (recorded on
-    # the launch stream) gives the kernel time of a step for the roofline -- rocprofv3's average kernel durations add up
-    # to it within 0-7 % on every workload.
+    # the launch stream) gives the kernel time of a step for the roofline -- rocprofv3's average kernel durations OF THESE K STEPS
+    # (`timed.first_step_index`: scripts/make_traffic.py keeps exactly those dispatches of the trace) add up to it.
     la, lb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
+    first_timed_step = b.step_calls
     t0 = time.perf_counter()
     la.record(stream)
     for _ in range(args.steps):
@@ -399,42 +686,26 @@ def main():
     # records cost ~2 us of queue time per step -- 10 % of the 17-35 us steps of cfg2 / cfg5, nothing on the others --
     # which is why they are not in the timed region.
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:
-        a.record(stream)
+    for ea, eb in ev:
+        ea.record(stream)
         step()
-        b.record(stream)
+        eb.record(stream)
     torch.cuda.synchronize()
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = [ea.elapsed_time(eb) for ea, eb in ev]
     kern_avg_ms = float(np.mean(kern_ms))
     if os.environ.get("BSQ_BENCH_DUMP"):  # per-step device times, for variance hunting
         print("per-step ms:", " ".join("%.3f" % v for v in kern_ms), file=sys.stderr)
+    if op == "augment+tokenize":
+        d_chars.copy_(torch.from_numpy(chars).to(dev))
 
     # Sustained: the same step looped for at least one second of wall clock (clocks, thermals), untimed for `value`.
     sustained = None
     if world == 1 and not args.no_sustained:
-        n_sus = max(args.steps, int(1.05 / max(loop_ms * 1e-3, 1e-6)))
-        sa, sb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        w0 = time.perf_counter()
-        # augmentation mutates the batch in place: looped 20 000 times on ONE buffer the sequences drift to the chain's stationary
-        # composition (residues with a high self-probability), rejections multiply and the kernel measures that drift, not a fresh
-        # batch.  The pristine characters are copied back every 64 steps, INSIDE the timed region (~0.5 us per step).
-        pristine = d_chars.clone() if op == "augment+tokenize" else None
-        sa.record(stream)
-        for it in range(n_sus):
-            if pristine is not None and it % 64 == 63:
-                d_chars.copy_(pristine)
-            step()
-        sb.record(stream)
-        torch.cuda.synchronize()
-        sus_wall = time.perf_counter() - w0
-        sus_ms = sa.elapsed_time(sb) / n_sus
-        sustained = {"steps": n_sus, "wall_s": sus_wall, "ms_per_step": sus_wall / n_sus * 1e3, "kernel_avg_ms": sus_ms,
-                     "frac": algo_bytes / (sus_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "frac_wall": algo_bytes / (sus_wall / n_sus) / 1e9 / HBM_PEAK_GBPS}
-        if pristine is not None:
-            sustained["restore_every"] = 64  # the batch is reset to its pristine characters every 64 steps, inside the timed region
-            del pristine
+        sustained = sustained_loop(b, 1.0, args.steps, loop_ms, stream)
+    step_calls_main = b.step_calls
+    cold = None
+    if world == 1 and args.cold and op in ("tokenize", "augment+tokenize"):
+        cold = cold_regime(b, args.steps, 1.0, stream)
 
     gather_info = None
     if world > 1 and args.gather > 0:
@@ -442,6 +713,19 @@ def main():
         seq_first = op == "onehot" or (op == "tokenize" and not batch_first)
         axis = 1 if seq_first else 0
         out_c = out.contiguous() if backend == "nccl" else out.cpu().contiguous()  # gloo smoke runs move host tensors
+
+        # what every assembled batch must be: THIS rank's own encode of the whole job batch (sequences [0, n_job) of the stream) in
+        # one single-rank pass -- compared by content (the three 64-bit folds), not by shape
+        whole = Batch(args.workload, lib, dev, stream, n=n_job, first=0)
+        whole.step()
+        torch.cuda.synchronize()
+        want = fold_device(whole.out)
+        want_shape = tuple(whole.out.shape)
+        if whole.full_size and golden_folds().get(args.workload):
+            g = golden_folds()[args.workload]
+            assert want == (g["xor"], g["sum"], g["wsum"]), "single-rank encode of the job batch differs from the reference's folds"
+        del whole
+        torch.cuda.empty_cache()
 
         def timed(fn, check_axis=None):
             ms = []
@@ -451,8 +735,9 @@ def main():
                 full = fn()
                 barrier()
                 ms.append((time.perf_counter() - g0) * 1e3)
-                if full is not None and check_axis is not None:
-                    assert full.shape[check_axis] == n_job, (tuple(full.shape), n_job)
+                if full is not None:  # (None: this rank is not the root of a rooted form)
+                    assert tuple(full.shape) == want_shape, (tuple(full.shape), want_shape)
+                    assert fold_device(full) == want, "an assembled batch differs from the single-rank encode of the whole batch"
                 del full
             t = torch.tensor([float(np.mean(ms[1:]))], dtype=torch.float64, device=red_dev)  # first one warms RCCL up
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -497,7 +782,9 @@ def main():
         for f in forms.values():
             f["gb_per_s_into_each_rank"] = recv_bytes / (f["ms"] * 1e-3) / 1e9
         gather_info = {"bytes_received_per_rank": recv_bytes, "forms": forms, "note": "encode time excluded; mean of %d "
-                       "assemblies after one warm-up, MAX over ranks" % args.gather}
+                       "assemblies after one warm-up, MAX over ranks" % args.gather,
+                       "check": "every assembled batch (every form, every repetition, on every rank that receives it) has the three 64-bit folds "
+                                "of the single-rank encode of the whole job batch"}
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
     tot_t = torch.tensor([float(total), float(out_bytes)], dtype=torch.float64, device=red_dev)
@@ -510,22 +797,8 @@ def main():
     if rank == 0:
         # kernel time of one step = one pair of events around the K timed launches, / K
         achieved = algo_bytes / (loop_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        kernel_name = (lib.bsq_onehot_kernel_name(ctypes.byref(desc), n, P, dt_code).decode() if op == "onehot"
-                       else (("k_tokens_bp8" if sz == 1 and P >= 128 and P % 16 == 0 else "k_tokenize_chunks")
-                             if batch_first else ("k_tokens_pb8_fast" if sz <= 2 and (n * sz) % 16 == 0 and os.environ.get("BSQ_TOKENS_PB8", "0") != "1"
-                                                 else ("k_tokens_raw<value>" if sz == 1 else "k_tokenize_tile"))))
-        if op == "augment+tokenize":
-            kernel_name = ("k_augment_tokens_fused(k_augment_groups -> k_tokens_bp8_fast)" if os.environ.get("BSQ_AUGMENT_FUSED", "0") != "1"
-                           else "k_augment_groups+" + kernel_name)
-        if op == "onehot_bcl":
-            kernel_name = "k_tokens_bp8<raw>+k_expand_bcl" if (P >= 128 and P % 16 == 0 and out_bytes >= (256 << 20)) else "k_tokenize_chunks<onehot bcl>"
+        traffic = traffic_of(args.workload)
+        kernel_name = b.kernel_name()
         res = {
             "metric": baseline_metric() if args.workload == "cfg3"
                       else "Gseq-chars/s + GB/s written (%s)" % args.workload,
@@ -536,10 +809,7 @@ def main():
             "ms_per_step": wall_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"f": "f32", "B": "u8"}.get(destchar, destchar), "data": "synthetic",
-            "config": {"workload": "%s: %s %s, %d seqs/GPU len~U(%d,%d), padlen %d, C=%d, %s output %s" % (
-                args.workload, cfg["key"], {"onehot": "batch_onehot_encode", "tokenize": "batch_tokenize", "onehot_bcl": "batch_onehot_encode(layout=bcl)"}.get(op, "BLOSUM62 augment + batch_tokenize"), n,
-                cfg["lo"], cfg["hi"], P, C, str(tdt).replace("torch.", ""),
-                "(P,B,C)" if op == "onehot" else "(B,C,P)" if op == "onehot_bcl" else ("(B,P)" if batch_first else "(P,B)")),
+            "config": {"workload": b.describe(),
                 "sequences_per_gpu": n, "padlen": P, "channels": C, "input_chars_per_gpu": total,
                 "output_bytes_per_gpu": out_bytes,
                 "sharding": ("by sequence, no collective; weak scaling: every rank encodes its own %d-sequence batch" % n)
@@ -566,8 +836,13 @@ def main():
                          "copy_mix_yardstick_gbps": mix_gbps,
                          "frac_of_copy_mix": (achieved / mix_gbps) if mix_gbps else None},
         }
+        res["check"] = check
+        # which step() calls of this process were the K timed ones (the rocprofv3 summaries under profiles/ keep exactly those dispatches)
+        res["timed"] = {"first_step_index": first_timed_step, "steps": args.steps, "step_calls_total": step_calls_main}
         if sustained is not None:
             res["sustained"] = sustained
+        if cold is not None:
+            res["cold"] = cold
         if op == "augment+tokenize":
             # the one-launch form: chunk waves that gave up waiting for their rows' augmentation (expected: 0; then the output is wrong)
             torch.cuda.synchronize()
@@ -582,6 +857,17 @@ def main():
             res["e2e"] = e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, args.cpu_threads or None)
+        # every other BASELINE workload in the same line (N = 1; default: only beside the headline workload)
+        which = "none" if args.no_configs else (args.configs if args.configs is not None else ("all" if args.workload == "cfg3" else "none"))
+        names = DEFAULT_CONFIGS if which == "all" else [] if which == "none" else [w for w in which.split(",") if w]
+        if world == 1 and names:
+            del b, d_chars, d_offs, out, step
+            torch.cuda.empty_cache()
+            res["configs"] = {}
+            for wname in names:
+                if wname not in WORKLOADS:
+                    raise SystemExit("unknown workload in --configs: %r" % wname)
+                res["configs"][wname] = run_config(wname, lib, dev, stream, args.steps, args.warmup)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -329,7 +329,7 @@ constexpr bool kLabs = true;
 constexpr bool kLabs = false;
 #endif
 std::mutex g_knob_mu;                          // writers only
-std::atomic<const Tuning *> g_tuning{nullptr};  // the published snapshot (old ones are never freed: a handful per process)
+std::atomic<const Tuning *> g_tuning{nullptr};  // the published snapshot (superseded ones: see set_tuning)
 
 const Tuning *initial_tuning() {  // defaults, then BSQ_<NAME> from the environment -- once
     Tuning *t = new Tuning();
@@ -490,12 +490,21 @@ int get_tuning(const char *name) {
 bool set_tuning(const char *name, int value) {
     const KnobInfo *k = find_knob(name);
     if (!k || (k->labs && !kLabs)) return false;
-    const Tuning &cur = tuning();
+    (void)tuning();  // (the initial snapshot exists)
     std::lock_guard<std::mutex> lock(g_knob_mu);
-    Tuning *next = new Tuning(*g_tuning.load(std::memory_order_acquire));
-    (void)cur;
+    const Tuning *cur = g_tuning.load(std::memory_order_acquire);
+    if (cur->*(k->field) == value) return true;  // nothing to publish (the `finally: set(knob, 0)` of every test)
+    Tuning *next = new Tuning(*cur);
     next->*(k->field) = value;
     g_tuning.store(next, std::memory_order_release);
+    // A launcher holds its snapshot for the microseconds of one call.  Superseded snapshots are freed once kRetired newer ones have
+    // been published (a randomised harness sets knobs thousands of times; round 3 leaked every one of them).
+    constexpr size_t kRetired = 1024;
+    static const Tuning *retired[kRetired] = {};
+    static size_t head = 0;
+    delete retired[head];
+    retired[head] = cur;
+    head = (head + 1) % kRetired;
     return true;
 }
 

@@ -397,7 +397,10 @@ struct FusedWait {            // what a token wave of the fused launch needs fro
     uint32_t epoch;
     uint32_t spins, naps;     // polls before a wave gives up; s_sleep(2) per poll
 };
-template <bool NT, bool FLAGS>
+// EOSV: the token at position bos + L (EOS) differs from the fill behind it.  Without it (cfg2, cfg5: no EOS) a store is
+// bfi(keep, tokens, fill) -- no constant half of the rule entry: 16 registers and four LDS reads less per lane, 66 -> <= 64 VGPRs =
+// EIGHT waves per SIMD instead of seven, which is what the cold-input regime (every character from HBM) is short of.
+template <bool NT, bool FLAGS, bool EOSV = true>
 __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                  uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR, uint32_t magic,
                                                  uint32_t shift, int32_t room, uint32_t packed, const T8Tab &tab, const T8Rules &rules,
@@ -476,7 +479,7 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
     {
         if (lane < 18) {
             s_rule[wave][0][lane] = rules.keep[lane];
-            s_rule[wave][1][lane] = rules.cst[lane];
+            if constexpr (EOSV) s_rule[wave][1][lane] = rules.cst[lane];
         }
         // wave-private: LDS operations of one wave execute in order, only the compiler must not reorder them
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -539,14 +542,15 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
         for (int u = 0; u < 4; ++u) cw[u] = u32x4u{0x41434447u, 0x61636474u, 0x4B4C4D4Eu, 0x50515253u};
     }
     // rule entries of the four stores: LDS reads that run beside the character loads
-    uint4 keep[4], cst[4];
+    uint4 keep[4], cst[EOSV ? 4 : 1];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int32_t dd = L[u] - j0[u];
         const int32_t idx = (dd < -1 ? -1 : (dd > 16 ? 16 : dd)) + 1;
         keep[u] = s_rule[wave][0][idx];
-        cst[u] = s_rule[wave][1][idx];
+        if constexpr (EOSV) cst[u] = s_rule[wave][1][idx];
     }
+    const uint32_t fill_w = (packed >> 24) * 0x01010101u;  // !EOSV
     if (__builtin_amdgcn_ballot_w64(slow[0] | slow[1] | slow[2] | slow[3]) != 0) {  // first / last bytes of the buffer: never read outside it
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -580,21 +584,28 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
             }
         }
         uint4 o;
-        o.x = (w[0] & keep[u].x) | cst[u].x;
-        o.y = (w[1] & keep[u].y) | cst[u].y;
-        o.z = (w[2] & keep[u].z) | cst[u].z;
-        o.w = (w[3] & keep[u].w) | cst[u].w;
+        if constexpr (EOSV) {
+            o.x = (w[0] & keep[u].x) | cst[u].x;
+            o.y = (w[1] & keep[u].y) | cst[u].y;
+            o.z = (w[2] & keep[u].z) | cst[u].z;
+            o.w = (w[3] & keep[u].w) | cst[u].w;
+        } else {  // v_bfi_b32: kept bytes from the tokens, the rest fill
+            o.x = (w[0] & keep[u].x) | (fill_w & ~keep[u].x);
+            o.y = (w[1] & keep[u].y) | (fill_w & ~keep[u].y);
+            o.z = (w[2] & keep[u].z) | (fill_w & ~keep[u].z);
+            o.w = (w[3] & keep[u].w) | (fill_w & ~keep[u].w);
+        }
         if (j0[u] < 0) o.x = (o.x & ~0xFFu) | bos_id;  // position 0 with BOS
         if (live[u]) store16<NT>(dst + u * 1024, o);
     }
 }
 
-template <bool NT>
+template <bool NT, bool EOSV>
 __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                               uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
                                                               uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
                                                               T8Tab tab, T8Rules rules) {
-    tokens_fast_body<NT, false>(blockIdx.x, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, FusedWait{});
+    tokens_fast_body<NT, false, EOSV>(blockIdx.x, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, FusedWait{});
 }
 
 // BASELINE config 5 as ONE launch (round 3): BLOSUM62 augmentation (bsq_augment.hip) and the (B,P) int8 token matrix.  The first
@@ -1154,12 +1165,13 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
             }
         }
         if (fuse) return BSQ_OK;  // the caller runs the two launches (fused_taken stays false; nothing was launched)
-        if (nt)
-            hipLaunchKernelGGL((k_tokens_bp8_fast<true>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks),
-                               uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules);
-        else
-            hipLaunchKernelGGL((k_tokens_bp8_fast<false>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks),
-                               uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules);
+        const bool eosv = (c.at_len_v & 0xFFu) != (c.fill_v & 0xFFu);
+#define BSQ_T8F(NTV, EV)                                                                                                                 \
+    hipLaunchKernelGGL((k_tokens_bp8_fast<NTV, EV>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks), uint32_t(B), \
+                       c.ppr, magic, shift, c.room, packed, tab, rules)
+        if (nt) { if (eosv) BSQ_T8F(true, true); else BSQ_T8F(true, false); }
+        else { if (eosv) BSQ_T8F(false, true); else BSQ_T8F(false, false); }
+#undef BSQ_T8F
         const hipError_t ef = hipGetLastError();
         if (ef != hipSuccess) return set_hip_error("k_tokens_bp8_fast", ef);
         return BSQ_OK;

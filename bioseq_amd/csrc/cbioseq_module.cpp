@@ -90,10 +90,16 @@ class WorkerPool {
             ++generation_;
         }
         cv_.notify_all();
+        // whatever fn(0) does on the caller -- return or throw --, the workers still hold &fn: wait for them before unwinding
+        struct Drain {
+            WorkerPool *p;
+            ~Drain() {
+                std::unique_lock<std::mutex> l(p->mu_);
+                p->done_.wait(l, [this] { return p->pending_ == 0; });
+                p->fn_ = nullptr;
+            }
+        } drain{this};
         fn(0);
-        std::unique_lock<std::mutex> l(mu_);
-        done_.wait(l, [this] { return pending_ == 0; });
-        fn_ = nullptr;
     }
 
   private:

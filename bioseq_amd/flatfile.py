@@ -91,6 +91,7 @@ class FlatFile:
             maxseqlen = self._longest
         self._maxseqlen = int(maxseqlen)
         self._dev = {}
+        self._top_cum = None
 
     # ---- reference surface ------------------------------------------------------------------
     def nseqs(self):
@@ -173,8 +174,8 @@ class FlatFile:
         """Packed batch (chars, offsets) of the sequences `indices` -- any order, repeats allowed -- rebuilt ON THE
         DEVICE from the uploaded store (`bsq_gather_packed_device`): what a shuffling sampler needs, with no host gather
         and no upload of characters.  `indices`: an int64 tensor already on `device` (nothing crosses PCIe at all) or a
-        host list / array (range-checked here, 8 bytes per index uploaded).  The returned `chars` tensor is
-        n * (longest sequence) bytes long; only its first offsets[-1] bytes belong to the batch."""
+        host list / array (range-checked here, 8 bytes per index uploaded).  The returned `chars` tensor may be longer
+        than the batch (device indices: sized by a bound); only its first offsets[-1] bytes belong to it."""
         import ctypes
         import torch
         from . import capi
@@ -192,19 +193,40 @@ class FlatFile:
                 raise IndexError("Accessing sequence out of range")
             idx = torch.from_numpy(host).to(dev)
         n = idx.numel()
-        capacity = n * self._longest
-        out_chars = torch.empty(max(capacity, 1), dtype=torch.uint8, device=dev)
+        # Size of the batch's characters.  Host indices: exact (the lengths are known here).  Device indices: the n longest
+        # sequences of the store bound every list WITHOUT repeats (a sampler's permutation) -- one 35 000-residue outlier no longer
+        # makes every 4096-sequence batch 143 MB --; a list with repeats can exceed that, the kernel reports the overflow, and the
+        # call is repeated with the unconditional bound n * longest (unchecked lists, validate=False, start there).
+        if not on_device:
+            capacity = int((self._offsets[host + 1] - self._offsets[host]).sum()) if n else 0
+        elif validate and n <= self._n:
+            capacity = int(self._top_lengths_cumsum()[n - 1]) if n else 0
+        else:
+            capacity = n * self._longest
         out_offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
         status = torch.empty(1, dtype=torch.int64, device=dev)
-        with torch.cuda.device(dev):
-            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), self._n, idx.data_ptr(), n,
-                                                    out_chars.data_ptr(), capacity, out_offs.data_ptr(), status.data_ptr(), stream))
-        if on_device and validate:  # the only synchronising step, and only for index tensors nobody has checked
-            bad = int(status.item())
-            if bad >= 0:
-                raise IndexError("Accessing sequence out of range (position %d of the index list)" % (bad % max(n, 1)))
-        return out_chars, out_offs
+        while True:
+            out_chars = torch.empty(max(capacity, 1), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), self._n, idx.data_ptr(), n,
+                                                        out_chars.data_ptr(), capacity, out_offs.data_ptr(), status.data_ptr(), stream))
+            if not (on_device and validate):  # (host lists were range-checked above and sized exactly)
+                break
+            bad = int(status.item())  # the only synchronising step, and only for index tensors nobody has checked
+            if bad < 0:
+                break
+            if bad >= n and capacity < n * self._longest:  # overflow of the no-repeats bound: the list repeats long sequences
+                capacity = n * self._longest
+                continue
+            raise IndexError("Accessing sequence out of range (position %d of the index list)" % (bad % max(n, 1)))
+        return (out_chars[:capacity] if not on_device else out_chars), out_offs
+
+    def _top_lengths_cumsum(self):
+        """cumsum of the store's sequence lengths in descending order: entry n - 1 bounds the characters of any n distinct sequences."""
+        if self._top_cum is None:
+            self._top_cum = np.cumsum(np.sort(np.diff(self._offsets))[::-1], dtype=np.int64)
+        return self._top_cum
 
     def batch_tokenize(self, tokenizer, start=0, stop=None, padlen=None, destchar="B", batch_first=True, device=None):
         """`tokenizer.batch_tokenize(ff.access(start, stop), ...)` without materialising the sequences

@@ -296,7 +296,42 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
     tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt.value]
     dev = torch.device(device)
     shape = {"tokens_bf": (int(B), padlen), "bcl": (int(B), C, padlen), "tbc": (padlen, int(B), C)}[layout]
-    full = open_root_buffer(shape, tdt, dev, root, group)
+    # Everything a rank can fail at on its own (mapping the root's memory, an invalid shard, an encode error) is caught and
+    # agreed on by ALL ranks below: one bad shard must raise everywhere, not leave the others waiting in a barrier.
+    failure = None
+    full = None
+    try:
+        full = open_root_buffer(shape, tdt, dev, root, group)
+    except Exception as ex:  # (the broadcast inside has completed or failed on every rank alike; the mapping is per rank)
+        failure = ex
+    try:
+        if failure is None:
+            _store_shard(lib, desc, dt, full, shard_chars, shard_offsets, b0, B, padlen, layout, dev, validate)
+        torch.cuda.synchronize(dev)   # this rank's stores have left its GPU ...
+    except Exception as ex:
+        failure = failure or ex
+    # ... and every rank's have -- or some rank failed: MIN over an ok flag (also the barrier that orders the stores)
+    ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32,
+                      device=dev if str(dist.get_backend(group)) == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        del full
+        if failure is not None:
+            raise failure
+        raise RuntimeError("store_shard_into_root: another rank failed to encode or store its shard; the root's buffer is incomplete")
+    if rank != root:
+        del full
+        return None
+    return full
+
+
+def _store_shard(lib, desc, dt, full, shard_chars, shard_offsets, b0, B, padlen, layout, dev, validate):
+    """This rank's part of `store_shard_into_root`: the ordinary encode kernels with the root's (mapped) slab as their output."""
+    import ctypes
+
+    import torch
+
+    from . import capi
     ch = torch.as_tensor(shard_chars).to(dev)
     of = torch.as_tensor(shard_offsets).to(dev).to(torch.int64).contiguous()
     nb = int(of.shape[0]) - 1
@@ -318,12 +353,6 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
             else:  # the tiled kernel with the root tensor's row pitch (bsq_onehot_block_device)
                 capi.check(lib.bsq_onehot_block_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), None, nb, padlen, dt,
                                                        slab.data_ptr(), int(B), stream))
-    torch.cuda.synchronize(dev)   # this rank's stores have left its GPU ...
-    dist.barrier(group=group)     # ... and every rank's have: the root may read the batch
-    if rank != root:
-        del full
-        return None
-    return full
 
 
 def encode_into_root(tokenizer, chars, offsets, padlen: int, destchar: str, layout: str, device, root: int = 0, group=None):

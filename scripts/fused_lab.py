@@ -24,7 +24,7 @@ def loop_us(fn, n=60, warm=300, reps=4):
 def fused(frac, chain=1):
     def f():
         seed[0] += 1
-        capi.check(lib.bsq_augment_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 1, 0, chain, frac, ctypes.c_uint64(seed[0]), out.data_ptr(), None))
+        capi.check(lib.bsq_augment_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 1, 0, out.data_ptr(), chain, frac, ctypes.c_uint64(seed[0]), None))
     return f
 def tokens(): capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, 1, 0, out.data_ptr(), None))
 def aug(frac):

@@ -1,26 +1,47 @@
 #!/usr/bin/env python3
-"""Copy the per-workload rocprofv3 summaries from gpurun_out/<tag>_<workload>/ into profiles/<tag>/ and rebuild
-profiles/traffic.json: HBM bytes per step = sum over the step's kernels of WRITE_SIZE + 2 x FETCH_SIZE (both in KB,
-separate --pmc passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
-import json, os, shutil, sys, glob
+"""Copy the per-workload rocprofv3 summaries from gpurun_out/<tag>_<workload>/ (scripts/gpu_evidence.sh profile) into
+profiles/<tag>/ and rebuild profiles/traffic.json.
+
+HBM bytes per step = sum over the step's kernels of WRITE_SIZE + 2 x FETCH_SIZE (both in KB, separate --pmc passes; FETCH_SIZE
+doubled as MI355X_MICROARCH.md prescribes for gfx950).  Kernel times are those of the K TIMED steps only (summarize_prof.py:
+kernel_timed_avg_us, kernel_median_us, n_timed), so that algorithmic bytes / SUM kernel_timed_avg_us / 8 TB/s reproduces the
+`frac` that same profiled run printed (`frac_from_trace` vs `frac_printed_under_rocprof`)."""
+import glob
+import json
+import os
+import shutil
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 traffic = {"_note": "HBM bytes per step from separate rocprofv3 --pmc passes (WRITE_SIZE, FETCH_SIZE; units KB), summed over the "
-                    "kernels of one bench step. FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (an upper "
-                    "bound). Sources: profiles/%s/<workload>_summary.json (scripts/evidence_all.sh + scripts/make_traffic.py)." % tag}
-STEP_KERNELS = ("k_augment_tokens_fused", "k_tokens_pb8", "k_tokens_raw", "k_expand_chunks", "k_expand_small", "k_expand_bcl", "k_onehot_tile", "k_onehot_chunks", "k_tokenize_chunks", "k_tokens_bp8",
-                "k_augment", "k_tokenize_rows", "k_tokenize_tile", "k_onehot_rows")
+                    "kernels of one bench step (the K timed steps only). FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for "
+                    "gfx950 (an upper bound). kernel_timed_avg_us: per step, over the K timed steps of the profiled run. Sources: "
+                    "profiles/%s/<workload>_summary.json (scripts/gpu_evidence.sh profile + scripts/make_traffic.py)." % tag}
+old = {}
+try:
+    old = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+except Exception:
+    pass
+STEP_KERNELS = ("k_augment_tokens_fused", "k_tokens_pb8", "k_tokens_raw", "k_expand_chunks", "k_expand_small", "k_expand_bcl", "k_onehot_tile",
+                "k_onehot_chunks", "k_tokenize_chunks", "k_tokens_bp8", "k_augment", "k_tokenize_rows", "k_tokenize_tile", "k_onehot_rows")
+
+
 def short(name):
     for k in STEP_KERNELS:
         if k in name:
             return k
     return None
-for w in ("cfg3", "cfg2", "cfg5", "cfg4f", "cfg4b", "cfg5aug", "cfg3bcl", "cfg2sf", "cfg1oh"):
+
+
+for w in ("cfg3", "cfg3b", "cfg2", "cfg2sf", "cfg5", "cfg5aug", "cfg4f", "cfg4b", "cfg3bcl", "cfg1oh"):
     src = os.path.join(ROOT, "gpurun_out", "%s_%s" % (tag, w))
     sj = os.path.join(src, "summary.json")
     if not os.path.exists(sj):
+        if w in old:
+            traffic[w] = old[w]  # (an earlier round's entry stays until it is re-measured)
         continue
     shutil.copy(sj, os.path.join(dst, "%s_summary.json" % w))
     shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, "%s_summary.txt" % w))
@@ -30,31 +51,29 @@ for w in ("cfg3", "cfg2", "cfg5", "cfg4f", "cfg4b", "cfg5aug", "cfg3bcl", "cfg2s
     if os.path.exists(bt):
         shutil.copy(bt, os.path.join(dst, "%s_bench_under_rocprof.json" % w))
     s = json.load(open(sj))
-    entry = {"WRITE_SIZE_KB": {}, "FETCH_SIZE_KB": {}, "kernel_avg_us": {}}
-    algo = None
-    try:
-        algo = json.loads(open(bt).read().strip().splitlines()[-1])["roofline"]["algorithmic_bytes_per_launch"]
-    except Exception:
-        pass
+    entry = {"WRITE_SIZE_KB": {}, "FETCH_SIZE_KB": {}, "kernel_timed_avg_us": {}, "kernel_median_us": {}, "n_timed": {}, "source": "profiles/%s" % tag}
     for ctr in ("WRITE_SIZE", "FETCH_SIZE"):
         for name, v in s.get(ctr, {}).items():
             k = short(name)
-            if k:
-                entry[ctr + "_KB"][k] = entry[ctr + "_KB"].get(k, 0.0) + v["avg"]
+            if k and "timed_avg_per_step" in v:  # step kernels only (the untimed check's kernels are not)
+                entry[ctr + "_KB"][k] = entry[ctr + "_KB"].get(k, 0.0) + v["timed_avg_per_step"]
     for name, v in s.get("kernel_trace", {}).items():
         k = short(name)
-        if k:
-            entry["kernel_avg_us"][k] = v["avg_ns"] / 1e3
-    if w == "cfg5aug" and "k_augment_tokens_fused" in entry["WRITE_SIZE_KB"]:
-        # the step is ONE launch; bench.py's untimed correctness check tokenises the mutated batch once more with k_tokens_bp8_fast
-        for ctr in ("WRITE_SIZE_KB", "FETCH_SIZE_KB", "kernel_avg_us"):
-            entry[ctr].pop("k_tokens_bp8", None)
+        if k and "kernel_timed_avg_us" in v:
+            entry["kernel_timed_avg_us"][k] = entry["kernel_timed_avg_us"].get(k, 0.0) + v["kernel_timed_avg_us"]
+            entry["kernel_median_us"][k] = v["kernel_median_us"]
+            entry["n_timed"][k] = v["n_timed"]
     wr, fe = sum(entry["WRITE_SIZE_KB"].values()), sum(entry["FETCH_SIZE_KB"].values())
     if wr:
         entry["hbm_bytes_per_launch"] = int((wr + 2 * fe) * 1024)
         entry["hbm_bytes_per_launch_fetch_undoubled"] = int((wr + fe) * 1024)
-    if algo:
-        entry["algorithmic_bytes_per_launch"] = algo
+    rc = s.get("roofline_check")
+    if rc:
+        entry["algorithmic_bytes_per_launch"] = rc["algorithmic_bytes_per_launch"]
+        entry["frac_from_trace"] = rc["frac_from_trace"]
+        entry["frac_printed_under_rocprof"] = rc["frac_printed"]
+        if wr:
+            entry["traffic_over_algorithmic"] = entry["hbm_bytes_per_launch"] / rc["algorithmic_bytes_per_launch"]
     traffic[w] = entry
-    print(w, entry)
+    print(w, json.dumps(entry))
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)

@@ -41,6 +41,22 @@ def main():
                 ok = ok and got.cpu().numpy().tobytes() == ora.onehot_packed(chars, offs, P, "f").tobytes()
             del got
             dist.barrier()
+    # ONE rank holds a broken shard (offsets that run past its characters): EVERY rank raises -- the failing one its own error, the
+    # others "another rank failed" -- and nobody is left waiting in a barrier
+    B = 64
+    chars, offs = synth.synth_packed(5, B, 0, 100, synth.DIRTY)
+    tok = bioseq_amd.Tokenizer("AMINO20", 1, 1, 1)
+    b0, _ = sharding.shard_bounds(B, world, rank)
+    c, o = sharding.shard_packed(chars, offs, world, rank)
+    if rank == world - 1:
+        o = np.array(o, copy=True)
+        o[-1] += 10 ** 6
+    try:
+        sharding.store_shard_into_root(tok, c, o, b0, B, 112, "b", "tokens_bf", dev, 0)
+        ok = False
+    except RuntimeError as ex:
+        ok = ok and (("another rank failed" in str(ex)) == (rank != world - 1))
+    dist.barrier()
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
