@@ -241,8 +241,9 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
                     int64_t B, int64_t P, int32_t bos, int32_t eos, size_t out_bytes, void *out,
                     bsq_space out_space, void *hip_stream, int64_t *first_bad, Launch launch) {
     if (first_bad) *first_bad = -1;
-    if (!d || !offsets || !out || B < 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer or B < 0");
+    if (!d || B < 0 || (B > 0 && (!offsets || !out))) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer or B < 0");
     if (P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "batch tokenize requires padlen is provded.");
+    if (B == 0) return BSQ_OK;  // an empty batch (e.g. a rank without sequences): nothing to encode, nothing to write
     int64_t bad = -1;
     bsq_status st = bsq_validate_lengths(offsets, B, P, bos, eos, &bad);
     if (first_bad) *first_bad = bad;

@@ -1650,7 +1650,8 @@ uint64_t one_bits_of(bsq_dtype t) {
 
 bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                        const uint8_t *mask, int64_t B, int64_t P, void *out) {
-    if (!d || !offsets || !out || B < 0 || P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
+    if (!d || B < 0 || P <= 0 || (B > 0 && (!offsets || !out)))  // (an EMPTY batch -- a rank without sequences -- has nothing to point at)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
     if (P > (int64_t(1) << 30)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "padlen > 2^30 is not supported");
     for (int i = 0; i < 256; ++i) k.lut[i] = d->lut[i];
     k.desc = d;
@@ -2331,7 +2332,7 @@ bsq_status bsq_onehot_from_raw_tokens_device(const uint8_t *tokens, int64_t pitc
                                              bsq_dtype t, void *out, void *hip_stream) {
     const size_t sz = bsq_dtype_size(t);
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
-    if (!tokens || !out || B < 0 || P <= 0 || C <= 0 || C > 250 || pitch < B)
+    if (B < 0 || P <= 0 || C <= 0 || C > 250 || pitch < B || (B > 0 && (!tokens || !out)))
         return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, bad shape or pitch < B");
     if (B == 0) return BSQ_OK;
     if (reinterpret_cast<uintptr_t>(out) % sz) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output is not aligned to its element size");
@@ -2515,7 +2516,8 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
 bsq_status bsq_onehot_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                      const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                                      void *hip_stream) {
-    if (!d || !offsets || !out || B < 0 || P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
+    if (!d || B < 0 || P <= 0 || (B > 0 && (!offsets || !out)))  // (an EMPTY batch -- a rank without sequences -- has nothing to point at)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
     if (B == 0) return BSQ_OK;
     GParams g;
     fill_generic(g, d, chars, offsets, mask_or_null, B, P, 0, out);
@@ -2574,7 +2576,8 @@ void bsq_fused_status_clear(void) { bsq_internal::fused_failures_clear(); }
 bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                        int64_t B, int64_t P, int32_t batch_first, bsq_dtype t, void *out,
                                        void *hip_stream) {
-    if (!d || !offsets || !out || B < 0 || P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
+    if (!d || B < 0 || P <= 0 || (B > 0 && (!offsets || !out)))  // (an EMPTY batch -- a rank without sequences -- has nothing to point at)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
     if (B == 0) return BSQ_OK;
     GParams g;
     fill_generic(g, d, chars, offsets, nullptr, B, P, batch_first != 0, out);

@@ -1,0 +1,76 @@
+"""Worker of tests/test_multi_gpu.py: one rank of an N-rank job, ONE GPU PER RANK, backend nccl (= RCCL over xGMI).  Every whole-batch
+assembly of bioseq_amd.sharding on DEVICE tensors produced by the HIP kernels -- all_gather forms, grouped point-to-point
+(`gather_direct`, to a root and to every rank), token matrices + local expansion (`onehot_gathered`), and the encode kernels storing
+straight into the root's IPC-mapped buffer (`store_shard_into_root`, three layouts) -- for equal, ragged and EMPTY shards, each result
+compared bit for bit with the CPU oracle's encode of the whole batch.  Prints MULTI_GPU_OK on rank 0."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import bioseq_amd
+    from bioseq_amd import sharding, synth
+    from oracle import oracle as O
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    # BSQ_TEST_BACKEND=gloo: the same script with the ranks SHARING one GPU and the shards crossing the process boundary as host
+    # tensors (gloo moves no device memory) -- a rehearsal of this worker's own logic on a 1-GPU box, not a test of RCCL
+    nccl = os.environ.get("BSQ_TEST_BACKEND", "nccl") == "nccl"
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % (torch.cuda.device_count() if not nccl else 1 << 30))
+    torch.cuda.set_device(dev)
+    if nccl:
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    ship = (lambda t: t) if nccl else (lambda t: t.cpu())
+    ok = True
+    tok, ora = bioseq_amd.Tokenizer("AMINO20", 1, 1, 1), O.OracleTokenizer("AMINO20", 1, 1, 1)
+    # B: equal shards, ragged shards, fewer sequences than ranks (empty shards), one big batch
+    for B, hi in ((world * 64, 120), (world * 50 + 1, 250), (max(1, world - 1), 60), (20011, 300)):
+        chars, offs = synth.synth_packed(1000 + B, B, 0, hi, synth.DIRTY)
+        P = (hi + 2 + 15) // 16 * 16
+        full_oh = ora.onehot_packed(chars, offs, P, "f")
+        full_bf = ora.tokenize_packed(chars, offs, P, "b", True)
+        full_sf = ora.tokenize_packed(chars, offs, P, "b", False)
+        enc_oh = lambda c, o: ship(tok.onehot_packed(torch.as_tensor(np.ascontiguousarray(c)).to(dev), torch.as_tensor(np.ascontiguousarray(o)).to(dev), P, "f"))
+        enc_bf = lambda c, o: ship(tok.tokenize_packed(torch.as_tensor(np.ascontiguousarray(c)).to(dev), torch.as_tensor(np.ascontiguousarray(o)).to(dev), P, "b", True))
+        enc_sf = lambda c, o: ship(tok.tokenize_packed(torch.as_tensor(np.ascontiguousarray(c)).to(dev), torch.as_tensor(np.ascontiguousarray(o)).to(dev), P, "b", False))
+
+        def same(t, want):
+            return t is not None and (t.is_cuda or not nccl) and t.cpu().numpy().tobytes() == want.tobytes()
+
+        for gather, enc, want in (("onehot", enc_oh, full_oh), ("tokens_bf", enc_bf, full_bf), ("tokens_sf", enc_sf, full_sf),
+                                  ("direct_onehot", enc_oh, full_oh), ("direct_tokens_bf", enc_bf, full_bf), ("direct_tokens_sf", enc_sf, full_sf)):
+            ok = ok and same(sharding.encode_sharded(enc, chars, offs, gather=gather), want)
+        keep_oh = sharding.encode_sharded(enc_oh, chars, offs)
+        keep_bf = sharding.encode_sharded(enc_bf, chars, offs)
+        for root in range(world):
+            r = sharding.gather_direct(keep_oh.contiguous(), 1, B, root)
+            ok = ok and (same(r, full_oh) if rank == root else r is None)
+            r = sharding.gather_direct(keep_bf.contiguous(), 0, B, root)
+            ok = ok and (same(r, full_bf) if rank == root else r is None)
+            for dc, layout, want in (("b", "tokens_bf", full_bf), ("f", "bcl", np.ascontiguousarray(full_oh.transpose(1, 2, 0))), ("f", "tbc", full_oh)):
+                got = sharding.encode_into_root(tok, chars, offs, P, dc, layout, dev, root=root)
+                ok = ok and (same(got, want) if rank == root else got is None)
+                del got
+                dist.barrier()
+        raw_tokens, expand = sharding.device_passes(tok, P, "f", dev)
+        if nccl:
+            ok = ok and same(sharding.onehot_gathered(raw_tokens, expand, chars, offs), full_oh)
+        else:
+            ok = ok and same(sharding.onehot_gathered(lambda c, o: raw_tokens(c, o).cpu(), lambda t: expand(t.to(dev)), chars, offs), full_oh)
+    flag = torch.tensor([1 if ok else 0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print("MULTI_GPU_OK" if int(flag.item()) == 1 else "MULTI_GPU_MISMATCH", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
