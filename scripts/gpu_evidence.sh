@@ -56,34 +56,41 @@ do_profile() {
     timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P/pmc_write" -- python3 "$REPO/bench.py" $A > "$P/bench_pmc_write.json" 2> "$P/pmc_write.err"
     timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P/pmc_fetch" -- python3 "$REPO/bench.py" $A > "$P/bench_pmc_fetch.json" 2> "$P/pmc_fetch.err"
     python3 "$REPO/scripts/summarize_prof.py" "$P" > "$P/summary.txt" 2>&1
+    find "$P/trace" -name "*kernel_stats.csv" -exec cp {} "$P/kernel_stats.csv" \;
+    rm -rf "$P/trace" "$P/pmc_write" "$P/pmc_fetch"   # (per-dispatch CSVs: tens of MB; gpurun copies back at most 64 MiB)
     echo "$w: $(grep -A1 roofline_check "$P/summary.txt" | tail -1 | cut -c1-240)"
   done
 }
 do_sq() {
   for w in "$@"; do
-    P=$REPO/gpurun_out/${TAG}_sq_$w; mkdir -p "$P"; cd /tmp
-    A="--workload $w --no-configs --steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-sustained"
+    P=$REPO/gpurun_out/${TAG}_sq${COLD:+cold}_$w; mkdir -p "$P"; cd /tmp
+    # COLD=1: the cold-input regime (bench.py --cold: thousands of dispatches cycling over > 512 MiB of distinct batches dominate every
+    # average; the copy-mix yardstick runs the same way and is listed beside the kernel)
+    A="--workload $w --no-configs --steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-sustained ${COLD:+--cold}"
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -- python3 "$REPO/bench.py" $A > /dev/null 2> "$P/trace.err"
     timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$P/sq1" -- python3 "$REPO/bench.py" $A > /dev/null 2> "$P/sq1.err"
     timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM --output-format csv -d "$P/sq2" -- python3 "$REPO/bench.py" $A > /dev/null 2> "$P/sq2.err"
     timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum --output-format csv -d "$P/tcc" -- python3 "$REPO/bench.py" $A > /dev/null 2> "$P/tcc.err"
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P/fetch" -- python3 "$REPO/bench.py" $A > /dev/null 2> "$P/fetch.err"
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P/write" -- python3 "$REPO/bench.py" $A > /dev/null 2> "$P/write.err"
     python3 - "$P" <<'PY' > "$P/summary.txt"
 import csv, glob, os, sys
 from collections import defaultdict
 for f in glob.glob(os.path.join(sys.argv[1], "trace", "**", "*kernel_stats.csv"), recursive=True):
     for r in list(csv.DictReader(open(f)))[:6]:
         print("%-90s calls %4s avg %10.2f us  %5s%%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
-for sub in ("sq1", "sq2", "tcc"):
+for sub in ("sq1", "sq2", "tcc", "fetch", "write"):
     for f in glob.glob(os.path.join(sys.argv[1], sub, "**", "*counter_collection.csv"), recursive=True):
         d = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(f)):
             d[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in d.items():
-            if "k_" in k and "fill" not in k and "copy_mix" not in k:
+            if "k_" in k and "fill" not in k and ("copy_mix" not in k or os.environ.get("COLD")):
                 print(k[:100])
                 for c, v in sorted(cs.items()):
                     print("   %-24s avg %.4g (n=%d)" % (c, sum(v) / len(v), len(v)))
 PY
+    rm -rf "$P/trace" "$P/sq1" "$P/sq2" "$P/tcc" "$P/fetch" "$P/write"
     echo "sq $w: $(wc -l < "$P/summary.txt") lines"
   done
 }

@@ -45,8 +45,8 @@ for w in ("cfg3", "cfg3b", "cfg2", "cfg2sf", "cfg5", "cfg5aug", "cfg4f", "cfg4b"
         continue
     shutil.copy(sj, os.path.join(dst, "%s_summary.json" % w))
     shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, "%s_summary.txt" % w))
-    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(dst, "%s_kernel_stats.csv" % w))
+    if os.path.exists(os.path.join(src, "kernel_stats.csv")):
+        shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_kernel_stats.csv" % w))
     bt = os.path.join(src, "bench_trace.json")
     if os.path.exists(bt):
         shutil.copy(bt, os.path.join(dst, "%s_bench_under_rocprof.json" % w))

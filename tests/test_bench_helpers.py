@@ -1,0 +1,70 @@
+"""CPU: the pieces bench.py's untimed correctness checks stand on.
+
+* `bench.fold_device` (torch integer arithmetic, what runs on the GPU) computes the same three 64-bit folds as the numpy definition in
+  tests/golden/make_bench_folds.py, on sizes that are not multiples of 8 and across its chunk boundary;
+* the committed folds (made from the compiled REFERENCE's outputs) are reproduced by the C oracle on the workloads the oracle
+  finishes in seconds -- the fixture is not a number nobody can recompute;
+* every workload bench.py puts into the driver's line has its folds."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def bench():
+    return _load("bsq_bench", os.path.join(ROOT, "bench.py"))
+
+
+def _np_fold(arr):
+    M64 = (1 << 64) - 1
+    b = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    if b.size % 8:
+        b = np.concatenate([b, np.zeros(8 - b.size % 8, dtype=np.uint8)])
+    w = b.view("<u8")
+    x = int(np.bitwise_xor.reduce(w)) if w.size else 0
+    s = int(sum(int(v) for v in w.tolist())) & M64 if w.size < 4096 else None
+    with np.errstate(over="ignore"):
+        s2 = int(w.sum(dtype=np.uint64))
+        ws = int((w * (np.arange(w.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1))).sum(dtype=np.uint64))
+    assert s is None or s == s2
+    return "%016x" % x, "%016x" % s2, "%016x" % ws
+
+
+def test_fold_device_equals_the_numpy_definition(bench):
+    import torch
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 8, 9, 1000, 4093, (1 << 16) + 5):
+        a = rng.integers(0, 256, size=n, dtype=np.uint8)
+        assert bench.fold_device(torch.from_numpy(a)) == _np_fold(a), n
+    f = rng.standard_normal((33, 7, 5)).astype(np.float32)
+    assert bench.fold_device(torch.from_numpy(f)) == _np_fold(f)
+    t = torch.from_numpy(rng.integers(-100, 100, size=(50, 40), dtype=np.int64))
+    assert bench.fold_device(t.t()) == _np_fold(np.ascontiguousarray(t.numpy().T))  # non-contiguous input: folded in C order
+
+
+def test_committed_folds_are_reproduced_by_the_oracle(bench, oracle):
+    from bioseq_amd import synth
+    folds = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_folds.json")))
+    for w in bench.DEFAULT_CONFIGS + ["cfg3", "cfg1oh"]:
+        assert w in folds and {"xor", "sum", "wsum", "nbytes"} <= set(folds[w]), w
+    assert {"mutated_chars", "mutated_sequences"} <= set(folds["cfg5aug"])
+    for w in ("cfg1oh", "cfg2", "cfg2sf", "cfg5"):
+        cfg_name, op, destchar, batch_first = bench.WORKLOADS[w]
+        c = synth.CONFIGS[cfg_name]
+        chars, offs = synth.synth_packed(c["seed"], c["n"], c["lo"], c["hi"], c["letters"])
+        ora = oracle.OracleTokenizer(c["key"], c["eos"], c["bos"], c["padchar"])
+        out = ora.onehot_packed(chars, offs, c["padlen"], destchar, 8) if op == "onehot" else ora.tokenize_packed(chars, offs, c["padlen"], destchar, batch_first, 8)
+        x, s, ws = _np_fold(out)
+        assert (x, s, ws, out.nbytes) == (folds[w]["xor"], folds[w]["sum"], folds[w]["wsum"], folds[w]["nbytes"]), w
