@@ -34,9 +34,11 @@ namespace {
 thread_local std::string t_last_error;
 
 // Grow-only staging buffers of one process (per HIP device).  All *_host calls are serialised by g_mu.
-// The input side is DOUBLE-BUFFERED: two (pinned pack area, device input area, "busy" event) slots used
-// alternately, so the host can gather + pack batch n + 1 while the GPU still copies / encodes batch n
-// (`busy` marks the point after which a slot may be reused).
+// The input side is a ring of kInSlots (pinned pack area, device input area, "busy" event) slots, so the host can gather +
+// pack batch n + 1 while the GPU still copies / encodes batch n (`busy` marks the point after which a slot may be reused: the
+// kernel that read its device area has finished).  THREE slots, not two: with two, pack(n + 2) waits for kernel(n) --
+// pack 0.8 ms, upload 0.7 ms, kernel 0.73 ms on cfg3 then alternate between a free and a stalled call: 1.15 ms per batch
+// back to back (rounds 2-3) instead of the 0.8 ms the slowest stage allows.
 struct InSlot {
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -45,9 +47,10 @@ struct InSlot {
     hipEvent_t busy = nullptr;
     bool busy_pending = false;
 };
+constexpr int kInSlots = 3;
 struct Staging {
     int device = -1;
-    InSlot in[2];
+    InSlot in[kInSlots];
     int next = 0;  // slot the next call packs into
     hipStream_t copy_stream = nullptr;  // uploads run here, so that H2D of batch n + 1 overlaps the encode of batch n
     hipEvent_t uploaded = nullptr;
@@ -264,7 +267,7 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
         if (in_pinned(cand, offsets)) slot = &cand;
     if (!slot) {
         slot = &s.in[s.next];
-        s.next ^= 1;
+        s.next = (s.next + 1) % kInSlots;
         st = wait_idle(*slot);
         if (st != BSQ_OK) return st;
     }
@@ -535,8 +538,8 @@ void *bsq_pinned_scratch(size_t nbytes) {
     std::lock_guard<std::mutex> lock(g_mu);
     Staging *sp = nullptr;
     if (current_staging(&sp) != BSQ_OK) return nullptr;
-    InSlot &s = sp->in[sp->next];  // the slots alternate: the previous batch may still be in flight in the other one
-    sp->next ^= 1;
+    InSlot &s = sp->in[sp->next];  // the slots take turns: the previous batches may still be in flight in the others
+    sp->next = (sp->next + 1) % kInSlots;
     if (wait_idle(s) != BSQ_OK) return nullptr;
     if (nbytes > s.pinned_cap) {
         if (s.pinned) (void)hipHostFree(s.pinned);

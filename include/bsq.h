@@ -245,8 +245,8 @@ bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const in
 
 /* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer): returns a buffer of
  * at least nbytes; pack offsets | chars | mask into it and hand those pointers to the next bsq_*_host call.
- * Two buffers alternate (the call waits until the batch packed two calls ago has left the GPU), so packing
- * batch n + 1 overlaps the copy + encode of batch n; a buffer stays valid until the call after next. */
+ * Three buffers take turns (the call waits until the batch packed three calls ago has left the GPU), so packing
+ * batch n + 1 overlaps the copy + encode of batches n and n - 1; a buffer stays valid until the call after next. */
 void *bsq_pinned_scratch(size_t nbytes);
 /* Free every cached staging buffer of the calling process (tests, shutdown). */
 void bsq_release_staging(void);

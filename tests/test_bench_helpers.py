@@ -68,3 +68,39 @@ def test_committed_folds_are_reproduced_by_the_oracle(bench, oracle):
         out = ora.onehot_packed(chars, offs, c["padlen"], destchar, 8) if op == "onehot" else ora.tokenize_packed(chars, offs, c["padlen"], destchar, batch_first, 8)
         x, s, ws = _np_fold(out)
         assert (x, s, ws, out.nbytes) == (folds[w]["xor"], folds[w]["sum"], folds[w]["wsum"], folds[w]["nbytes"]), w
+
+
+def test_summarizer_keeps_exactly_the_timed_dispatches(tmp_path):
+    """scripts/summarize_prof.py on a synthetic rocprofv3 trace: a step kernel dispatched twice per step (40 steps, the timed ones
+    are steps 10 .. 29 and take 100 ns, all others 1000 ns), a yardstick kernel and an odd one.  Only the timed dispatches enter
+    kernel_timed_avg_us, and algorithmic bytes / that time / 8 TB/s is the recomputed roofline fraction."""
+    import csv
+    import subprocess
+    import sys
+    out = tmp_path / "prof"
+    (out / "trace" / "x").mkdir(parents=True)
+    rows, t = [], 0
+    for step in range(40):
+        for rep in range(2):
+            d = 100 if 10 <= step < 30 else 1000
+            rows.append(dict(Kernel_Name="k_step", Start_Timestamp=t, End_Timestamp=t + d, VGPR_Count=64, SGPR_Count=32, LDS_Block_Size=0,
+                             Scratch_Size=0, Workgroup_Size=256, Grid_Size=1024))
+            t += 2000
+        if step % 7 == 0:
+            rows.append(dict(Kernel_Name="k_fill", Start_Timestamp=t, End_Timestamp=t + 5000, VGPR_Count=8, SGPR_Count=8, LDS_Block_Size=0,
+                             Scratch_Size=0, Workgroup_Size=256, Grid_Size=64))
+            t += 6000
+    with open(out / "trace" / "x" / "1_kernel_trace.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    line = {"roofline": {"algorithmic_bytes_per_launch": 1600, "frac": 0.99}, "timed": {"first_step_index": 10, "steps": 20, "step_calls_total": 40}}
+    (out / "bench_trace.json").write_text("noise\n" + json.dumps(line) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "summarize_prof.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    s = json.load(open(out / "summary.json"))
+    k = s["kernel_trace"]["k_step"]
+    assert k["calls"] == 80 and k["launches_per_step"] == 2 and k["n_timed"] == 40
+    assert abs(k["kernel_timed_avg_us"] - 0.2) < 1e-9 and abs(k["kernel_median_us"] - 0.1) < 1e-9     # 2 launches x 100 ns per step
+    assert "kernel_timed_avg_us" not in s["kernel_trace"]["k_fill"]
+    assert abs(s["roofline_check"]["frac_from_trace"] - 1600 / 0.2e-6 / 8e12) < 1e-12 and s["roofline_check"]["frac_printed"] == 0.99
