@@ -74,6 +74,30 @@ for w in ("cfg3", "cfg3b", "cfg2", "cfg2sf", "cfg5", "cfg5aug", "cfg4f", "cfg4b"
         entry["frac_printed_under_rocprof"] = rc["frac_printed"]
         if wr:
             entry["traffic_over_algorithmic"] = entry["hbm_bytes_per_launch"] / rc["algorithmic_bytes_per_launch"]
+    # the UN-profiled line of the same build on the same box (scripts/gpu_evidence.sh bench).  rocprofv3 serialises dispatches (a gap of
+    # ~10 us around each), so an event pair around K launches of a 16-40 us kernel reads far too long UNDER the profiler
+    # (frac_printed_under_rocprof); the kernel durations of the trace are the ones to hold against the un-profiled event times.
+    ub = os.path.join(ROOT, "gpurun_out", tag, "bench_%s.json" % w)
+    if os.path.exists(ub):
+        try:
+            j = json.loads(open(ub).read().strip().splitlines()[-1])
+            entry["frac_unprofiled_loop"] = j["roofline"]["frac"]
+            entry["frac_unprofiled_sustained"] = (j.get("sustained") or {}).get("frac")
+            if j.get("cold"):
+                entry["cold"] = {k: j["cold"][k] for k in ("batches", "input_bytes_total", "ms_per_step", "frac", "sustained_ms_per_step", "frac_sustained", "copy_mix_ms", "frac_of_copy_mix") if k in j["cold"]}
+            shutil.copy(ub, os.path.join(dst, "bench_%s.json" % w))
+        except Exception:
+            pass
     traffic[w] = entry
     print(w, json.dumps(entry))
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+# the round's other records: the driver's line, bench lines, GPU suite, harness, SQ / TCC counter summaries
+for name in ("bench_default.json", "bench_lines.txt", "gputest.txt", "fuzz.txt"):
+    f = os.path.join(ROOT, "gpurun_out", tag, name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, name))
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_sq*_*"))):
+    w = os.path.basename(d).split("_", 2)[2]
+    kind = "cold_sq_tcc_counters" if "_sqcold_" in os.path.basename(d) else "sq_tcc_counters"
+    if os.path.exists(os.path.join(d, "summary.txt")):
+        shutil.copy(os.path.join(d, "summary.txt"), os.path.join(dst, "%s_%s.txt" % (w, kind)))
