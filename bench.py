@@ -432,7 +432,7 @@ def sustained_loop(b, min_s, steps_floor, loop_ms, stream):
     return out
 
 
-def cold_regime(b, steps, min_s, stream):
+def cold_regime(b, steps, min_s, stream, verify=True):
     """The token workloads with NOTHING of the batch resident in a cache: the same step cycling over NB distinct batches (inputs and
     outputs in their own buffers) whose inputs add up to more than 512 MiB -- twice the 256-MiB Infinity Cache -- so that every
     character and offset comes from HBM, as in a training loop that never encodes one batch twice (bioseq/loaders.py:76-104).
@@ -479,7 +479,9 @@ def cold_regime(b, steps, min_s, stream):
            "sustained_steps": n_sus, "sustained_ms_per_step": sus_ms,
            "frac_sustained": b.algo_bytes / (sus_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     # untimed: every batch once more from its pristine characters, compared with batch 0's output rotated
-    if b.op != "augment+tokenize":
+    if not verify:
+        res["check"] = "none (a lab run with result-changing ablations)"
+    elif b.op != "augment+tokenize":
         for k in range(nb):
             one(k, 0)
         torch.cuda.synchronize()
