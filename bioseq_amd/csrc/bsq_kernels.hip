@@ -627,7 +627,13 @@ __device__ __forceinline__ ChunkCoord chunk_coord(const EParams &p, int64_t k, i
 // really runs on (HW_REG_XCC_ID), and its slot comes from that class's atomic counter (p.claim[class * 32], zeroed
 // before the launch); a class that has run out hands the workgroup on to the next one, so every slot is taken
 // exactly once whatever the placement.  No workgroup waits for another.
-template <typename ST, bool NT, int MATH, int CLAIM = 0>
+// GATE (rows of 24 ... 63 bytes; knob "expand_gate"): every wave first issues ONE agent-scope load -- of the head of the token scratch, a
+// line that is always at the memory side -- and makes its token loads depend on it.  The load means nothing; what it does is pace the
+// waves: the small-row expansion runs at 5 workgroups per CU, all of whose waves otherwise reach their token loads and their 4 KiB of
+// stores in step.  Measured over 24 shapes (profiles/r04/expand_gate_sweep.txt): 28-byte rows (DNA f32: cfg4) +1-2 %, 32-byte rows +5.5 %,
+// 56-byte rows +4.7 %; rows of 64 bytes and more lose 5-7 % (cfg3 0.724 -> 0.774 ms), rows of 20 bytes and less lose 1-4 %: those
+// do not get it.  (Found as a by-product of the one-launch experiment, profiles/r04/onehot_fused_one_launch_lost.txt.)
+template <typename ST, bool NT, int MATH, int CLAIM = 0, bool GATE = false>
 __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     constexpr int PIECE = kChunk;             // bytes per wave
     constexpr int NS = PIECE / 1024;          // 16-byte stores per lane
@@ -667,6 +673,8 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     const int64_t slot = group * 4 + wave_s;
     const int64_t k = static_cast<int64_t>(cls) + 8 * slot;
     if (k >= p.nchunks) return;
+    uint32_t gate = 0;
+    if constexpr (GATE) gate = __hip_atomic_load(reinterpret_cast<const uint32_t *>(p.tok) + (blockIdx.x & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
     const ST one = static_cast<ST>(p.one_bits);
     const ChunkCoord cc = chunk_coord<MATH>(p, k, rowbytes);
@@ -674,6 +682,7 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     const int64_t lo = cc.lo, b_lo = cc.b_lo, t_lo = cc.t_lo;
     const int32_t len = cc.len, skip = cc.skip, nr = cc.nr;
     const uint8_t *tok = p.tok + t_lo * p.Bp + b_lo;
+    if constexpr (GATE) tok += (gate == 0xFEFEFEFDu && p.nchunks < 0) ? 1 : 0;  // never taken: the token loads wait for the gate load
     const int64_t wrap_at = p.B - b_lo;  // rows i >= wrap_at belong to position t_lo + 1 (or later)
     // scatter: row r_lo + i has its one at image byte i*rowbytes - skip + tok*sizeof(ST).
     // NS (1..4) coalesced token loads in flight per step, straight-line per NS: the number of 64-row slots a
@@ -2001,10 +2010,17 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
         return check_launch("k_expand_chunks<div64>");
     }
 #endif
-    if (bsq_internal::nontemporal_stores())
-        hipLaunchKernelGGL((k_expand_chunks<ST, true, 0>), grid, dim3(kThreads), pad, s, e);
-    else
-        hipLaunchKernelGGL((k_expand_chunks<ST, false, 0>), grid, dim3(kThreads), pad, s, e);
+    // knob "expand_gate": 0 automatic (rows of 24 ... 63 bytes), 1 never, 2 always (the scratch holds at least 256 bytes: Bp >= 256)
+    const int gk = bsq_internal::tuning().expand_gate;
+    const int64_t rowb = e.C * int64_t(sizeof(ST));
+    const bool gated = (gk == 2 || (gk == 0 && rowb >= 24 && rowb < 64)) && e.Bp >= 256;
+    if (bsq_internal::nontemporal_stores()) {
+        if (gated) hipLaunchKernelGGL((k_expand_chunks<ST, true, 0, 0, true>), grid, dim3(kThreads), pad, s, e);
+        else hipLaunchKernelGGL((k_expand_chunks<ST, true, 0>), grid, dim3(kThreads), pad, s, e);
+    } else {
+        if (gated) hipLaunchKernelGGL((k_expand_chunks<ST, false, 0, 0, true>), grid, dim3(kThreads), pad, s, e);
+        else hipLaunchKernelGGL((k_expand_chunks<ST, false, 0>), grid, dim3(kThreads), pad, s, e);
+    }
     return check_launch("k_expand_chunks");
 }
 
