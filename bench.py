@@ -544,6 +544,28 @@ def run_config(name, lib, dev, stream, steps, warmup):
         from bioseq_amd import capi
         torch.cuda.synchronize()
         capi.check(lib.bsq_fused_status(None))
+    if name in ("cfg2sf", "cfg3b"):
+        # the reference's DEFAULT call of this entry point, end to end: a Python list in, a numpy array out (tokenize.cpp:65-98:
+        # destchar 'B', batch_first False) -- host scan + pack, H2D, kernel, D2H of the result.  PCIe-inclusive, never a `frac`.
+        import bioseq_amd
+        from bioseq_amd import synth
+        tok = bioseq_amd.Tokenizer(b.cfg["key"], bool(b.cfg["eos"]), bool(b.cfg["bos"]), bool(b.cfg["padchar"]))
+        seqs = synth.unpack(b.chars, b.offsets)
+        call = (lambda: tok.batch_onehot_encode(seqs, padlen=b.P)) if b.op == "onehot" else (lambda: tok.batch_tokenize(seqs, padlen=b.P))
+        r = call()
+        assert isinstance(r, np.ndarray) and r.dtype == np.int8 and r.shape == tuple(b.out.shape)
+        assert fold_device(torch.from_numpy(r)) == (res["check"]["xor"], res["check"]["sum"], res["check"]["wsum"])
+        ts = []
+        for _ in range(6):  # (the previous result is released first: a second 1.3-GB array alive during the call doubles the page faults)
+            del r
+            t1 = time.perf_counter()
+            r = call()
+            ts.append(time.perf_counter() - t1)
+        ts = ts[1:]
+        res["e2e_reference_default_call_ms"] = float(np.median(ts) * 1e3)
+        res["e2e_reference_default_call"] = ("tok.batch_onehot_encode(seqs, padlen)" if b.op == "onehot" else "tok.batch_tokenize(seqs, padlen)") + \
+                                            " -> numpy int8 %r (%.0f MB over PCIe back to the host)" % (tuple(r.shape), r.nbytes / 1e6)
+        del r, seqs
     res["seconds"] = time.perf_counter() - t0
     del b
     torch.cuda.empty_cache()
