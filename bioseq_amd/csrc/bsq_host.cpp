@@ -54,6 +54,7 @@ struct Staging {
     int next = 0;  // slot the next call packs into
     hipStream_t copy_stream = nullptr;  // uploads run here, so that H2D of batch n + 1 overlaps the encode of batch n
     hipEvent_t uploaded = nullptr;
+    hipEvent_t piece[8] = {};  // "piece j of this batch is on the device" (run_host in pieces; created on first use)
     void *d_out = nullptr;
     size_t d_out_cap = 0;
     // device -> pageable host results: ring of pinned bounce slots (see download())
@@ -239,10 +240,59 @@ bsq_status download(Staging &s, void *out, const void *dev_out, size_t nbytes, h
     return BSQ_OK;
 }
 
-template <typename Launch>
+template <typename Block>
+bsq_status run_pieces(Staging &s, InSlot &slot, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask, int64_t B, void *out,
+                      hipStream_t stream, const Block &block) {
+    const size_t total = static_cast<size_t>(offsets[B]);
+    const size_t off_bytes = round_up(size_t(B + 1) * 8, 256);
+    const size_t chr_bytes = round_up(total + 8, 256);
+    bsq_status st = grow_device(&slot.d_in, &slot.d_in_cap, off_bytes + chr_bytes + (mask ? chr_bytes : 0));
+    if (st != BSQ_OK) return st;
+    char *base = static_cast<char *>(slot.d_in);
+    g_upload_bytes.fetch_add(uint64_t(B + 1) * 8 + uint64_t(total) * (mask ? 2 : 1), std::memory_order_relaxed);
+    hipError_t e = hipMemcpyAsync(base, offsets, size_t(B + 1) * 8, hipMemcpyHostToDevice, s.copy_stream);
+    constexpr int kEvents = int(sizeof(s.piece) / sizeof(s.piece[0]));
+    int j = 0;
+    for (int64_t b0 = 0; b0 < B && e == hipSuccess; b0 += block.seqs, ++j) {
+        const int64_t n = B - b0 < block.seqs ? B - b0 : block.seqs;
+        const size_t c0 = size_t(offsets[b0]), c1 = size_t(offsets[b0 + n]);
+        if (block.fill) block.fill(block.ctx, b0, b0 + n);  // (piece j - 1 is on the bus meanwhile)
+        if (c1 > c0) e = hipMemcpyAsync(base + off_bytes + c0, chars + c0, c1 - c0, hipMemcpyHostToDevice, s.copy_stream);
+        if (e == hipSuccess && mask && c1 > c0)
+            e = hipMemcpyAsync(base + off_bytes + chr_bytes + c0, mask + c0, c1 - c0, hipMemcpyHostToDevice, s.copy_stream);
+        hipEvent_t &ev = s.piece[j % kEvents];
+        if (e == hipSuccess && !ev) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ev, s.copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev, 0);
+        if (e != hipSuccess) break;
+        DeviceBatch db;
+        db.offsets = reinterpret_cast<const int64_t *>(base) + b0;
+        db.chars = reinterpret_cast<const uint8_t *>(base + off_bytes);
+        db.mask = mask ? reinterpret_cast<const uint8_t *>(base + off_bytes + chr_bytes) : nullptr;
+        st = block(db, n, static_cast<char *>(out) + size_t(b0) * block.row_bytes, stream);
+        if (st != BSQ_OK) return st;
+    }
+    if (e != hipSuccess) return bsq_internal::set_hip_error("upload in pieces", e);
+    return BSQ_OK;
+}
+
+// A batch in PIECES (the seq-first one-hot with a device result, when nobody is ahead of this call on its stream): the characters go up
+// in `count` slices of `seqs` sequences and the encode of slice j -- a column block of the (P, B, C) tensor -- runs while slice j + 1 is
+// still on the bus.  One call then costs pack + upload + the LAST block's kernel instead of pack + upload + the whole kernel
+// (cfg3 list -> device tensor, synchronous: 2.0-2.1 -> see profiles/r04/host_pieces_lab.txt).  `block` encodes sequences
+// [b0, b0 + n) given the device batch (offsets pointer already advanced to b0) and the address of element (0, b0, 0).
+struct NoPieces {
+    int64_t seqs = 0;
+    size_t row_bytes = 0;
+    bsq_pack_fn fill = nullptr;  // the caller writes the characters of sequences [first, last) into the host buffers on demand
+    void *ctx = nullptr;
+    bsq_status operator()(const struct DeviceBatch &, int64_t, void *, hipStream_t) const { return BSQ_OK; }
+};
+
+template <typename Launch, typename Block = NoPieces>
 bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask,
                     int64_t B, int64_t P, int32_t bos, int32_t eos, size_t out_bytes, void *out,
-                    bsq_space out_space, void *hip_stream, int64_t *first_bad, Launch launch) {
+                    bsq_space out_space, void *hip_stream, int64_t *first_bad, Launch launch, Block block = Block()) {
     if (first_bad) *first_bad = -1;
     if (!d || B < 0 || (B > 0 && (!offsets || !out))) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer or B < 0");
     if (P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "batch tokenize requires padlen is provded.");
@@ -271,8 +321,17 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
         st = wait_idle(*slot);
         if (st != BSQ_OK) return st;
     }
+    if (block.seqs > 0 && out_space == BSQ_SPACE_DEVICE && block.seqs < B) {
+        st = run_pieces(s, *slot, chars, offsets, mask, B, out, stream, block);
+        if (st != BSQ_OK) return st;
+        const hipError_t eb = hipEventRecord(slot->busy, stream);
+        if (eb != hipSuccess) return bsq_internal::set_hip_error("hipEventRecord", eb);
+        slot->busy_pending = true;
+        return BSQ_OK;
+    }
     // Upload on the copy stream (the slot is idle: waited for above or in bsq_pinned_scratch), then make the
     // caller's stream wait for it: the copy overlaps whatever that stream is still running (the previous encode).
+    if (block.fill) block.fill(block.ctx, 0, B);
     DeviceBatch db;
     st = upload(*slot, chars, offsets, mask, B, s.copy_stream, &db);
     if (st != BSQ_OK) return st;
@@ -297,6 +356,28 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
         slot->busy_pending = true;
     }
     return BSQ_OK;
+}
+
+// Sequences per piece for run_host in pieces, or 0 = one upload and one encode.  Knob "host_pieces": 0 automatic, 1 never, N >= 2 that
+// many pieces.  Automatic: 2 ... 8 pieces of ~8 MB of characters when the batch is large (>= 16 384 sequences, >= 4 MB of characters), the result's rows are >= 16
+// bytes (the two-pass kernels take the blocks: pieces are multiples of 4096 sequences, so that every block row is whole 4-KiB chunks of
+// an aligned tensor) and the caller's stream is IDLE -- somebody who keeps the stream busy is measuring throughput, where the host's own
+// work per batch is what counts and one upload is cheaper than four.
+int64_t piece_sequences(int64_t B, size_t nchars, size_t row_bytes, const void *out, hipStream_t stream) {
+    const int knob = bsq_internal::tuning().host_pieces;
+    if (knob == 1 || row_bytes < 16 || reinterpret_cast<uintptr_t>(out) % 4096 != 0) return 0;
+    int64_t count = knob >= 2 ? knob : int64_t(nchars >> 23);  // automatic: ~8 MB of characters per piece, 2 ... 8 pieces
+    if (count < 2) count = 2;
+    if (count > 8) count = 8;
+    if (knob == 0) {
+        if (B < 16384 || nchars < (size_t(4) << 20)) return 0;
+        if (hipStreamQuery(stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+    }
+    const int64_t seqs = (B / count) / 4096 * 4096;
+    return seqs >= 4096 && seqs < B ? seqs : 0;
 }
 
 }  // namespace
@@ -572,6 +653,8 @@ void bsq_release_staging(void) {
         }
         if (s.copy_stream) (void)hipStreamDestroy(s.copy_stream);
         if (s.uploaded) (void)hipEventDestroy(s.uploaded);
+        for (hipEvent_t ev : s.piece)
+            if (ev) (void)hipEventDestroy(ev);
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.bounce) (void)hipHostFree(s.bounce);
         for (hipEvent_t ev : s.slot_done)
@@ -596,14 +679,44 @@ bsq_status bsq_tokenize_host(const bsq_desc *d, const uint8_t *chars, const int6
 bsq_status bsq_onehot_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                            const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                            bsq_space out_space, void *hip_stream, int64_t *first_bad) {
+    return bsq_onehot_host_pieces(d, chars, offsets, mask_or_null, B, P, t, out, out_space, hip_stream, first_bad, nullptr, nullptr);
+}
+
+bsq_status bsq_onehot_host_pieces(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null,
+                                int64_t B, int64_t P, bsq_dtype t, void *out, bsq_space out_space, void *hip_stream,
+                                int64_t *first_bad, bsq_pack_fn fill, void *ctx) {
     const size_t sz = bsq_dtype_size(t);
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
     const size_t C = d ? size_t(bsq_alphabet_size(d)) : 0;
     const size_t out_bytes = (B > 0 && P > 0) ? size_t(P) * size_t(B) * C * sz : 0;
-    return run_host(d, chars, offsets, mask_or_null, B, P, d ? d->bos : 0, d ? d->eos : 0, out_bytes, out,
-                    out_space, hip_stream, first_bad, [&](const DeviceBatch &db, void *dev_out, hipStream_t s) {
+    struct Block {
+        int64_t seqs = 0;
+        size_t row_bytes = 0;
+        bsq_pack_fn fill = nullptr;
+        void *ctx = nullptr;
+        const bsq_desc *d;
+        int64_t B, P;
+        bsq_dtype t;
+        bsq_status operator()(const DeviceBatch &db, int64_t n, void *out_block, hipStream_t s) const {
+            return bsq_onehot_block_device(d, db.chars, db.offsets, db.mask, n, P, t, out_block, B, s);
+        }
+    } block;
+    block.d = d;
+    block.B = B;
+    block.P = P;
+    block.t = t;
+    block.row_bytes = C * sz;
+    block.fill = fill;
+    block.ctx = ctx;
+    block.seqs = out_space == BSQ_SPACE_DEVICE && d && offsets && B > 0
+                     ? piece_sequences(B, size_t(offsets[B]), block.row_bytes, out, static_cast<hipStream_t>(hip_stream))
+                     : 0;
+    return run_host(d, chars, offsets, mask_or_null, B, P, d ? d->bos : 0, d ? d->eos : 0, out_bytes, out, out_space, hip_stream,
+                    first_bad,
+                    [&](const DeviceBatch &db, void *dev_out, hipStream_t s) {
                         return bsq_onehot_device(d, db.chars, db.offsets, db.mask, B, P, t, dev_out, s);
-                    });
+                    },
+                    block);
 }
 
 bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,

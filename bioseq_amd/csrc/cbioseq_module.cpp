@@ -297,7 +297,9 @@ struct Packed {
 
 size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
 
-Packed pack(const Gathered &g, int nthreads) {
+// pack = pack_begin (pinned scratch + offsets) + pack_range over every sequence; batch_onehot_encode hands pack_range to the
+// library instead (bsq_onehot_host_pieces), which calls it piece by piece between its uploads.
+Packed pack_begin(const Gathered &g) {
     Packed p;
     p.B = int64_t(g.items.size());
     const size_t off_bytes = align_up(size_t(p.B + 1) * 8, 64);
@@ -314,6 +316,10 @@ Packed pack(const Gathered &g, int nthreads) {
         acc += int64_t(g.items[size_t(i)].len);
     }
     p.offsets[p.B] = acc;
+    return p;
+}
+
+void pack_range(const Gathered &g, const Packed &p, int64_t first, int64_t last, int nthreads) {
     auto copy_range = [&](int64_t lo, int64_t hi) {
         for (int64_t i = lo; i < hi; ++i) {
             const Item &it = g.items[size_t(i)];
@@ -326,16 +332,21 @@ Packed pack(const Gathered &g, int nthreads) {
             }
         }
     };
-    if (nthreads <= 1 || g.total < (size_t(1) << 20) || p.B < 2 * nthreads) {
-        copy_range(0, p.B);
+    const int64_t n = last - first;
+    if (nthreads <= 1 || size_t(p.offsets[last] - p.offsets[first]) < (size_t(1) << 20) || n < 2 * nthreads) {
+        copy_range(first, last);
     } else {  // workers touch raw bytes only; the caller keeps the GIL so the items stay alive
-        // (Handing finished pieces to the copy engine while the rest is still being packed was built and measured in round 3
-        // -- 1 MiB .. 16 MiB pieces, profiles/r03/e2e_lab1.txt: no gain at any piece size, the pack and the H2D copy compete
-        // for the same host memory bandwidth -- and taken out again.)
-        const int64_t B = p.B;
+        // (Handing finished pieces to the copy engine while the rest is still being packed, WITHOUT encoding the pieces as they
+        // arrive, was built and measured in round 3 -- profiles/r03/e2e_lab1.txt: no gain -- and taken out again; with the
+        // encode of piece j under the upload of piece j + 1 it is what bsq_onehot_host_pieces does: profiles/r04/host_pieces_lab.txt.)
         const int nt = nthreads;
-        pool().parallel_for(nt, [&](int t) { copy_range(B * t / nt, B * (t + 1) / nt); });
+        pool().parallel_for(nt, [&](int t) { copy_range(first + n * t / nt, first + n * (t + 1) / nt); });
     }
+}
+
+Packed pack(const Gathered &g, int nthreads) {
+    const Packed p = pack_begin(g);
+    pack_range(g, p, 0, p.B, nthreads);
     return p;
 }
 
@@ -525,11 +536,27 @@ class Tokenizer {
         const py::ssize_t C = py::ssize_t(bsq_alphabet_size(&desc)), nb = py::ssize_t(g.items.size());
         make_out(out, bcl ? std::vector<py::ssize_t>{nb, C, padlen} : std::vector<py::ssize_t>{padlen, nb, C}, t, device);
         const auto t2 = std::chrono::steady_clock::now();
-        const Packed p = pack(g, nthreads);
+        // Seq-first result on a device: the library asks for the characters piece by piece (pack_range as its fill callback) and
+        // uploads + encodes one piece while the next is packed.  The GIL stays held, as it is during every pack (the items must
+        // stay alive and unchanged); nothing in that call blocks on the GPU.
+        const bool fill = !bcl && out.space == BSQ_SPACE_DEVICE;
+        const Packed p = fill ? pack_begin(g) : pack(g, nthreads);
         const auto t3 = std::chrono::steady_clock::now();
         int64_t bad = -1;
         bsq_status st;
-        {
+        if (fill) {
+            struct Ctx {
+                const Gathered *g;
+                const Packed *p;
+                int nthreads;
+            } ctx{&g, &p, nthreads};
+            st = bsq_onehot_host_pieces(&desc, p.chars, p.offsets, p.mask, p.B, padlen, t, out.ptr, out.space, out.stream, &bad,
+                                      [](void *c, int64_t first, int64_t last) {
+                                          const Ctx *x = static_cast<const Ctx *>(c);
+                                          pack_range(*x->g, *x->p, first, last, x->nthreads);
+                                      },
+                                      &ctx);
+        } else {
             py::gil_scoped_release nogil;
             st = (bcl ? bsq_onehot_bcl_host : bsq_onehot_host)(&desc, p.chars, p.offsets, p.mask, p.B, padlen, t, out.ptr,
                                                                out.space, out.stream, &bad);

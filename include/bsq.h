@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSQ_ABI_VERSION 5
+#define BSQ_ABI_VERSION 6
 
 typedef int32_t bsq_status;
 enum {
@@ -242,6 +242,18 @@ bsq_status bsq_onehot_host(const bsq_desc *d, const uint8_t *chars, const int64_
 bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                                bsq_space out_space, void *hip_stream, int64_t *first_bad);
+
+/* bsq_onehot_host for a caller that PRODUCES the characters on demand (the pybind11 layer copying them out of Python objects):
+ * `offsets` is complete on entry; chars (and the mask) are buffers that `fill(ctx, first, last)` writes for sequences
+ * [first, last).  fill is called on the calling thread, in order, over ranges that cover [0, B) exactly once, and always
+ * before the library reads those bytes.  A large batch with a device result goes up in PIECES: fill(piece j + 1) runs while
+ * piece j is on the bus and the one-hot of piece j (a column block of `out`, bsq_onehot_block_device) runs while piece j + 1
+ * is -- the call costs scan + upload + one piece of packing and of kernel instead of the sum of all four (tuning knob
+ * "host_pieces").  Everything else, and fill == NULL (the buffers are already full), is bsq_onehot_host. */
+typedef void (*bsq_pack_fn)(void *ctx, int64_t first, int64_t last);
+bsq_status bsq_onehot_host_pieces(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null,
+                                int64_t B, int64_t P, bsq_dtype t, void *out, bsq_space out_space, void *hip_stream,
+                                int64_t *first_bad, bsq_pack_fn fill, void *ctx);
 
 /* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer): returns a buffer of
  * at least nbytes; pack offsets | chars | mask into it and hand those pointers to the next bsq_*_host call.

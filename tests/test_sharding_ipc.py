@@ -56,3 +56,42 @@ def test_onehot_written_as_a_column_block_of_a_larger_tensor(gpu, oracle, key, f
         assert (host[:guard] == 7).all() and (host[-guard:] == 7).all(), "wrote outside the tensor"
         assert host[guard:-guard].tobytes() == exp.tobytes(), (key, B, P)
     assert lib.bsq_onehot_block_device(ctypes.byref(desc), c.data_ptr(), o.data_ptr(), None, 10, P, dt, full.data_ptr(), 5, None) != 0   # row_seqs < B
+
+
+@pytest.mark.parametrize("key,flags,dtype", [("AMINO20", (0, 0, 0), "f"), ("DNA", (1, 1, 1), "f"), ("SEB8", (0, 1, 0), "h"), ("AMINO20", (1, 1, 1), "b")])
+def test_column_blocks_made_of_whole_chunks(gpu, oracle, key, flags, dtype):
+    """Blocks of k x 4096 sequences at 4096-sequence boundaries of a 4-KiB aligned tensor go through the two-pass stream with a
+    row gap (rows >= 16 bytes), the ragged last block through the tiles; the offsets are the whole batch's, advanced to the
+    block's first sequence (what the host path in pieces hands over).  Also with the tiled kernel forced."""
+    import ctypes
+    import numpy as np
+    import torch
+    from bioseq_amd import capi, synth
+    lib = capi.load()
+    desc = capi.make_desc(key, *flags)
+    ora = oracle.OracleTokenizer(key, *flags)
+    C = ora.alphabet_size()
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(dtype.encode(), ctypes.byref(dt)))
+    tdt = {0: torch.int8, 1: torch.int16, 4: torch.float32, 5: torch.float64}[dt.value]
+    for B, P, cuts in ((12288, 70, (0, 4096, 12288)), (20000, 33, (0, 8192, 16384, 20000)), (8192, 128, (0, 4096, 8192))):
+        chars, offs = synth.synth_packed(B + P, B, 0, P - 2, synth.DIRTY)
+        exp = ora.onehot_packed(chars, offs, P, dtype)
+        dchars, doffs = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+        for path in (0, 1):
+            capi.check(lib.bsq_tuning_set(b"onehot_path", path))
+            try:
+                guard = 4096 // tdt.itemsize
+                raw = torch.full((P * B * C + 3 * guard,), 7, dtype=tdt, device=gpu)
+                buf = raw[(-raw.data_ptr() % 4096) // tdt.itemsize:][:P * B * C + 2 * guard]  # the caching allocator aligns to 512 only
+                assert buf.data_ptr() % 4096 == 0
+                full = buf[guard:guard + P * B * C].view(P, B, C)
+                for b0, b1 in zip(cuts[:-1], cuts[1:]):
+                    capi.check(lib.bsq_onehot_block_device(ctypes.byref(desc), dchars.data_ptr(), doffs[b0:].data_ptr(), None, b1 - b0, P, dt,
+                                                           full[:, b0:b1].data_ptr(), B, None))
+                torch.cuda.synchronize()
+                host = buf.cpu().numpy()
+            finally:
+                capi.check(lib.bsq_tuning_set(b"onehot_path", 0))
+            assert (host[:guard] == 7).all() and (host[-guard:] == 7).all(), "wrote outside the tensor"
+            assert host[guard:-guard].tobytes() == exp.tobytes(), (key, B, P, path)
