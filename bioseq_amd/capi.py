@@ -96,7 +96,10 @@ def load():
         "bsq_tokenize_host": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, c_int, vp, i64p]),
         "bsq_onehot_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),
         "bsq_onehot_bcl_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),
-        "bsq_onehot_host_pieces": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p, vp, vp]),
+        "bsq_stage_begin": (i32, [i64, sz, i32, vp, vp, vp, vp, vp]),
+        "bsq_stage_upload": (i32, [vp, i64, i64, vp, vp, vp]),
+        "bsq_stage_end": (i32, [vp]),
+        "bsq_stage_piece_hint": (i64, [i64, sz, sz, vp, vp]),
         "bsq_fastx_to_flatfile": (i32, [ctypes.c_char_p, ctypes.c_char_p, i64p, i64p]),
         "bsq_fastx_lengths": (i32, [ctypes.c_char_p, vp, i64, i64p]),
         "bsq_pinned_scratch": (vp, [sz]),

@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <chrono>
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
@@ -118,6 +120,18 @@ bsq_status grow_device(void **buf, size_t *cap, size_t need) {
         return BSQ_OK;
     }
     *cap = want;
+    return BSQ_OK;
+}
+
+bsq_status grow_pinned(InSlot &s, size_t nbytes) {
+    if (nbytes <= s.pinned_cap) return BSQ_OK;
+    if (s.pinned) (void)hipHostFree(s.pinned);
+    s.pinned = nullptr;
+    s.pinned_cap = 0;
+    const size_t want = round_up(nbytes + nbytes / 4, size_t(1) << 20);
+    const hipError_t e = hipHostMalloc(&s.pinned, want, hipHostMallocDefault);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipHostMalloc", e);
+    s.pinned_cap = want;
     return BSQ_OK;
 }
 
@@ -252,25 +266,34 @@ bsq_status run_pieces(Staging &s, InSlot &slot, const uint8_t *chars, const int6
     g_upload_bytes.fetch_add(uint64_t(B + 1) * 8 + uint64_t(total) * (mask ? 2 : 1), std::memory_order_relaxed);
     hipError_t e = hipMemcpyAsync(base, offsets, size_t(B + 1) * 8, hipMemcpyHostToDevice, s.copy_stream);
     constexpr int kEvents = int(sizeof(s.piece) / sizeof(s.piece[0]));
+    static const bool prof = std::getenv("BSQ_PROFILE_HOST") != nullptr;  // per-piece host times on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](auto a, auto b) { return long(std::chrono::duration_cast<std::chrono::microseconds>(b - a).count()); };
     int j = 0;
     for (int64_t b0 = 0; b0 < B && e == hipSuccess; b0 += block.seqs, ++j) {
         const int64_t n = B - b0 < block.seqs ? B - b0 : block.seqs;
         const size_t c0 = size_t(offsets[b0]), c1 = size_t(offsets[b0 + n]);
-        if (block.fill) block.fill(block.ctx, b0, b0 + n);  // (piece j - 1 is on the bus meanwhile)
+        const auto t0 = now();
+        const auto t1 = now();
         if (c1 > c0) e = hipMemcpyAsync(base + off_bytes + c0, chars + c0, c1 - c0, hipMemcpyHostToDevice, s.copy_stream);
         if (e == hipSuccess && mask && c1 > c0)
             e = hipMemcpyAsync(base + off_bytes + chr_bytes + c0, mask + c0, c1 - c0, hipMemcpyHostToDevice, s.copy_stream);
+        const auto t2 = now();
         hipEvent_t &ev = s.piece[j % kEvents];
         if (e == hipSuccess && !ev) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(ev, s.copy_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev, 0);
         if (e != hipSuccess) break;
+        const auto t3 = now();
         DeviceBatch db;
         db.offsets = reinterpret_cast<const int64_t *>(base) + b0;
         db.chars = reinterpret_cast<const uint8_t *>(base + off_bytes);
         db.mask = mask ? reinterpret_cast<const uint8_t *>(base + off_bytes + chr_bytes) : nullptr;
         st = block(db, n, static_cast<char *>(out) + size_t(b0) * block.row_bytes, stream);
         if (st != BSQ_OK) return st;
+        if (prof)
+            std::fprintf(stderr, "[bsq host] piece %d: pack %ld us, hipMemcpyAsync %ld us, event + wait %ld us, launches %ld us\n", j, us(t0, t1),
+                         us(t1, t2), us(t2, t3), us(t3, now()));
     }
     if (e != hipSuccess) return bsq_internal::set_hip_error("upload in pieces", e);
     return BSQ_OK;
@@ -284,8 +307,6 @@ bsq_status run_pieces(Staging &s, InSlot &slot, const uint8_t *chars, const int6
 struct NoPieces {
     int64_t seqs = 0;
     size_t row_bytes = 0;
-    bsq_pack_fn fill = nullptr;  // the caller writes the characters of sequences [first, last) into the host buffers on demand
-    void *ctx = nullptr;
     bsq_status operator()(const struct DeviceBatch &, int64_t, void *, hipStream_t) const { return BSQ_OK; }
 };
 
@@ -331,7 +352,6 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
     }
     // Upload on the copy stream (the slot is idle: waited for above or in bsq_pinned_scratch), then make the
     // caller's stream wait for it: the copy overlaps whatever that stream is still running (the previous encode).
-    if (block.fill) block.fill(block.ctx, 0, B);
     DeviceBatch db;
     st = upload(*slot, chars, offsets, mask, B, s.copy_stream, &db);
     if (st != BSQ_OK) return st;
@@ -365,7 +385,9 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
 // work per batch is what counts and one upload is cheaper than four.
 int64_t piece_sequences(int64_t B, size_t nchars, size_t row_bytes, const void *out, hipStream_t stream) {
     const int knob = bsq_internal::tuning().host_pieces;
-    if (knob == 1 || row_bytes < 16 || reinterpret_cast<uintptr_t>(out) % 4096 != 0) return 0;
+    if (knob == 1) return -1;  // (the stage API's callers read < 0 as "no staging at all": the whole-batch path of rounds 1-3)
+    // row_bytes == 0: the blocks of the result are contiguous (batch-first tokens, channels-first one-hot) -- any split will do
+    if (row_bytes != 0 && (row_bytes < 16 || reinterpret_cast<uintptr_t>(out) % 4096 != 0)) return 0;
     int64_t count = knob >= 2 ? knob : int64_t(nchars >> 23);  // automatic: ~8 MB of characters per piece, 2 ... 8 pieces
     if (count < 2) count = 2;
     if (count > 8) count = 8;
@@ -622,19 +644,109 @@ void *bsq_pinned_scratch(size_t nbytes) {
     InSlot &s = sp->in[sp->next];  // the slots take turns: the previous batches may still be in flight in the others
     sp->next = (sp->next + 1) % kInSlots;
     if (wait_idle(s) != BSQ_OK) return nullptr;
-    if (nbytes > s.pinned_cap) {
-        if (s.pinned) (void)hipHostFree(s.pinned);
-        s.pinned = nullptr;
-        s.pinned_cap = 0;
-        const size_t want = round_up(nbytes + nbytes / 4, size_t(1) << 20);
-        const hipError_t e = hipHostMalloc(&s.pinned, want, hipHostMallocDefault);
-        if (e != hipSuccess) {
-            bsq_internal::set_hip_error("hipHostMalloc", e);
-            return nullptr;
-        }
-        s.pinned_cap = want;
-    }
-    return s.pinned;
+    return grow_pinned(s, nbytes) == BSQ_OK ? s.pinned : nullptr;
+}
+
+/* ---- staged batches (bsq.h): the slot of the ring is owned from bsq_stage_begin to bsq_stage_end (g_mu held) */
+struct bsq_stage {
+    std::unique_lock<std::mutex> lock;
+    Staging *s = nullptr;
+    InSlot *slot = nullptr;
+    hipStream_t stream = nullptr;
+    int64_t max_seqs = 0;
+    size_t max_chars = 0;
+    bool with_mask = false;
+    int64_t *h_offsets = nullptr;
+    uint8_t *h_chars = nullptr, *h_mask = nullptr;
+    char *d_base = nullptr;
+    size_t d_off_bytes = 0, d_chr_bytes = 0;
+    int64_t uploaded = 0;  // sequences [0, uploaded) are on their way
+    int pieces = 0;
+};
+
+bsq_status bsq_stage_begin(int64_t max_seqs, size_t max_chars, int32_t with_mask, void *hip_stream, bsq_stage **stage,
+                           int64_t **offsets, uint8_t **chars, uint8_t **mask) {
+    if (!stage || !offsets || !chars || max_seqs < 0 || (with_mask && !mask))
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_begin: null pointer or max_seqs < 0");
+    *stage = nullptr;
+    std::unique_ptr<bsq_stage> st(new (std::nothrow) bsq_stage());
+    if (!st) return bsq_internal::set_error(BSQ_ERR_ALLOC, "bsq_stage");
+    st->lock = std::unique_lock<std::mutex>(g_mu);
+    bsq_status rc = current_staging(&st->s);
+    if (rc != BSQ_OK) return rc;
+    st->slot = &st->s->in[st->s->next];
+    st->s->next = (st->s->next + 1) % kInSlots;
+    rc = wait_idle(*st->slot);
+    if (rc != BSQ_OK) return rc;
+    const size_t h_off = round_up(size_t(max_seqs + 1) * 8, 64), h_chr = round_up(max_chars + 8, 64);
+    rc = grow_pinned(*st->slot, h_off + h_chr * (with_mask ? 2 : 1));
+    if (rc != BSQ_OK) return rc;
+    st->d_off_bytes = round_up(size_t(max_seqs + 1) * 8, 256);
+    st->d_chr_bytes = round_up(max_chars + 8, 256);  // +8: slack so the tail word is always mapped
+    rc = grow_device(&st->slot->d_in, &st->slot->d_in_cap, st->d_off_bytes + st->d_chr_bytes * (with_mask ? 2 : 1));
+    if (rc != BSQ_OK) return rc;
+    st->stream = static_cast<hipStream_t>(hip_stream);
+    st->max_seqs = max_seqs;
+    st->max_chars = max_chars;
+    st->with_mask = with_mask != 0;
+    char *h = static_cast<char *>(st->slot->pinned);
+    st->h_offsets = reinterpret_cast<int64_t *>(h);
+    st->h_chars = reinterpret_cast<uint8_t *>(h + h_off);
+    st->h_mask = with_mask ? st->h_chars + h_chr : nullptr;
+    st->d_base = static_cast<char *>(st->slot->d_in);
+    st->h_offsets[0] = 0;
+    *offsets = st->h_offsets;
+    *chars = st->h_chars;
+    if (mask) *mask = st->h_mask;
+    *stage = st.release();
+    return BSQ_OK;
+}
+
+bsq_status bsq_stage_upload(bsq_stage *st, int64_t first, int64_t last, const int64_t **d_offsets, const uint8_t **d_chars,
+                            const uint8_t **d_mask) {
+    if (!st || !d_offsets || !d_chars) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_upload: null pointer");
+    if (first != st->uploaded || last < first || last > st->max_seqs)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_upload: pieces must follow one another inside [0, max_seqs]");
+    const int64_t c0 = st->h_offsets[first], c1 = st->h_offsets[last];
+    if (c0 < 0 || c1 < c0 || size_t(c1) > st->max_chars)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_upload: offsets decrease or exceed max_chars");
+    Staging &s = *st->s;
+    hipStream_t copy = s.copy_stream;
+    // offsets[first] went up as the previous piece's last entry (entry 0 with the first piece)
+    const int64_t o0 = first == 0 ? 0 : first + 1;
+    hipError_t e = hipSuccess;
+    if (last + 1 > o0)
+        e = hipMemcpyAsync(st->d_base + size_t(o0) * 8, st->h_offsets + o0, size_t(last + 1 - o0) * 8, hipMemcpyHostToDevice, copy);
+    char *dc = st->d_base + st->d_off_bytes;
+    if (e == hipSuccess && c1 > c0) e = hipMemcpyAsync(dc + c0, st->h_chars + c0, size_t(c1 - c0), hipMemcpyHostToDevice, copy);
+    if (e == hipSuccess && st->with_mask && c1 > c0)
+        e = hipMemcpyAsync(dc + st->d_chr_bytes + c0, st->h_mask + c0, size_t(c1 - c0), hipMemcpyHostToDevice, copy);
+    constexpr int kEvents = int(sizeof(s.piece) / sizeof(s.piece[0]));
+    hipEvent_t &ev = s.piece[st->pieces++ % kEvents];
+    if (e == hipSuccess && !ev) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, copy);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st->stream, ev, 0);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("bsq_stage_upload", e);
+    g_upload_bytes.fetch_add(uint64_t(last + 1 - o0) * 8 + uint64_t(c1 - c0) * (st->with_mask ? 2 : 1), std::memory_order_relaxed);
+    st->uploaded = last;
+    *d_offsets = reinterpret_cast<const int64_t *>(st->d_base) + first;
+    *d_chars = reinterpret_cast<const uint8_t *>(dc);
+    if (d_mask) *d_mask = st->with_mask ? reinterpret_cast<const uint8_t *>(dc + st->d_chr_bytes) : nullptr;
+    return BSQ_OK;
+}
+
+bsq_status bsq_stage_end(bsq_stage *st) {
+    if (!st) return BSQ_OK;
+    std::unique_ptr<bsq_stage> owner(st);  // (unlocks g_mu)
+    if (st->pieces == 0) return BSQ_OK;    // nothing was uploaded: nothing on the stream reads the slot
+    const hipError_t e = hipEventRecord(st->slot->busy, st->stream);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipEventRecord", e);
+    st->slot->busy_pending = true;
+    return BSQ_OK;
+}
+
+int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, const void *out, void *hip_stream) {
+    return piece_sequences(B, nchars, block_row_bytes, out, static_cast<hipStream_t>(hip_stream));
 }
 
 void bsq_release_staging(void) {
@@ -679,12 +791,6 @@ bsq_status bsq_tokenize_host(const bsq_desc *d, const uint8_t *chars, const int6
 bsq_status bsq_onehot_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                            const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                            bsq_space out_space, void *hip_stream, int64_t *first_bad) {
-    return bsq_onehot_host_pieces(d, chars, offsets, mask_or_null, B, P, t, out, out_space, hip_stream, first_bad, nullptr, nullptr);
-}
-
-bsq_status bsq_onehot_host_pieces(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null,
-                                int64_t B, int64_t P, bsq_dtype t, void *out, bsq_space out_space, void *hip_stream,
-                                int64_t *first_bad, bsq_pack_fn fill, void *ctx) {
     const size_t sz = bsq_dtype_size(t);
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
     const size_t C = d ? size_t(bsq_alphabet_size(d)) : 0;
@@ -692,8 +798,6 @@ bsq_status bsq_onehot_host_pieces(const bsq_desc *d, const uint8_t *chars, const
     struct Block {
         int64_t seqs = 0;
         size_t row_bytes = 0;
-        bsq_pack_fn fill = nullptr;
-        void *ctx = nullptr;
         const bsq_desc *d;
         int64_t B, P;
         bsq_dtype t;
@@ -706,8 +810,6 @@ bsq_status bsq_onehot_host_pieces(const bsq_desc *d, const uint8_t *chars, const
     block.P = P;
     block.t = t;
     block.row_bytes = C * sz;
-    block.fill = fill;
-    block.ctx = ctx;
     block.seqs = out_space == BSQ_SPACE_DEVICE && d && offsets && B > 0
                      ? piece_sequences(B, size_t(offsets[B]), block.row_bytes, out, static_cast<hipStream_t>(hip_stream))
                      : 0;

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "bsq.h"
+#include "bsq_worker_pool.h"
 #include "bsq_diag.h"
 
 namespace py = pybind11;
@@ -59,79 +60,6 @@ int default_threads() {
     return hc ? int(hc) : 1;
 }
 
-// Persistent host workers for the two parallel phases of a list-of-objects call (item scan, pinned pack): creating and
-// joining 2 x nthreads std::threads per call cost 0.2-0.4 ms of a 2.7 ms call (profiles/r02/e2e_python_api.txt: 32 threads
-// were SLOWER than 8).  parallel_for(n, fn) runs fn(t) for t in [0, n) -- t = 0 on the caller -- and returns when all are
-// done.  Workers only ever touch raw bytes (never the interpreter), the caller keeps the GIL meanwhile, so the items stay
-// alive.  One job at a time (g_pack_mu / the GIL serialise the callers).
-class WorkerPool {
-  public:
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (std::thread &t : threads_) t.join();
-    }
-    void parallel_for(int n, const std::function<void(int)> &fn) {
-        if (n <= 1) {
-            if (n == 1) fn(0);
-            return;
-        }
-        std::unique_lock<std::mutex> job_lock(job_mu_);  // one job at a time
-        grow(n - 1);
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            fn_ = &fn;
-            next_ = 1;
-            limit_ = n;
-            pending_ = n - 1;
-            ++generation_;
-        }
-        cv_.notify_all();
-        // whatever fn(0) does on the caller -- return or throw --, the workers still hold &fn: wait for them before unwinding
-        struct Drain {
-            WorkerPool *p;
-            ~Drain() {
-                std::unique_lock<std::mutex> l(p->mu_);
-                p->done_.wait(l, [this] { return p->pending_ == 0; });
-                p->fn_ = nullptr;
-            }
-        } drain{this};
-        fn(0);
-    }
-
-  private:
-    void grow(int want) {
-        std::lock_guard<std::mutex> l(mu_);
-        while (int(threads_.size()) < want && threads_.size() < 256) threads_.emplace_back([this] { run(); });
-    }
-    void run() {
-        uint64_t seen = 0;
-        std::unique_lock<std::mutex> l(mu_);
-        for (;;) {
-            cv_.wait(l, [&] { return stop_ || (generation_ != seen && next_ < limit_); });
-            if (stop_) return;
-            while (next_ < limit_) {
-                const int t = next_++;
-                const std::function<void(int)> *fn = fn_;
-                l.unlock();
-                (*fn)(t);
-                l.lock();
-                if (--pending_ == 0) done_.notify_all();
-            }
-            seen = generation_;
-        }
-    }
-    std::mutex mu_, job_mu_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> threads_;
-    const std::function<void(int)> *fn_ = nullptr;
-    int next_ = 0, limit_ = 0, pending_ = 0;
-    uint64_t generation_ = 0;
-    bool stop_ = false;
-};
 // Leaked on purpose (joining threads during interpreter shutdown can deadlock); a forked child starts with a fresh pool
 // (the parent's worker threads do not exist there).
 std::atomic<WorkerPool *> g_pool{nullptr};
@@ -205,43 +133,56 @@ inline bool fast_item(PyObject *o, Item *it) {
 // arrays too but falls through to its error label; they are accepted here.)
 // Large batches without a mask list are first scanned by `nthreads` workers (the scan is bound by the cache
 // misses on 64k object headers); whatever is not a plain bytes / bytearray / ASCII str is left to the serial pass.
-void gather(py::sequence batch, const py::object &mask, Gathered &g, int &nthreads) {
+// scan_begin: the list itself (item count, mask list); scan_range: pointer + length of items [lo, hi) into g.items / g.masks.
+// The whole-batch path scans [0, n) at once; the staged path (Tokenizer::staged) piece by piece.
+struct Scan {
+    PyObject **objs = nullptr;
+    Py_ssize_t n = 0;
+    bool mask_is_list = false;
+    py::list mlist;
+};
+
+Scan scan_begin(py::sequence batch, const py::object &mask, Gathered &g, int &nthreads) {
     py::object fast = py::reinterpret_steal<py::object>(PySequence_Fast(batch.ptr(), "batch must be a sequence"));
     if (!fast) throw py::error_already_set();
-    const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast.ptr());
-    nthreads = resolve_threads(nthreads, n);
-    PyObject **objs = PySequence_Fast_ITEMS(fast.ptr());
+    Scan sc;
+    sc.n = PySequence_Fast_GET_SIZE(fast.ptr());
+    nthreads = resolve_threads(nthreads, sc.n);
+    sc.objs = PySequence_Fast_ITEMS(fast.ptr());
     g.keep.push_back(fast);
-    const bool mask_is_list = py::isinstance<py::list>(mask);  // anything else is ignored (tokenize.h:294)
-    py::list mlist;
-    if (mask_is_list) {
-        mlist = py::reinterpret_borrow<py::list>(mask);
-        g.masks.reserve(size_t(n));
+    sc.mask_is_list = py::isinstance<py::list>(mask);  // anything else is ignored (tokenize.h:294)
+    g.items.assign(size_t(sc.n), Item{nullptr, 0});
+    if (sc.mask_is_list) {
+        sc.mlist = py::reinterpret_borrow<py::list>(mask);
+        g.masks.assign(size_t(sc.n), nullptr);
         g.has_mask = true;
     }
+    return sc;
+}
+
+void scan_range(const Scan &sc, Gathered &g, Py_ssize_t lo, Py_ssize_t hi, int nthreads) {
+    PyObject **objs = sc.objs;
+    const Py_ssize_t n = hi - lo;
     std::vector<uint8_t> resolved;
-    if (!mask_is_list && nthreads > 1 && n >= 8192) {
-        g.items.assign(size_t(n), Item{nullptr, 0});
+    if (!sc.mask_is_list && nthreads > 1 && sc.n >= 8192 && n >= 1024) {
         resolved.assign(size_t(n), 0);
         std::vector<size_t> part(size_t(nthreads), 0);
-        // (Software prefetch of the object headers / first data lines of the items ahead, here and in pack(): built and measured in
+        // (Software prefetch of the object headers / first data lines of the items ahead, here and in pack_range(): built and measured in
         //  round 4 on the list in allocation order and shuffled -- no effect, profiles/r04/host_prefetch_lab.txt -- and taken out.)
         auto scan = [&](int t) {
             size_t sum = 0;
-            for (Py_ssize_t i = n * t / nthreads, e = n * (t + 1) / nthreads; i < e; ++i)
+            for (Py_ssize_t i = lo + n * t / nthreads, e = lo + n * (t + 1) / nthreads; i < e; ++i)
                 if (fast_item(objs[i], &g.items[size_t(i)])) {
-                    resolved[size_t(i)] = 1;
+                    resolved[size_t(i - lo)] = 1;
                     sum += g.items[size_t(i)].len;
                 }
             part[size_t(t)] = sum;
         };
         pool().parallel_for(nthreads, scan);
         for (size_t v : part) g.total += v;
-    } else {
-        g.items.reserve(size_t(n));
     }
-    for (Py_ssize_t i = 0; i < n; ++i) {
-        if (!resolved.empty() && resolved[size_t(i)]) continue;
+    for (Py_ssize_t i = lo; i < hi; ++i) {
+        if (!resolved.empty() && resolved[size_t(i - lo)]) continue;
         PyObject *o = objs[i];
         Item it{nullptr, 0};
         if (PyUnicode_Check(o)) {
@@ -266,10 +207,10 @@ void gather(py::sequence batch, const py::object &mask, Gathered &g, int &nthrea
         } else {
             throw std::invalid_argument("item was none of string, bytes, or numpy array of 8-bit integers. ");
         }
-        if (mask_is_list) {
+        if (sc.mask_is_list) {
             const uint8_t *mp = nullptr;
-            if (size_t(i) >= mlist.size()) throw py::index_error("list index out of range");
-            py::object m = mlist[size_t(i)];
+            if (size_t(i) >= sc.mlist.size()) throw py::index_error("list index out of range");
+            py::object m = sc.mlist[size_t(i)];
             if (py::isinstance<py::array>(m)) {  // tokenize.h:372-380; other entries: sequence unmasked
                 py::array_t<uint8_t, py::array::forcecast | py::array::c_style> arr(m);
                 if (size_t(arr.size()) < it.len)
@@ -277,13 +218,10 @@ void gather(py::sequence batch, const py::object &mask, Gathered &g, int &nthrea
                 g.keep.push_back(arr);
                 mp = arr.data();
             }
-            g.masks.push_back(mp);
+            g.masks[size_t(i)] = mp;
         }
         g.total += it.len;
-        if (resolved.empty())
-            g.items.push_back(it);
-        else
-            g.items[size_t(i)] = it;
+        g.items[size_t(i)] = it;
     }
 }
 
@@ -338,10 +276,78 @@ void pack_range(const Gathered &g, const Packed &p, int64_t first, int64_t last,
     } else {  // workers touch raw bytes only; the caller keeps the GIL so the items stay alive
         // (Handing finished pieces to the copy engine while the rest is still being packed, WITHOUT encoding the pieces as they
         // arrive, was built and measured in round 3 -- profiles/r03/e2e_lab1.txt: no gain -- and taken out again; with the
-        // encode of piece j under the upload of piece j + 1 it is what bsq_onehot_host_pieces does: profiles/r04/host_pieces_lab.txt.)
+        // encode of piece j under the upload of piece j + 1 it is what Tokenizer::staged does: profiles/r04/host_pieces_lab.txt.)
         const int nt = nthreads;
         pool().parallel_for(nt, [&](int t) { copy_range(first + n * t / nt, first + n * (t + 1) / nt); });
     }
+}
+
+// Scan AND pack of items [first, last) as ONE job of the pool, for the staged path (the pinned area is sized for the longest legal
+// batch, so nothing needs the total first): every thread reads pointer + length of its share of the items, all meet at a barrier,
+// every thread derives the offset of its first item from the shares before it, writes its offsets and copies its bytes.  One pool
+// job, no serial pass over the items.  Plain bytes / bytearray / ASCII str only: false = some item is something else (or there
+// is a mask list) and nothing usable was written -- the caller takes scan_range + pack_range for this piece.  An item longer than
+// maxlen stops everything before a byte is copied: *too_long = the first such item and p.offsets[*too_long + 1] holds its end.
+bool scan_pack_fast(const Scan &sc, Gathered &g, const Packed &p, int64_t first, int64_t last, int nthreads, int64_t maxlen, int64_t *too_long) {
+    *too_long = -1;
+    const int64_t n = last - first;
+    const int nt = int(std::min<int64_t>(std::min(nthreads, 64), n / 256));  // (every task of the job needs a thread of its own: barrier)
+    if (sc.mask_is_list || nt < 2) return false;
+    struct Part {
+        size_t sum = 0;
+        int64_t odd = -1, too_long = -1;  // first item of the share that is not a fast item / that is too long
+        char pad[40];
+    };
+    std::vector<Part> part(size_t(nt), Part{});
+    std::atomic<int> arrived{0}, verdict{0};  // verdict: 1 go on, 2 stop
+    PyObject **objs = sc.objs;
+    pool().parallel_for(nt, [&](int t) {
+        const int64_t i0 = first + n * t / nt, i1 = first + n * (t + 1) / nt;
+        Part mine;
+        for (int64_t i = i0; i < i1; ++i) {
+            Item &it = g.items[size_t(i)];
+            if (!fast_item(objs[i], &it)) {
+                mine.odd = i;
+                break;
+            }
+            if (int64_t(it.len) > maxlen && mine.too_long < 0) mine.too_long = i;
+            mine.sum += it.len;
+        }
+        part[size_t(t)] = mine;
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nt) {  // the last one in decides for all
+            bool go = true;
+            for (const Part &q : part) go = go && q.odd < 0 && q.too_long < 0;
+            verdict.store(go ? 1 : 2, std::memory_order_release);
+        }
+        int v;
+        for (unsigned spins = 0; (v = verdict.load(std::memory_order_acquire)) == 0; ++spins) {
+            if (spins < (1u << 16)) __builtin_ia32_pause();
+            else std::this_thread::yield();
+        }
+        if (v != 1) return;
+        int64_t at = p.offsets[first];
+        for (int u = 0; u < t; ++u) at += int64_t(part[size_t(u)].sum);
+        for (int64_t i = i0; i < i1; ++i) {
+            const Item &it = g.items[size_t(i)];
+            if (it.len) std::memcpy(p.chars + at, it.ptr, it.len);
+            at += int64_t(it.len);
+            p.offsets[i + 1] = at;  // (offsets[i0] is the end the share before writes; offsets[first] was there on entry)
+        }
+    });
+    for (const Part &q : part)
+        if (q.odd >= 0) return false;
+    for (const Part &q : part)
+        if (q.too_long >= 0) {  // the first too-long item: lengths up to it are all known
+            int64_t at = p.offsets[first];
+            for (int64_t i = first; i <= q.too_long; ++i) {
+                p.offsets[i] = at;
+                at += int64_t(g.items[size_t(i)].len);
+            }
+            p.offsets[q.too_long + 1] = at;
+            *too_long = q.too_long;
+            return true;
+        }
+    return true;
 }
 
 Packed pack(const Gathered &g, int nthreads) {
@@ -489,18 +495,73 @@ class Tokenizer {
         throw std::runtime_error(msg);
     }
 
+    // A list -> DEVICE result in pieces (include/bsq.h, "staged batches"): items [lo, hi) are scanned, packed into the pinned staging
+    // area, sent on their way and encoded as a block of the result while the next piece is scanned and packed -- the call costs
+    // one piece of host work + the upload + one piece of kernel instead of the sum of the three.  false = not applicable (small
+    // batch, numpy result, knob host_pieces = 1): nothing has been scanned, the caller goes on with the whole-batch path.  The GIL stays held as it
+    // is during every pack (the items must stay alive and unchanged); nothing in here blocks on the GPU.
+    template <typename BlockFn>
+    bool staged(const Scan &sc, Gathered &g, py::ssize_t padlen, int nthreads, const OutBuf &out, bool splittable, size_t block_row_bytes,
+                bool onehot, BlockFn block) const {
+        const int64_t maxlen = int64_t(padlen) - desc.bos - desc.eos;  // a longer item is an error anyway
+        if (out.space != BSQ_SPACE_DEVICE || sc.n < 16384 || maxlen <= 0) return false;
+        const size_t max_chars = size_t(sc.n) * size_t(maxlen);
+        if (max_chars > (size_t(1) << 30)) return false;
+        int64_t seqs = splittable ? bsq_stage_piece_hint(sc.n, max_chars / 2, block_row_bytes, out.ptr, out.stream) : 0;
+        if (seqs < 0) return false;                  // knob host_pieces = 1: the whole-batch path of rounds 1-3
+        if (seqs == 0 || seqs > sc.n) seqs = sc.n;   // one piece (busy stream, misaligned result, ...): still one scan + pack job
+        bsq_stage *stage = nullptr;
+        Packed p;
+        p.B = sc.n;
+        bsq_status st = bsq_stage_begin(sc.n, max_chars, g.has_mask ? 1 : 0, out.stream, &stage, &p.offsets, &p.chars, &p.mask);
+        if (st != BSQ_OK) throw_status(st);
+        struct End {
+            bsq_stage *s;
+            ~End() { (void)bsq_stage_end(s); }
+        } end{stage};
+        for (int64_t lo = 0; lo < sc.n; lo += seqs) {
+            const int64_t hi = std::min<int64_t>(sc.n, lo + seqs);
+            int64_t bad = -1;
+            if (!scan_pack_fast(sc, g, p, lo, hi, nthreads, maxlen, &bad)) {  // mask list / other item types: the general passes
+                scan_range(sc, g, lo, hi, nthreads);
+                for (int64_t i = lo; i < hi; ++i) {
+                    p.offsets[i + 1] = p.offsets[i] + int64_t(g.items[size_t(i)].len);
+                    if (int64_t(g.items[size_t(i)].len) > maxlen) throw_too_long(p.offsets, i, padlen, onehot);
+                }
+                pack_range(g, p, lo, hi, nthreads);
+            }
+            if (bad >= 0) throw_too_long(p.offsets, bad, padlen, onehot);
+            const int64_t *d_offsets = nullptr;
+            const uint8_t *d_chars = nullptr, *d_mask = nullptr;
+            st = bsq_stage_upload(stage, lo, hi, &d_offsets, &d_chars, &d_mask);
+            if (st == BSQ_OK) st = block(d_chars, d_offsets, d_mask, lo, hi - lo);
+            if (st != BSQ_OK) throw_status(st);
+        }
+        return true;
+    }
+
     // batch_tokenize (tokenize.cpp:82-98 -> tokenize.h:381-485)
     py::object batch_tokenize(py::sequence batch, py::ssize_t padlen, const std::string &dt, bool batch_first,
                               int nthreads, const py::object &device) const {
         const bsq_dtype t = parse_dtype(dt);
         check_padlen(padlen);
         Gathered g;
-        gather(batch, py::none(), g, nthreads);  // (resolves nthreads = 0 to the automatic count)
+        const Scan sc = scan_begin(batch, py::none(), g, nthreads);  // (resolves nthreads = 0 to the automatic count)
+        if (device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);   // (item errors before the result is allocated, as ever)
         PackLock lock;
         OutBuf out;  // first: it makes `device=` the current device, so the pinned scratch and the staging
                      // buffers used by pack() and by the encode call belong to the same device
-        const py::ssize_t nb = py::ssize_t(g.items.size());
+        const py::ssize_t nb = py::ssize_t(sc.n);
         make_out(out, batch_first ? std::vector<py::ssize_t>{nb, padlen} : std::vector<py::ssize_t>{padlen, nb}, t, device);
+        const size_t row = size_t(padlen) * bsq_dtype_size(t);
+        // (batch-first: a piece is rows [lo, lo + n); seq-first: always one piece, lo == 0)
+        if (staged(sc, g, padlen, nthreads, out, batch_first, 0, false,
+                   [&](const uint8_t *chars, const int64_t *offsets, const uint8_t *, int64_t lo, int64_t n) {
+                       return bsq_tokenize_device(&desc, chars, offsets, n, padlen, batch_first, t, static_cast<char *>(out.ptr) + size_t(lo) * row,
+                                                  out.stream);
+                   }))
+            return out.obj;
+        if (!device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);
         const Packed p = pack(g, nthreads);
         int64_t bad = -1;
         bsq_status st;
@@ -529,44 +590,46 @@ class Tokenizer {
         static const bool prof = std::getenv("BSQ_PROFILE_HOST") != nullptr;  // per-phase host times on stderr
         const auto t0 = std::chrono::steady_clock::now();
         Gathered g;
-        gather(batch, mask, g, nthreads);
+        const Scan sc = scan_begin(batch, mask, g, nthreads);
+        if (device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);  // (item errors before the result is allocated, as ever)
         const auto t1 = std::chrono::steady_clock::now();
         PackLock lock;
         OutBuf out;  // before pack(): see batch_tokenize
-        const py::ssize_t C = py::ssize_t(bsq_alphabet_size(&desc)), nb = py::ssize_t(g.items.size());
+        const py::ssize_t C = py::ssize_t(bsq_alphabet_size(&desc)), nb = py::ssize_t(sc.n);
         make_out(out, bcl ? std::vector<py::ssize_t>{nb, C, padlen} : std::vector<py::ssize_t>{padlen, nb, C}, t, device);
         const auto t2 = std::chrono::steady_clock::now();
-        // Seq-first result on a device: the library asks for the characters piece by piece (pack_range as its fill callback) and
-        // uploads + encodes one piece while the next is packed.  The GIL stays held, as it is during every pack (the items must
-        // stay alive and unchanged); nothing in that call blocks on the GPU.
-        const bool fill = !bcl && out.space == BSQ_SPACE_DEVICE;
-        const Packed p = fill ? pack_begin(g) : pack(g, nthreads);
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        // seq-first: piece = a column block of (P, B, C); channels-first: piece = rows [lo, lo + n) of (B, C, P)
+        const size_t row = size_t(C) * bsq_dtype_size(t);
+        const bool done =
+            bcl ? staged(sc, g, padlen, nthreads, out, true, 0, true,
+                         [&](const uint8_t *chars, const int64_t *offsets, const uint8_t *m, int64_t lo, int64_t n) {
+                             return bsq_onehot_bcl_device(&desc, chars, offsets, m, n, padlen, t,
+                                                          static_cast<char *>(out.ptr) + size_t(lo) * row * size_t(padlen), out.stream);
+                         })
+                : staged(sc, g, padlen, nthreads, out, true, row, true,
+                         [&](const uint8_t *chars, const int64_t *offsets, const uint8_t *m, int64_t lo, int64_t n) {
+                             return bsq_onehot_block_device(&desc, chars, offsets, m, n, padlen, t, static_cast<char *>(out.ptr) + size_t(lo) * row,
+                                                            int64_t(nb), out.stream);
+                         });
+        if (done) {
+            if (prof) std::fprintf(stderr, "[bsq host] list setup %ld us, output alloc %ld us, scan + pack + upload + launch in pieces %ld us\n", us(t0, t1),
+                                   us(t1, t2), us(t2, std::chrono::steady_clock::now()));
+            return out.obj;
+        }
+        if (!device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);
+        const Packed p = pack(g, nthreads);
         const auto t3 = std::chrono::steady_clock::now();
         int64_t bad = -1;
         bsq_status st;
-        if (fill) {
-            struct Ctx {
-                const Gathered *g;
-                const Packed *p;
-                int nthreads;
-            } ctx{&g, &p, nthreads};
-            st = bsq_onehot_host_pieces(&desc, p.chars, p.offsets, p.mask, p.B, padlen, t, out.ptr, out.space, out.stream, &bad,
-                                      [](void *c, int64_t first, int64_t last) {
-                                          const Ctx *x = static_cast<const Ctx *>(c);
-                                          pack_range(*x->g, *x->p, first, last, x->nthreads);
-                                      },
-                                      &ctx);
-        } else {
+        {
             py::gil_scoped_release nogil;
             st = (bcl ? bsq_onehot_bcl_host : bsq_onehot_host)(&desc, p.chars, p.offsets, p.mask, p.B, padlen, t, out.ptr,
                                                                out.space, out.stream, &bad);
         }
-        if (prof) {
-            const auto t4 = std::chrono::steady_clock::now();
-            auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-            std::fprintf(stderr, "[bsq host] gather %ld us, output alloc %ld us, pack %ld us, upload+launch %ld us\n", us(t0, t1),
-                         us(t1, t2), us(t2, t3), us(t3, t4));
-        }
+        if (prof)
+            std::fprintf(stderr, "[bsq host] gather %ld us, output alloc %ld us, scan (device results) + pack %ld us, upload+launch %ld us\n", us(t0, t1),
+                         us(t1, t2), us(t2, t3), us(t3, std::chrono::steady_clock::now()));
         if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(p.offsets, bad, padlen, true);
         if (st != BSQ_OK) throw_status(st);
         return out.obj;

@@ -243,17 +243,30 @@ bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const in
                                const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                                bsq_space out_space, void *hip_stream, int64_t *first_bad);
 
-/* bsq_onehot_host for a caller that PRODUCES the characters on demand (the pybind11 layer copying them out of Python objects):
- * `offsets` is complete on entry; chars (and the mask) are buffers that `fill(ctx, first, last)` writes for sequences
- * [first, last).  fill is called on the calling thread, in order, over ranges that cover [0, B) exactly once, and always
- * before the library reads those bytes.  A large batch with a device result goes up in PIECES: fill(piece j + 1) runs while
- * piece j is on the bus and the one-hot of piece j (a column block of `out`, bsq_onehot_block_device) runs while piece j + 1
- * is -- the call costs scan + upload + one piece of packing and of kernel instead of the sum of all four (tuning knob
- * "host_pieces").  Everything else, and fill == NULL (the buffers are already full), is bsq_onehot_host. */
-typedef void (*bsq_pack_fn)(void *ctx, int64_t first, int64_t last);
-bsq_status bsq_onehot_host_pieces(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null,
-                                int64_t B, int64_t P, bsq_dtype t, void *out, bsq_space out_space, void *hip_stream,
-                                int64_t *first_bad, bsq_pack_fn fill, void *ctx);
+/* ---- staged batches: for a caller that PRODUCES a host batch piece by piece (the pybind11 layer scanning and copying Python
+ * objects) and wants piece j on the bus and under the encode kernels while it produces piece j + 1.
+ *   bsq_stage_begin   takes the next pinned + device staging slot of the current device (waits until the batch that used it has
+ *                     left the GPU) sized for max_seqs sequences / max_chars characters, and returns the PINNED host buffers to
+ *                     write: offsets[max_seqs + 1] (offsets[0] = 0 is set), chars[max_chars], mask[max_chars] (with_mask).
+ *   bsq_stage_upload  sequences [first, last) are complete -- offsets[first + 1 .. last] and their characters written; pieces
+ *                     follow one another from 0.  Enqueues their copy on the library's copy stream, makes `hip_stream` wait for
+ *                     it, and returns DEVICE pointers for a *_device call on hip_stream over those sequences: d_offsets points
+ *                     at the entry of sequence `first` (values are offsets into d_chars / d_mask, the bases of the whole batch).
+ *   bsq_stage_end     always pairs with a successful begin: the slot may be reused once the work enqueued on hip_stream so far
+ *                     has run.  Other bsq_*_host calls of the process wait between begin and end (one staging area per device).
+ *   bsq_stage_piece_hint  sequences per piece the library recommends for a batch of B sequences / ~nchars characters whose
+ *                     result blocks have block_row_bytes-byte rows at `out` (0: the blocks are contiguous), 0 = one piece, or
+ *                     -1 = the knob asks for the whole-batch path (host_pieces = 1): knob "host_pieces"; automatic = pieces of ~8 MB when the batch is large and hip_stream is idle (a busy
+ *                     stream means the caller is not waiting for this batch: one upload costs the host less than several).
+ * What it buys (list of 65 536 bytes objects, 35 MB -> f32 one-hot on the device, synchronous): 2.1 ms as one pack + one
+ * upload + one encode, 1.5 ms with the encode and the pack of the pieces under the uploads (profiles/r04/host_pieces_lab.txt). */
+typedef struct bsq_stage bsq_stage;
+bsq_status bsq_stage_begin(int64_t max_seqs, size_t max_chars, int32_t with_mask, void *hip_stream, bsq_stage **stage,
+                           int64_t **offsets, uint8_t **chars, uint8_t **mask);
+bsq_status bsq_stage_upload(bsq_stage *stage, int64_t first, int64_t last, const int64_t **d_offsets, const uint8_t **d_chars,
+                            const uint8_t **d_mask);
+bsq_status bsq_stage_end(bsq_stage *stage);
+int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, const void *out, void *hip_stream);
 
 /* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer): returns a buffer of
  * at least nbytes; pack offsets | chars | mask into it and hand those pointers to the next bsq_*_host call.
