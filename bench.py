@@ -174,8 +174,18 @@ def e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
+    def whole_batch_ms():  # the path of rounds 1-3 (scan, pack, one upload, one encode) on the same box, for comparison
+        from bioseq_amd import capi
+        lib = capi.load()
+        capi.check(lib.bsq_tuning_set(b"host_pieces", 1))
+        try:
+            return median_ms(lambda: call(dev), 10)
+        finally:
+            capi.check(lib.bsq_tuning_set(b"host_pieces", 0))
+
     out = {"nthreads": nthreads, "sequences": len(seqs), "host_cpus": os.cpu_count(),
            "list_to_device_sync_ms": median_ms(lambda: call(dev), 10),
+           "list_to_device_sync_one_upload_one_encode_ms": whole_batch_ms(),
            "list_to_device_sync_default_nthreads_ms": median_ms(lambda: (tok.batch_onehot_encode(seqs, padlen=P, destchar=destchar, device=dev) if op == "onehot" else tok.batch_tokenize(seqs, padlen=P, destchar=destchar, batch_first=batch_first, device=dev)), 10),
            "list_to_device_pipelined20_ms": float(np.median([pipelined_ms(lambda: call(dev)) for _ in range(3)])),
            "packed_resident_to_device_incl_alloc_ms": median_ms(packed, 10),

@@ -1559,6 +1559,7 @@ struct GParams {
     void *out;
     int64_t B, P;
     int32_t C, bos, eos, bos_id, eos_id, pad_id, padchar, batch_first;
+    int64_t row_seqs;  // (P, B, C) one-hot: sequences per position row of the destination (= B unless the batch is a column block)
 };
 
 __device__ __forceinline__ int32_t token_at(const GParams &p, int64_t b, int64_t t) {
@@ -1598,7 +1599,7 @@ __global__ __launch_bounds__(kThreads) void k_onehot_generic(const GParams p) {
             b = r - t * p.B;
         }
         const int32_t tk = token_at(p, b, t);
-        out[e] = (tk == c) ? T(1) : T(0);
+        out[p.batch_first == 2 ? e : (t * p.row_seqs + b) * p.C + c] = (tk == c) ? T(1) : T(0);
     }
 }
 
@@ -1731,6 +1732,7 @@ void fill_generic(GParams &g, const bsq_desc *d, const uint8_t *chars, const int
     g.pad_id = bsq_pad_id(d);
     g.padchar = d->padchar;
     g.batch_first = batch_first;
+    g.row_seqs = B;
 }
 
 unsigned generic_grid(int64_t n) {
@@ -2207,6 +2209,9 @@ bsq_status launch_expand_bcl(const uint8_t *tokens, int64_t B, int64_t P, int32_
 
 }  // namespace
 
+static bsq_status onehot_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null, int64_t B,
+                                       int64_t P, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream);
+
 extern "C" {
 
 // 0 generic, 1 tiled, 2 two-pass, 3 chunk-owner
@@ -2320,8 +2325,7 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
     if (reinterpret_cast<uintptr_t>(out) % sz) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output is not aligned to its element size");
     const int block_path = choose_onehot_path(k.C, sz, B, P, false);
-    if (block_path == 0)
-        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "column-block one-hot: alphabets with ids > 250 / shapes of the generic kernel are not supported");
+    if (block_path == 0) return onehot_generic_block(d, chars, offsets, mask_or_null, B, P, t, out, row_seqs, hip_stream);
     k.one_bits = one_bits_of(t);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     // A block whose position rows are whole 4-KiB chunks (B * C * sizeof(T) and the address of its first element multiples of 4096: e.g.
@@ -2550,11 +2554,17 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
 bsq_status bsq_onehot_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                      const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
                                      void *hip_stream) {
+    return onehot_generic_block(d, chars, offsets, mask_or_null, B, P, t, out, B, hip_stream);
+}
+
+static bsq_status onehot_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null, int64_t B,
+                                       int64_t P, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream) {
     if (!d || B < 0 || P <= 0 || (B > 0 && (!offsets || !out)))  // (an EMPTY batch -- a rank without sequences -- has nothing to point at)
         return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
     if (B == 0) return BSQ_OK;
     GParams g;
     fill_generic(g, d, chars, offsets, mask_or_null, B, P, 0, out);
+    g.row_seqs = row_seqs;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const unsigned grid = generic_grid(P * B * g.C);
 #define BSQ_GEN(T) hipLaunchKernelGGL((k_onehot_generic<T>), dim3(grid), dim3(kThreads), 0, s, g)

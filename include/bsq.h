@@ -121,7 +121,10 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
                                  void *hip_stream);
 /* The same one-hot written as a COLUMN BLOCK of a larger (P, row_seqs, C) tensor: `out` points at element (0, b0, 0) of it and
  * row t of this batch goes to out + t * row_seqs * C * sizeof(T).  What a rank of a sharded job needs to store its
- * sequences straight into the whole-batch tensor of another GPU (peer-mapped memory, sharding.store_shard_into_root). */
+ * sequences straight into the whole-batch tensor of another GPU (peer-mapped memory, sharding.store_shard_into_root), and what
+ * a host batch that arrives in pieces is encoded with (staged batches, below).  A block whose position rows are whole 4-KiB
+ * chunks (B * C * sizeof(T) and `out` multiples of 4096, e.g. k x 4096 sequences at a 4096-sequence boundary of an aligned
+ * tensor, rows >= 16 bytes) runs at the speed of the whole-tensor kernels; any other block through the tiled kernel. */
 bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                    const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out, int64_t row_seqs,
                                    void *hip_stream);

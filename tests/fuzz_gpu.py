@@ -79,12 +79,24 @@ def run(budget=120.0, seed=1):
                 ml = None if mask is None else [mask[offs[i]:offs[i + 1]].copy() for i in range(B)]
                 g = tok.batch_onehot_encode(seqs, padlen=P, destchar=d, mask=ml)
                 assert g.tobytes() == e.tobytes(), "host onehot"
+            if B >= 16384 and rng.random() < 0.6:  # list -> DEVICE result: the staged path (scan + pack + upload + encode in pieces)
+                seqs = synth.unpack(chars, offs, as_str=bool(rng.integers(0, 2)))  # (every fuzz alphabet is ASCII)
+                ml = None if mask is None else [mask[offs[i]:offs[i + 1]].copy() for i in range(B)]
+                capi.check(lib.bsq_tuning_set(b"host_pieces", int(rng.choice([0, 1, 2, 3, 4, 8]))))
+                if rng.random() < 0.5:
+                    torch.cuda.synchronize()  # (an idle stream: the automatic rule splits)
+                g = u64(tok.batch_onehot_encode(seqs, padlen=P, destchar=d, mask=ml, device="cuda").cpu().numpy())
+                assert g.tobytes() == e.tobytes(), "list -> device onehot"
+                g = tok.batch_onehot_encode(seqs, padlen=P, destchar=d, mask=ml, device="cuda", layout="bcl").cpu().numpy()
+                assert g.tobytes() == np.ascontiguousarray(e.transpose(1, 2, 0)).tobytes(), "list -> device onehot bcl"
+                g = u64(tok.batch_tokenize(seqs, padlen=P, destchar=d, batch_first=bf, device="cuda").cpu().numpy())
+                assert g.tobytes() == ora.tokenize_packed(chars, offs, P, d, bf).tobytes(), ("list -> device tokens", bf)
         except AssertionError as ex:
             raise AssertionError("MISMATCH %s %r" % (ex, desc))
         n += 1
     torch.cuda.synchronize()
     capi.check(lib.bsq_fused_status(None))  # no token wave of a fused augmentation launch gave up waiting
-    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"augment_fused", b"bcl_path", b"tokenize_tb"):
+    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"augment_fused", b"bcl_path", b"tokenize_tb", b"host_pieces"):
         capi.check(lib.bsq_tuning_set(name, 0))
     return n
 

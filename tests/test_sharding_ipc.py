@@ -58,7 +58,8 @@ def test_onehot_written_as_a_column_block_of_a_larger_tensor(gpu, oracle, key, f
     assert lib.bsq_onehot_block_device(ctypes.byref(desc), c.data_ptr(), o.data_ptr(), None, 10, P, dt, full.data_ptr(), 5, None) != 0   # row_seqs < B
 
 
-@pytest.mark.parametrize("key,flags,dtype", [("AMINO20", (0, 0, 0), "f"), ("DNA", (1, 1, 1), "f"), ("SEB8", (0, 1, 0), "h"), ("AMINO20", (1, 1, 1), "b")])
+@pytest.mark.parametrize("key,flags,dtype", [("AMINO20", (0, 0, 0), "f"), ("DNA", (1, 1, 1), "f"), ("SEB8", (0, 1, 0), "h"), ("AMINO20", (1, 1, 1), "b"),
+                                             ("BYTES", (1, 0, 1), "h")])  # (BYTES: ids > 250 -> the generic kernel, also as a block)
 def test_column_blocks_made_of_whole_chunks(gpu, oracle, key, flags, dtype):
     """Blocks of k x 4096 sequences at 4096-sequence boundaries of a 4-KiB aligned tensor go through the two-pass stream with a
     row gap (rows >= 16 bytes), the ragged last block through the tiles; the offsets are the whole batch's, advanced to the
