@@ -270,8 +270,8 @@ bsq_status run_pieces(Staging &s, InSlot &slot, const uint8_t *chars, const int6
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](auto a, auto b) { return long(std::chrono::duration_cast<std::chrono::microseconds>(b - a).count()); };
     int j = 0;
-    for (int64_t b0 = 0; b0 < B && e == hipSuccess; b0 += block.seqs, ++j) {
-        const int64_t n = B - b0 < block.seqs ? B - b0 : block.seqs;
+    for (int64_t b0 = 0, want = block.head + block.seqs; b0 < B && e == hipSuccess; b0 += want, want = block.seqs, ++j) {
+        const int64_t n = B - b0 < want ? B - b0 : want;
         const size_t c0 = size_t(offsets[b0]), c1 = size_t(offsets[b0 + n]);
         const auto t0 = now();
         const auto t1 = now();
@@ -289,7 +289,13 @@ bsq_status run_pieces(Staging &s, InSlot &slot, const uint8_t *chars, const int6
         db.offsets = reinterpret_cast<const int64_t *>(base) + b0;
         db.chars = reinterpret_cast<const uint8_t *>(base + off_bytes);
         db.mask = mask ? reinterpret_cast<const uint8_t *>(base + off_bytes + chr_bytes) : nullptr;
-        st = block(db, n, static_cast<char *>(out) + size_t(b0) * block.row_bytes, stream);
+        const int64_t lead = b0 == 0 && block.head < n ? block.head : 0;  // the sequences in front of the first chunk boundary
+        if (lead) {
+            st = block(db, lead, out, stream);
+            if (st != BSQ_OK) return st;
+            db.offsets += lead;
+        }
+        st = block(db, n - lead, static_cast<char *>(out) + size_t(b0 + lead) * block.row_bytes, stream);
         if (st != BSQ_OK) return st;
         if (prof)
             std::fprintf(stderr, "[bsq host] piece %d: pack %ld us, hipMemcpyAsync %ld us, event + wait %ld us, launches %ld us\n", j, us(t0, t1),
@@ -305,7 +311,7 @@ bsq_status run_pieces(Staging &s, InSlot &slot, const uint8_t *chars, const int6
 // (cfg3 list -> device tensor, synchronous: 2.0-2.1 -> see profiles/r04/host_pieces_lab.txt).  `block` encodes sequences
 // [b0, b0 + n) given the device batch (offsets pointer already advanced to b0) and the address of element (0, b0, 0).
 struct NoPieces {
-    int64_t seqs = 0;
+    int64_t seqs = 0, head = 0;  // pieces of `seqs` sequences; the first one holds `head` more in front (see piece_sequences)
     size_t row_bytes = 0;
     bsq_status operator()(const struct DeviceBatch &, int64_t, void *, hipStream_t) const { return BSQ_OK; }
 };
@@ -383,11 +389,24 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
 // bytes (the two-pass kernels take the blocks: pieces are multiples of 4096 sequences, so that every block row is whole 4-KiB chunks of
 // an aligned tensor) and the caller's stream is IDLE -- somebody who keeps the stream busy is measuring throughput, where the host's own
 // work per batch is what counts and one upload is cheaper than four.
-int64_t piece_sequences(int64_t B, size_t nchars, size_t row_bytes, const void *out, hipStream_t stream) {
+int64_t piece_sequences(int64_t B, size_t nchars, size_t row_bytes, const void *out, hipStream_t stream, int64_t *head) {
+    *head = 0;
     const int knob = bsq_internal::tuning().host_pieces;
     if (knob == 1) return -1;  // (the stage API's callers read < 0 as "no staging at all": the whole-batch path of rounds 1-3)
-    // row_bytes == 0: the blocks of the result are contiguous (batch-first tokens, channels-first one-hot) -- any split will do
-    if (row_bytes != 0 && (row_bytes < 16 || reinterpret_cast<uintptr_t>(out) % 4096 != 0)) return 0;
+    // row_bytes == 0: the blocks of the result are contiguous (batch-first tokens, channels-first one-hot) -- any split will do.
+    // Column blocks: pieces must start where a 4-KiB chunk of the result starts.  torch's allocator aligns to 512 bytes only, so the
+    // first such sequence boundary is rarely 0: the `*head` sequences in front of it travel with the first piece and are encoded by a
+    // call of their own (the tiled kernel; a few hundred sequences).
+    int64_t lead = 0;
+    if (row_bytes != 0) {
+        if (row_bytes < 16) return 0;
+        const size_t mis = reinterpret_cast<uintptr_t>(out) % 4096;
+        if (mis != 0) {
+            for (int64_t b = 1; b <= 4096 && lead == 0; ++b)
+                if ((mis + size_t(b) * row_bytes) % 4096 == 0) lead = b;
+            if (lead == 0) return 0;  // (an address that is not a multiple of gcd(row_bytes, 4096): no boundary is aligned)
+        }
+    }
     int64_t count = knob >= 2 ? knob : int64_t(nchars >> 23);  // automatic: ~8 MB of characters per piece, 2 ... 8 pieces
     if (count < 2) count = 2;
     if (count > 8) count = 8;
@@ -398,8 +417,10 @@ int64_t piece_sequences(int64_t B, size_t nchars, size_t row_bytes, const void *
             return 0;
         }
     }
-    const int64_t seqs = (B / count) / 4096 * 4096;
-    return seqs >= 4096 && seqs < B ? seqs : 0;
+    const int64_t seqs = ((B - lead) / count) / 4096 * 4096;
+    if (seqs < 4096 || lead + seqs >= B) return 0;
+    *head = lead;
+    return seqs;
 }
 
 }  // namespace
@@ -745,8 +766,11 @@ bsq_status bsq_stage_end(bsq_stage *st) {
     return BSQ_OK;
 }
 
-int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, const void *out, void *hip_stream) {
-    return piece_sequences(B, nchars, block_row_bytes, out, static_cast<hipStream_t>(hip_stream));
+int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, const void *out, void *hip_stream, int64_t *head_seqs) {
+    int64_t head = 0;
+    const int64_t seqs = piece_sequences(B, nchars, block_row_bytes, out, static_cast<hipStream_t>(hip_stream), &head);
+    if (head_seqs) *head_seqs = head;
+    return head_seqs || head == 0 ? seqs : 0;  // (a caller that cannot take a head gets one piece)
 }
 
 void bsq_release_staging(void) {
@@ -796,7 +820,7 @@ bsq_status bsq_onehot_host(const bsq_desc *d, const uint8_t *chars, const int64_
     const size_t C = d ? size_t(bsq_alphabet_size(d)) : 0;
     const size_t out_bytes = (B > 0 && P > 0) ? size_t(P) * size_t(B) * C * sz : 0;
     struct Block {
-        int64_t seqs = 0;
+        int64_t seqs = 0, head = 0;
         size_t row_bytes = 0;
         const bsq_desc *d;
         int64_t B, P;
@@ -811,7 +835,7 @@ bsq_status bsq_onehot_host(const bsq_desc *d, const uint8_t *chars, const int64_
     block.t = t;
     block.row_bytes = C * sz;
     block.seqs = out_space == BSQ_SPACE_DEVICE && d && offsets && B > 0
-                     ? piece_sequences(B, size_t(offsets[B]), block.row_bytes, out, static_cast<hipStream_t>(hip_stream))
+                     ? piece_sequences(B, size_t(offsets[B]), block.row_bytes, out, static_cast<hipStream_t>(hip_stream), &block.head)
                      : 0;
     return run_host(d, chars, offsets, mask_or_null, B, P, d ? d->bos : 0, d ? d->eos : 0, out_bytes, out, out_space, hip_stream,
                     first_bad,

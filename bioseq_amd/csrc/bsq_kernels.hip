@@ -2344,7 +2344,10 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
     // otherwise the tiled kernel: a workgroup owns (sequence tile x 64 positions) and writes one row SEGMENT per position, so a row
     // pitch other than B * C is just another stride
     k.row_seqs = row_seqs;
-    k.aligned = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && ((row_seqs * k.C * int64_t(sz)) % 16 == 0);
+    // 16-byte stores: the block's first element, the row pitch AND the block's own row segment must be multiples of 16 (the last tile's
+    // segment ends where the block ends; with the whole tensor that is the pitch, here it is not: a block that started aligned and
+    // ended 8 bytes short of a line wrote those 8 bytes of its neighbour -- found in round 4 by the misaligned-result test)
+    k.aligned = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && ((row_seqs * k.C * int64_t(sz)) % 16 == 0) && (block_pitch % 16 == 0);
     switch (sz) {
     case 1: return dispatch_onehot_tile<uint8_t>(k, s);
     case 2: return dispatch_onehot_tile<uint16_t>(k, s);

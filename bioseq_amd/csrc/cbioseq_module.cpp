@@ -507,7 +507,8 @@ class Tokenizer {
         if (out.space != BSQ_SPACE_DEVICE || sc.n < 16384 || maxlen <= 0) return false;
         const size_t max_chars = size_t(sc.n) * size_t(maxlen);
         if (max_chars > (size_t(1) << 30)) return false;
-        int64_t seqs = splittable ? bsq_stage_piece_hint(sc.n, max_chars / 2, block_row_bytes, out.ptr, out.stream) : 0;
+        int64_t head = 0;  // sequences in front of the first piece boundary (column blocks of a result that is not 4-KiB aligned)
+        int64_t seqs = splittable ? bsq_stage_piece_hint(sc.n, max_chars / 2, block_row_bytes, out.ptr, out.stream, &head) : 0;
         if (seqs < 0) return false;                  // knob host_pieces = 1: the whole-batch path of rounds 1-3
         if (seqs == 0 || seqs > sc.n) seqs = sc.n;   // one piece (busy stream, misaligned result, ...): still one scan + pack job
         bsq_stage *stage = nullptr;
@@ -519,8 +520,8 @@ class Tokenizer {
             bsq_stage *s;
             ~End() { (void)bsq_stage_end(s); }
         } end{stage};
-        for (int64_t lo = 0; lo < sc.n; lo += seqs) {
-            const int64_t hi = std::min<int64_t>(sc.n, lo + seqs);
+        for (int64_t lo = 0, want = head + seqs; lo < sc.n; lo += want, want = seqs) {
+            const int64_t hi = std::min<int64_t>(sc.n, lo + want);
             int64_t bad = -1;
             if (!scan_pack_fast(sc, g, p, lo, hi, nthreads, maxlen, &bad)) {  // mask list / other item types: the general passes
                 scan_range(sc, g, lo, hi, nthreads);
@@ -534,7 +535,9 @@ class Tokenizer {
             const int64_t *d_offsets = nullptr;
             const uint8_t *d_chars = nullptr, *d_mask = nullptr;
             st = bsq_stage_upload(stage, lo, hi, &d_offsets, &d_chars, &d_mask);
-            if (st == BSQ_OK) st = block(d_chars, d_offsets, d_mask, lo, hi - lo);
+            const int64_t lead = lo == 0 && head < hi ? head : 0;
+            if (st == BSQ_OK && lead) st = block(d_chars, d_offsets, d_mask, 0, lead);
+            if (st == BSQ_OK) st = block(d_chars, d_offsets + lead, d_mask, lo + lead, hi - lo - lead);
             if (st != BSQ_OK) throw_status(st);
         }
         return true;
@@ -613,8 +616,8 @@ class Tokenizer {
                                                             int64_t(nb), out.stream);
                          });
         if (done) {
-            if (prof) std::fprintf(stderr, "[bsq host] list setup %ld us, output alloc %ld us, scan + pack + upload + launch in pieces %ld us\n", us(t0, t1),
-                                   us(t1, t2), us(t2, std::chrono::steady_clock::now()));
+            if (prof) std::fprintf(stderr, "[bsq host] list setup %ld us, output alloc %ld us (address %% 4096 = %lu), scan + pack + upload + launch in pieces %ld us\n",
+                                   us(t0, t1), us(t1, t2), (unsigned long)(reinterpret_cast<uintptr_t>(out.ptr) % 4096), us(t2, std::chrono::steady_clock::now()));
             return out.obj;
         }
         if (!device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);

@@ -259,7 +259,10 @@ bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const in
  *                     has run.  Other bsq_*_host calls of the process wait between begin and end (one staging area per device).
  *   bsq_stage_piece_hint  sequences per piece the library recommends for a batch of B sequences / ~nchars characters whose
  *                     result blocks have block_row_bytes-byte rows at `out` (0: the blocks are contiguous), 0 = one piece, or
- *                     -1 = the knob asks for the whole-batch path (host_pieces = 1): knob "host_pieces"; automatic = pieces of ~8 MB when the batch is large and hip_stream is idle (a busy
+ *                     -1 = the knob asks for the whole-batch path (host_pieces = 1).  *head_seqs: sequences the FIRST piece holds
+ *                     in front of that (pieces [0, head + n), [head + n, head + 2n), ...): column blocks run fastest when they
+ *                     start where a 4-KiB chunk of the result starts, and `out` is rarely aligned that far -- encode the head
+ *                     with a call of its own.  Knob "host_pieces"; automatic = pieces of ~8 MB when the batch is large and hip_stream is idle (a busy
  *                     stream means the caller is not waiting for this batch: one upload costs the host less than several).
  * What it buys (list of 65 536 bytes objects, 35 MB -> f32 one-hot on the device, synchronous): 2.1 ms as one pack + one
  * upload + one encode, 1.5 ms with the encode and the pack of the pieces under the uploads (profiles/r04/host_pieces_lab.txt). */
@@ -269,7 +272,7 @@ bsq_status bsq_stage_begin(int64_t max_seqs, size_t max_chars, int32_t with_mask
 bsq_status bsq_stage_upload(bsq_stage *stage, int64_t first, int64_t last, const int64_t **d_offsets, const uint8_t **d_chars,
                             const uint8_t **d_mask);
 bsq_status bsq_stage_end(bsq_stage *stage);
-int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, const void *out, void *hip_stream);
+int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, const void *out, void *hip_stream, int64_t *head_seqs);
 
 /* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer): returns a buffer of
  * at least nbytes; pack offsets | chars | mask into it and hand those pointers to the next bsq_*_host call.

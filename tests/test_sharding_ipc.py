@@ -44,17 +44,19 @@ def test_onehot_written_as_a_column_block_of_a_larger_tensor(gpu, oracle, key, f
         chars, offs = synth.synth_packed(B + P, B, 0, P - 2, synth.DIRTY)
         exp = ora.onehot_packed(chars, offs, P, dtype)
         guard = 64
-        buf = torch.full((P * B * C + 2 * guard,), 7, dtype=tdt, device=gpu)
-        full = buf[guard:guard + P * B * C].view(P, B, C)
-        for b0, b1 in zip(cuts[:-1], cuts[1:]):
-            c = torch.from_numpy(chars[offs[b0]:offs[b1]].copy()).to(gpu)
-            o = torch.from_numpy(offs[b0:b1 + 1] - offs[b0]).to(gpu)
-            capi.check(lib.bsq_onehot_block_device(ctypes.byref(desc), c.data_ptr(), o.data_ptr(), None, b1 - b0, P, dt,
-                                                   full[:, b0:b1].data_ptr(), B, None))
-        torch.cuda.synchronize()
-        host = buf.cpu().numpy()
-        assert (host[:guard] == 7).all() and (host[-guard:] == 7).all(), "wrote outside the tensor"
-        assert host[guard:-guard].tobytes() == exp.tobytes(), (key, B, P)
+        blocks = list(zip(cuts[:-1], cuts[1:]))
+        for order in (blocks, blocks[::-1]):  # (in both orders: a block that writes a byte of its neighbour is then caught either way)
+            buf = torch.full((P * B * C + 2 * guard,), 7, dtype=tdt, device=gpu)
+            full = buf[guard:guard + P * B * C].view(P, B, C)
+            for b0, b1 in order:
+                c = torch.from_numpy(chars[offs[b0]:offs[b1]].copy()).to(gpu)
+                o = torch.from_numpy(offs[b0:b1 + 1] - offs[b0]).to(gpu)
+                capi.check(lib.bsq_onehot_block_device(ctypes.byref(desc), c.data_ptr(), o.data_ptr(), None, b1 - b0, P, dt,
+                                                       full[:, b0:b1].data_ptr(), B, None))
+            torch.cuda.synchronize()
+            host = buf.cpu().numpy()
+            assert (host[:guard] == 7).all() and (host[-guard:] == 7).all(), "wrote outside the tensor"
+            assert host[guard:-guard].tobytes() == exp.tobytes(), (key, B, P)
     assert lib.bsq_onehot_block_device(ctypes.byref(desc), c.data_ptr(), o.data_ptr(), None, 10, P, dt, full.data_ptr(), 5, None) != 0   # row_seqs < B
 
 
