@@ -2331,8 +2331,37 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
     // A block whose position rows are whole 4-KiB chunks (B * C * sizeof(T) and the address of its first element multiples of 4096: e.g.
     // any multiple of 4096 sequences at a 4096-sequence boundary of an aligned tensor) is the two-pass stream with a gap after every
     // row: no chunk straddles two rows.  16 384-sequence blocks of cfg3: 4 x 0.19 ms against 4 x 0.25 ms for the tiles.
-    const int64_t block_pitch = B * k.C * int64_t(sz);
-    if (block_path != 1 && k.C * int64_t(sz) >= 16 && block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0) {
+    const int64_t block_pitch = B * k.C * int64_t(sz), rb = k.C * int64_t(sz);
+    if (block_path != 1 && rb >= 16 && !(block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0)) {
+        // Any other large block: the sequences up to the first one that starts a chunk of the result, the run of whole chunks behind
+        // it (a multiple of 4096 / gcd(row bytes, 4096) sequences), the rest -- three calls, the middle one the fast stream; worth it
+        // once the middle is large (the two short ones cost a ~15-us tile launch each).  Ragged shards of a sharded job
+        // (sharding.store_shard_into_root), the last piece of a host batch, results that torch aligned to 512 bytes only.
+        const int64_t mis = int64_t(reinterpret_cast<uintptr_t>(out) % kChunk);
+        int64_t g = rb, h = kChunk;
+        while (h) {
+            const int64_t r = g % h;
+            g = h;
+            h = r;
+        }
+        const int64_t m = kChunk / g;  // sequences per period of (b * rb) mod 4096
+        int64_t lead = -1;
+        for (int64_t b = 0; b < m && lead < 0; ++b)
+            if ((mis + b * rb) % kChunk == 0) lead = b;
+        const int64_t main = lead >= 0 && lead < B ? (B - lead) / m * m : 0;
+        if (main > 0 && main * rb * P >= (int64_t(128) << 20)) {
+            uint8_t *o = static_cast<uint8_t *>(out);
+            if (lead > 0) {
+                st = bsq_onehot_block_device(d, chars, offsets, mask_or_null, lead, P, t, o, row_seqs, hip_stream);
+                if (st != BSQ_OK) return st;
+            }
+            st = bsq_onehot_block_device(d, chars, offsets + lead, mask_or_null, main, P, t, o + lead * rb, row_seqs, hip_stream);
+            if (st != BSQ_OK || lead + main == B) return st;
+            return bsq_onehot_block_device(d, chars, offsets + lead + main, mask_or_null, B - lead - main, P, t, o + (lead + main) * rb, row_seqs,
+                                           hip_stream);
+        }
+    }
+    if (block_path != 1 && rb >= 16 && block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0) {
         std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());
         void *ws = nullptr;
         bsq_status wst = bsq_internal::workspace_acquire(two_pass_workspace_bytes(B, P), s, &ws);

@@ -123,8 +123,9 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
  * row t of this batch goes to out + t * row_seqs * C * sizeof(T).  What a rank of a sharded job needs to store its
  * sequences straight into the whole-batch tensor of another GPU (peer-mapped memory, sharding.store_shard_into_root), and what
  * a host batch that arrives in pieces is encoded with (staged batches, below).  A block whose position rows are whole 4-KiB
- * chunks (B * C * sizeof(T) and `out` multiples of 4096, e.g. k x 4096 sequences at a 4096-sequence boundary of an aligned
- * tensor, rows >= 16 bytes) runs at the speed of the whole-tensor kernels; any other block through the tiled kernel. */
+ * chunks (B * C * sizeof(T) and `out` multiples of 4096, rows >= 16 bytes) runs at the speed of the whole-tensor kernels; any
+ * other LARGE block is split inside the call into the sequences in front of its first chunk boundary, the run of whole chunks,
+ * and the rest (two short launches of the tiled kernel around the fast one); small blocks go through the tiled kernel. */
 bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                    const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out, int64_t row_seqs,
                                    void *hip_stream);

@@ -98,3 +98,34 @@ def test_column_blocks_made_of_whole_chunks(gpu, oracle, key, flags, dtype):
                 capi.check(lib.bsq_tuning_set(b"onehot_path", 0))
             assert (host[:guard] == 7).all() and (host[-guard:] == 7).all(), "wrote outside the tensor"
             assert host[guard:-guard].tobytes() == exp.tobytes(), (key, B, P, path)
+
+
+@pytest.mark.parametrize("mis", [8, 2560, 0])
+def test_large_ragged_blocks_split_into_head_chunks_tail(gpu, oracle, mis):
+    """A large block that neither starts nor ends on a 4-KiB chunk of the result (a ragged shard; a tensor torch aligned to 512 bytes)
+    is encoded as head + run of whole chunks + tail; blocks written in both orders, guard bytes around the tensor."""
+    import ctypes
+    import numpy as np
+    import torch
+    from bioseq_amd import capi, synth
+    lib = capi.load()
+    key, flags, P, B = "AMINO20", (1, 1, 0), 64, 40000
+    desc = capi.make_desc(key, *flags)
+    ora = oracle.OracleTokenizer(key, *flags)
+    C = ora.alphabet_size()  # 22: rows of 88 bytes, period 512 sequences
+    chars, offs = synth.synth_packed(11, B, 0, P - 2, synth.DIRTY)
+    exp = ora.onehot_packed(chars, offs, P, "f")
+    dchars, doffs = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+    nbytes = exp.nbytes
+    raw = torch.empty((nbytes + 3 * 4096,), dtype=torch.uint8, device=gpu)
+    start = (-raw.data_ptr()) % 4096 + 4096 + mis
+    blocks = [(0, 13001), (13001, 13002), (13002, 40000)]
+    for order in (blocks, blocks[::-1]):
+        raw.fill_(7)
+        for b0, b1 in order:
+            capi.check(lib.bsq_onehot_block_device(ctypes.byref(desc), dchars.data_ptr(), doffs[b0:].data_ptr(), None, b1 - b0, P, 4,
+                                                   raw.data_ptr() + start + b0 * C * 4, B, None))
+        torch.cuda.synchronize()
+        host = raw.cpu().numpy()
+        assert (host[:start] == 7).all() and (host[start + nbytes:] == 7).all(), "wrote outside the tensor"
+        assert host[start:start + nbytes].tobytes() == exp.tobytes(), (mis, order[0])
