@@ -276,9 +276,10 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
 
     layout: 'tokens_bf' -> (B, padlen) tokens and 'bcl' -> (B, C, padlen) one-hot: a rank's shard is one CONTIGUOUS slab of
     the result, written by the streaming kernels; 'tbc' -> the seq-first (padlen, B, C) one-hot: the shard is a column block
-    of every position row and goes through `bsq_onehot_block_device` (the tiled kernel with the root tensor's row pitch --
-    slower than the flat-stream kernels in HBM terms, 0.68 vs 0.93 of the roofline at cfg3, but the xGMI links, not HBM,
-    bound a remote store).  Returns the whole-batch tensor on `root`, None elsewhere."""
+    of every position row and goes through `bsq_onehot_block_device` (the two-pass stream with a gap after every position
+    row for the run of whole 4-KiB chunks of a large shard, the tiled kernel with the root tensor's row pitch for its ragged
+    ends and for small shards; the xGMI links, not HBM, bound a remote store).  Returns the whole-batch tensor on `root`,
+    None elsewhere."""
     import ctypes
 
     import torch
@@ -350,7 +351,7 @@ def _store_shard(lib, desc, dt, full, shard_chars, shard_offsets, b0, B, padlen,
             elif layout == "bcl":
                 capi.check(lib.bsq_onehot_bcl_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), None, nb, padlen, dt,
                                                      slab.data_ptr(), stream))
-            else:  # the tiled kernel with the root tensor's row pitch (bsq_onehot_block_device)
+            else:  # a column block of the root tensor (bsq_onehot_block_device)
                 capi.check(lib.bsq_onehot_block_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), None, nb, padlen, dt,
                                                        slab.data_ptr(), int(B), stream))
 
