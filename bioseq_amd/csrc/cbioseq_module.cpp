@@ -975,6 +975,40 @@ PYBIND11_MODULE(cbioseq, m) {
     m.attr("abi_version") = bsq_abi_version();
     m.def("device_count", [] { return bsq_device_count(); }, "Number of visible HIP devices");
     m.def("release_staging", [] { bsq_release_staging(); });
+    // The host half of the staged path without a device (tests, sanitizer runs): scan + pack `batch` piece by piece exactly as
+    // Tokenizer::staged does -- scan_pack_fast per piece, the general passes where it declines -- into ordinary memory.
+    // Returns (offsets int64[n + 1], chars uint8[total], first item longer than maxlen or -1, pieces that took the fast job).
+    m.def("_pack_list_in_pieces", [](py::sequence batch, int64_t piece, int64_t maxlen, int nthreads) {
+        Gathered g;
+        const Scan sc = scan_begin(batch, py::none(), g, nthreads);
+        if (piece <= 0) piece = std::max<int64_t>(1, sc.n);
+        std::vector<int64_t> offsets(size_t(sc.n) + 1, 0);
+        std::vector<uint8_t> chars(size_t(sc.n) * size_t(std::max<int64_t>(maxlen, 0)) + 8);
+        Packed p;
+        p.B = sc.n;
+        p.offsets = offsets.data();
+        p.chars = chars.data();
+        int64_t bad = -1, fast = 0;
+        for (int64_t lo = 0; lo < sc.n && bad < 0; lo += piece) {
+            const int64_t hi = std::min<int64_t>(sc.n, lo + piece);
+            if (scan_pack_fast(sc, g, p, lo, hi, nthreads, maxlen, &bad)) {
+                ++fast;
+                continue;
+            }
+            scan_range(sc, g, lo, hi, nthreads);
+            for (int64_t i = lo; i < hi && bad < 0; ++i) {
+                offsets[size_t(i) + 1] = offsets[size_t(i)] + int64_t(g.items[size_t(i)].len);
+                if (int64_t(g.items[size_t(i)].len) > maxlen) bad = i;
+            }
+            if (bad < 0) pack_range(g, p, lo, hi, nthreads);
+        }
+        const int64_t upto = bad >= 0 ? bad : sc.n;
+        py::array_t<int64_t> o(upto + 1);
+        std::memcpy(o.mutable_data(), offsets.data(), size_t(upto + 1) * 8);
+        py::array_t<uint8_t> c(offsets[size_t(upto)]);
+        if (offsets[size_t(upto)]) std::memcpy(c.mutable_data(), chars.data(), size_t(offsets[size_t(upto)]));
+        return py::make_tuple(o, c, bad, fast);
+    }, py::arg("batch"), py::arg("piece"), py::arg("maxlen"), py::arg("nthreads") = 0);
     m.def("alphabet_keys", [] {
         std::vector<std::string> k;
         for (int i = 0; i < bsq_num_keys(); ++i) k.emplace_back(bsq_key_name(i));

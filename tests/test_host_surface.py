@@ -134,6 +134,14 @@ def test_no_gpu_means_loud_failure(bsq):
         tok.batch_onehot_encode(["ACGT"], padlen=8)
     with pytest.raises(RuntimeError, match="no HIP device"):
         tok.onehot_packed(np.frombuffer(b"ACGT", dtype=np.uint8), np.array([0, 4]), 8, "f")
+    # the staged-batch API has nothing to stage into either (and hands out no buffers)
+    import ctypes
+    from bioseq_amd import capi
+    lib = capi.load()
+    stage, off, chars, mask = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    st = lib.bsq_stage_begin(10, 100, 0, None, ctypes.byref(stage), ctypes.byref(off), ctypes.byref(chars), ctypes.byref(mask))
+    assert st == 5 and not stage.value and b"no HIP device" in lib.bsq_strerror(st)  # BSQ_ERR_NO_DEVICE
+    assert lib.bsq_stage_end(None) == 0
 
 
 def test_parallel_item_scan_runs_before_the_device_is_needed(bsq):
@@ -152,3 +160,35 @@ def test_parallel_item_scan_runs_before_the_device_is_needed(bsq):
     if bsq.device_count() == 0:
         with pytest.raises(RuntimeError, match="no HIP device"):
             tok.batch_tokenize(items, padlen=40, nthreads=4)
+
+
+def test_scan_and_pack_in_pieces_without_a_device(bsq):
+    """The host half of the staged path (list -> device result in pieces): one pool job per piece scans the items, meets at a
+    barrier, derives the offsets and copies the bytes; pieces with other item types take the general passes; an item longer than
+    maxlen stops before a byte of its piece is copied.  Runs without a GPU (and under the sanitizers, scripts/asan_host.sh)."""
+    from bioseq_amd import cbioseq
+    rng = np.random.default_rng(3)
+    n, maxlen = 20000, 60
+    lens = rng.integers(0, maxlen + 1, n)
+    raw = [bytes(rng.integers(65, 91, int(k), dtype=np.uint8)) for k in lens]
+    want_off = np.concatenate([[0], np.cumsum(lens)])
+    want = b"".join(raw)
+    for items, fast_expected in (([r if i % 3 else r.decode() for i, r in enumerate(raw)], True),
+                                 ([bytearray(r) if i % 2 else r for i, r in enumerate(raw)], True),
+                                 ([np.frombuffer(r, dtype=np.uint8) if i == 7000 else r for i, r in enumerate(raw)], False)):
+        for piece, nt in ((0, 8), (4096, 4), (4096, 16), (1000, 3), (256, 64)):
+            off, chars, bad, fast = cbioseq._pack_list_in_pieces(items, piece, maxlen, nt)
+            assert bad == -1 and off.tolist() == want_off.tolist() and chars.tobytes() == want, (piece, nt)
+            npieces = 1 if piece == 0 else -(-n // piece)
+            if piece == 256:
+                assert fast == 0  # (pieces of fewer than 512 items are not worth a pool job: the serial passes)
+            else:
+                assert fast == (npieces if fast_expected else npieces - 1), (piece, nt, fast)  # (the numpy item's piece declines)
+    late = list(raw)
+    late[15000] = b"A" * (maxlen + 1)
+    late[18000] = b"A" * (maxlen + 5)
+    off, chars, bad, fast = cbioseq._pack_list_in_pieces(late, 4096, maxlen, 8)
+    assert bad == 15000 and off.tolist() == want_off[:15001].tolist()
+    assert chars.tobytes()[:want_off[12288]] == want[:want_off[12288]]  # (the pieces before the one that holds item 15000; of that one only the offsets)
+    off, chars, bad, fast = cbioseq._pack_list_in_pieces([], 4096, maxlen, 8)
+    assert bad == -1 and off.tolist() == [0] and chars.size == 0
