@@ -498,8 +498,9 @@ class Tokenizer {
     // A list -> DEVICE result in pieces (include/bsq.h, "staged batches"): items [lo, hi) are scanned, packed into the pinned staging
     // area, sent on their way and encoded as a block of the result while the next piece is scanned and packed -- the call costs
     // one piece of host work + the upload + one piece of kernel instead of the sum of the three.  false = not applicable (small
-    // batch, numpy result, knob host_pieces = 1): nothing has been scanned, the caller goes on with the whole-batch path.  The GIL stays held as it
-    // is during every pack (the items must stay alive and unchanged); nothing in here blocks on the GPU.
+    // batch, numpy result, knob host_pieces = 1): nothing has been scanned, the caller goes on with the whole-batch path.
+    // The GIL stays held as it is during every pack (the items must stay alive and unchanged); nothing in here blocks on the
+    // GPU except the wait for the staging slot used three calls ago.
     template <typename BlockFn>
     bool staged(const Scan &sc, Gathered &g, py::ssize_t padlen, int nthreads, const OutBuf &out, bool splittable, size_t block_row_bytes,
                 bool onehot, BlockFn block) const {
