@@ -1618,7 +1618,7 @@ __global__ __launch_bounds__(kThreads) void k_tokenize_generic(const GParams p) 
             b = e - t * p.B;
         }
         const int32_t tk = token_at(p, b, t);
-        out[e] = tk >= 0 ? static_cast<T>(tk) : T(0);
+        out[p.batch_first ? e : t * p.row_seqs + b] = tk >= 0 ? static_cast<T>(tk) : T(0);
     }
 }
 
@@ -2211,6 +2211,8 @@ bsq_status launch_expand_bcl(const uint8_t *tokens, int64_t B, int64_t P, int32_
 
 static bsq_status onehot_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null, int64_t B,
                                        int64_t P, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream);
+static bsq_status tokenize_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
+                                         int32_t batch_first, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream);
 
 extern "C" {
 
@@ -2652,11 +2654,36 @@ void bsq_fused_status_clear(void) { bsq_internal::fused_failures_clear(); }
 bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                        int64_t B, int64_t P, int32_t batch_first, bsq_dtype t, void *out,
                                        void *hip_stream) {
+    return tokenize_generic_block(d, chars, offsets, B, P, batch_first, t, out, B, hip_stream);
+}
+
+// The (P, B) token matrix as a COLUMN BLOCK of a wider (P, row_seqs) matrix: `out` points at element (0, b0) of it.  The block form of
+// batch_tokenize's default layout -- pieces of a host batch (staged batches), a rank's shard stored into another GPU's matrix.
+// 1-, 2- and 8-byte types of alphabets with ids < 251 run through k_tokens_pb8_fast at the speed of the whole matrix; the rest
+// through the generic kernel (correct, slow: callers that care split only the fast types).
+bsq_status bsq_tokenize_block_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
+                                     bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream) {
+    if (row_seqs < B) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "row_seqs < B");
+    if (row_seqs == B) return bsq_tokenize_device(d, chars, offsets, B, P, 0, t, out, hip_stream);
+    if (!d || B < 0 || P <= 0 || (B > 0 && (!offsets || !out)))
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
+    if (B == 0) return BSQ_OK;
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    if (reinterpret_cast<uintptr_t>(out) % sz) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output is not aligned to its element size");
+    if (row_seqs < (int64_t(1) << 31) && bsq_internal::tokens_pb8_applicable(d, B, P, out, row_seqs, t))
+        return bsq_internal::launch_tokens_pb8(d, chars, offsets, B, P, out, row_seqs, static_cast<hipStream_t>(hip_stream), false, t);
+    return tokenize_generic_block(d, chars, offsets, B, P, 0, t, out, row_seqs, hip_stream);
+}
+
+static bsq_status tokenize_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
+                                         int32_t batch_first, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream) {
     if (!d || B < 0 || P <= 0 || (B > 0 && (!offsets || !out)))  // (an EMPTY batch -- a rank without sequences -- has nothing to point at)
         return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
     if (B == 0) return BSQ_OK;
     GParams g;
     fill_generic(g, d, chars, offsets, nullptr, B, P, batch_first != 0, out);
+    g.row_seqs = row_seqs;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const unsigned grid = generic_grid(P * B);
 #define BSQ_GEN(T) hipLaunchKernelGGL((k_tokenize_generic<T>), dim3(grid), dim3(kThreads), 0, s, g)

@@ -851,6 +851,9 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     __syncthreads();
 
     // ---- the tile's position rows: TB * SZ contiguous bytes of the output each (pitch in ELEMENTS) ----
+    // columns that exist: the scratch of the two-pass one-hot is written up to its padded pitch; a token matrix has B of them --
+    // its row stride may be larger: a COLUMN BLOCK of a wider (P, pitch) matrix (bsq_tokenize_block_device)
+    const int64_t ncols = (packed & 2u) ? pitch : static_cast<int64_t>(B);
     constexpr int N = 16 / SZ;     // tokens per 16-byte store
     constexpr int PPR = TB / N;    // stores per tile row
     static_assert((TT * PPR) % kThreads == 0 && (PPR & (PPR - 1)) == 0, "row walk");
@@ -861,7 +864,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
             const int rr = f / PPR, piece = f % PPR;           // physical row rr holds position 16 (rr % 4) + rr / 4
             const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
             const int64_t col = static_cast<int64_t>(tb) * TB + piece * N;
-            if (t < static_cast<int32_t>(P) && col < pitch)
+            if (t < static_cast<int32_t>(P) && col < ncols)
                 store16<NT>(out + (static_cast<int64_t>(t) * pitch + col) * SZ, widen_tokens<SZ, FLT>(s_t + rr * STRIDE + piece * N));
         }
     } else {
@@ -872,7 +875,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
         static_assert(!UA || (SZ <= 2 && !FLT), "unaligned rows: 1- and 2-byte integers");
         constexpr int SLOTS = PPR + 1;
         const int64_t c_tile = static_cast<int64_t>(tb) * TB;
-        const int32_t nb = pitch - c_tile < TB ? static_cast<int32_t>(pitch - c_tile) : TB;  // elements of the tile's row segment
+        const int32_t nb = ncols - c_tile < TB ? static_cast<int32_t>(ncols - c_tile) : TB;  // elements of the tile's row segment
         for (int f = tid; f < TT * SLOTS; f += kThreads) {
             const int rr = f / SLOTS, slot = f % SLOTS;
             const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
@@ -1208,7 +1211,8 @@ bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
     // rows / outputs that are only element-aligned: the UA form (1- and 2-byte integers; its stores are cut at the output's
     // 16-byte lines).  65 537 x 1024 int8 42.8 -> 27.5 us, 65 000 x 1024 int8 30.2 -> 25.0, 100 001 x 512 int16 34.0 -> 28.8
     // (profiles/r03/pb8_unaligned_rows.txt).  Knob tokens_pb8 = 3: aligned shapes only.
-    const bool aligned = (pitch * sz) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+    // (a column block -- pitch > B, final matrix -- must also END on a 16-byte line for the aligned form: its last store is whole)
+    const bool aligned = (pitch * sz) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && (B * sz) % 16 == 0;
     if (!aligned && (sz > 2 || tuning().tokens_pb8 == 3 || reinterpret_cast<uintptr_t>(out) % uintptr_t(sz) != 0)) return false;
     return B > 0 && P >= 1 && P <= (int64_t(1) << 30) && B < (int64_t(1) << 31) - 4096 && pitch >= B && pitch < (int64_t(1) << 31) &&
            bsq_alphabet_size(d) <= 250;
@@ -1253,7 +1257,8 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     const int64_t ntb = (B + TB - 1) / TB, ntt = (P + TT - 1) / TT;
     const int64_t blocks = (ntb + 7) / 8 * 8 * ntt;
     if (blocks >= (int64_t(1) << 31)) return set_error(BSQ_ERR_INVALID_ARG, "output too large");
-    const bool ua = !((pitch * int64_t(bsq_dtype_size(t))) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    const bool ua = !((pitch * int64_t(bsq_dtype_size(t))) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
+                      (raw || (B * int64_t(bsq_dtype_size(t))) % 16 == 0));
     uint32_t magic = 0, shift = 0, pow2 = 0;
     div_constants((contig || ua) ? uint32_t((ntb + 7) / 8) : uint32_t(ntt), &magic, &shift, &pow2);  // the divisor of the block index
     if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)

@@ -558,11 +558,16 @@ class Tokenizer {
         const py::ssize_t nb = py::ssize_t(sc.n);
         make_out(out, batch_first ? std::vector<py::ssize_t>{nb, padlen} : std::vector<py::ssize_t>{padlen, nb}, t, device);
         const size_t row = size_t(padlen) * bsq_dtype_size(t);
-        // (batch-first: a piece is rows [lo, lo + n); seq-first: always one piece, lo == 0)
-        if (staged(sc, g, padlen, nthreads, out, batch_first, 0, false,
+        // batch-first: a piece is rows [lo, lo + n) of (B, P); seq-first: a column block of (P, B) -- split only for the types that
+        // run through k_tokens_pb8_fast as a block (1, 2, 8 bytes, ids < 251), one piece otherwise
+        const size_t tsz = bsq_dtype_size(t);
+        const bool sf_blocks = (tsz == 1 || tsz == 2 || (tsz == 8 && nb % 2 == 0)) && bsq_alphabet_size(&desc) <= 250;  // (8-byte: whole 16-byte lines)
+        if (staged(sc, g, padlen, nthreads, out, batch_first || sf_blocks, 0, false,
                    [&](const uint8_t *chars, const int64_t *offsets, const uint8_t *, int64_t lo, int64_t n) {
-                       return bsq_tokenize_device(&desc, chars, offsets, n, padlen, batch_first, t, static_cast<char *>(out.ptr) + size_t(lo) * row,
-                                                  out.stream);
+                       if (batch_first)
+                           return bsq_tokenize_device(&desc, chars, offsets, n, padlen, 1, t, static_cast<char *>(out.ptr) + size_t(lo) * row, out.stream);
+                       return bsq_tokenize_block_device(&desc, chars, offsets, n, padlen, t, static_cast<char *>(out.ptr) + size_t(lo) * tsz, int64_t(nb),
+                                                        out.stream);
                    }))
             return out.obj;
         if (!device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);

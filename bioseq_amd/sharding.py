@@ -275,7 +275,8 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
     broadcast (the handle) before, one barrier after.  Collective call (every rank of the group).
 
     layout: 'tokens_bf' -> (B, padlen) tokens and 'bcl' -> (B, C, padlen) one-hot: a rank's shard is one CONTIGUOUS slab of
-    the result, written by the streaming kernels; 'tbc' -> the seq-first (padlen, B, C) one-hot: the shard is a column block
+    the result, written by the streaming kernels; 'tokens_sf' -> the (padlen, B) token matrix (batch_tokenize's default layout):
+    a column block through `bsq_tokenize_block_device`; 'tbc' -> the seq-first (padlen, B, C) one-hot: the shard is a column block
     of every position row and goes through `bsq_onehot_block_device` (the two-pass stream with a gap after every position
     row for the run of whole 4-KiB chunks of a large shard, the tiled kernel with the root tensor's row pitch for its ragged
     ends and for small shards; the xGMI links, not HBM, bound a remote store).  Returns the whole-batch tensor on `root`,
@@ -287,8 +288,8 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
     from . import capi
     dist = _dist()
     rank = dist.get_rank(group)
-    if layout not in ("tokens_bf", "bcl", "tbc"):
-        raise ValueError("layout must be 'tokens_bf', 'bcl' or 'tbc'")
+    if layout not in ("tokens_bf", "tokens_sf", "bcl", "tbc"):
+        raise ValueError("layout must be 'tokens_bf', 'tokens_sf', 'bcl' or 'tbc'")
     lib = capi.load()
     desc = capi.make_desc(tokenizer.key, tokenizer.includes_eos(), tokenizer.includes_bos(), tokenizer.is_padded())
     C = int(tokenizer.alphabet_size())
@@ -296,7 +297,7 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
     capi.check(lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt)))
     tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt.value]
     dev = torch.device(device)
-    shape = {"tokens_bf": (int(B), padlen), "bcl": (int(B), C, padlen), "tbc": (padlen, int(B), C)}[layout]
+    shape = {"tokens_bf": (int(B), padlen), "tokens_sf": (padlen, int(B)), "bcl": (int(B), C, padlen), "tbc": (padlen, int(B), C)}[layout]
     # Everything a rank can fail at on its own (mapping the root's memory, an invalid shard, an encode error) is caught and
     # agreed on by ALL ranks below: one bad shard must raise everywhere, not leave the others waiting in a barrier.
     failure = None
@@ -338,8 +339,8 @@ def _store_shard(lib, desc, dt, full, shard_chars, shard_offsets, b0, B, padlen,
     nb = int(of.shape[0]) - 1
     if nb > 0:
         # 'tbc': this rank's sequences are a COLUMN BLOCK of every position row of the (P, B, C) tensor
-        slab = full[:, b0:b0 + nb] if layout == "tbc" else full[b0:b0 + nb]
-        assert layout == "tbc" or (slab.is_contiguous() and slab.shape[0] == nb)
+        slab = full[:, b0:b0 + nb] if layout in ("tbc", "tokens_sf") else full[b0:b0 + nb]
+        assert layout in ("tbc", "tokens_sf") or (slab.is_contiguous() and slab.shape[0] == nb)
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             if validate:
@@ -348,6 +349,9 @@ def _store_shard(lib, desc, dt, full, shard_chars, shard_offsets, b0, B, padlen,
             if layout == "tokens_bf":
                 capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), nb, padlen, 1, dt,
                                                    slab.data_ptr(), stream))
+            elif layout == "tokens_sf":  # batch_tokenize's default layout: a column block of the root's (P, B) matrix
+                capi.check(lib.bsq_tokenize_block_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), nb, padlen, dt,
+                                                         slab.data_ptr(), int(B), stream))
             elif layout == "bcl":
                 capi.check(lib.bsq_onehot_bcl_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), None, nb, padlen, dt,
                                                      slab.data_ptr(), stream))

@@ -129,6 +129,12 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
 bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                    const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out, int64_t row_seqs,
                                    void *hip_stream);
+/* batch_tokenize's DEFAULT layout -- the (P, B) token matrix -- as a column block of a wider (P, row_seqs) matrix: `out` points at
+ * element (0, b0).  1-, 2- and 8-byte types of alphabets with ids < 251 at the speed of the whole matrix (any block width: widths
+ * that are not a multiple of 16 bytes take the element-aligned form of 1- / 2-byte types); everything else through the generic
+ * kernel.  (The (B, P) matrix needs no block form: rows [b0, b0 + n) are contiguous -- bsq_tokenize_device on a sub-batch.) */
+bsq_status bsq_tokenize_block_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
+                                     bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream);
 /* Name of the kernel(s) bsq_onehot_device would launch for this shape (profiling / bench labels). */
 const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_dtype t);
 /* Same results through the simple one-thread-per-element kernels (any shape/alignment/alphabet).

@@ -31,6 +31,11 @@ def main():
                 ok = ok and got.cpu().numpy().tobytes() == ora.tokenize_packed(chars, offs, P, "b", True).tobytes()
             else:
                 ok = ok and got is None
+            got = sharding.encode_into_root(tok, chars, offs, P, "b", "tokens_sf", dev, root=root)  # (P, B): column blocks
+            if rank == root:
+                ok = ok and got.cpu().numpy().tobytes() == ora.tokenize_packed(chars, offs, P, "b", False).tobytes()
+            else:
+                ok = ok and got is None
             got = sharding.encode_into_root(tok, chars, offs, P, "f", "bcl", dev, root=root)
             if rank == root:
                 exp = np.ascontiguousarray(ora.onehot_packed(chars, offs, P, "f").transpose(1, 2, 0))

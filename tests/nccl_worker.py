@@ -55,7 +55,8 @@ def main():
             ok = ok and (same(r, full_oh) if rank == root else r is None)
             r = sharding.gather_direct(keep_bf.contiguous(), 0, B, root)
             ok = ok and (same(r, full_bf) if rank == root else r is None)
-            for dc, layout, want in (("b", "tokens_bf", full_bf), ("f", "bcl", np.ascontiguousarray(full_oh.transpose(1, 2, 0))), ("f", "tbc", full_oh)):
+            for dc, layout, want in (("b", "tokens_bf", full_bf), ("b", "tokens_sf", full_sf), ("f", "bcl", np.ascontiguousarray(full_oh.transpose(1, 2, 0))),
+                                     ("f", "tbc", full_oh)):
                 got = sharding.encode_into_root(tok, chars, offs, P, dc, layout, dev, root=root)
                 ok = ok and (same(got, want) if rank == root else got is None)
                 del got

@@ -129,3 +129,36 @@ def test_large_ragged_blocks_split_into_head_chunks_tail(gpu, oracle, mis):
         host = raw.cpu().numpy()
         assert (host[:start] == 7).all() and (host[start + nbytes:] == 7).all(), "wrote outside the tensor"
         assert host[start:start + nbytes].tobytes() == exp.tobytes(), (mis, order[0])
+
+
+@pytest.mark.parametrize("key,flags,dtype", [("AMINO20", (1, 1, 1), "b"), ("DNA", (0, 1, 0), "h"), ("SEB8", (1, 0, 1), "q"), ("AMINO20", (0, 0, 0), "i"),
+                                             ("DNA5", (1, 1, 0), "f"), ("BYTES", (1, 1, 1), "h")])
+def test_seq_first_tokens_written_as_column_blocks(gpu, oracle, key, flags, dtype):
+    """bsq_tokenize_block_device: shards written side by side into ONE (P, B) token matrix == the oracle's matrix of the whole batch;
+    ragged and unaligned block widths, both orders, guard bytes; the fast types (b, h, q) and the generic fallback (i, f, BYTES)."""
+    import ctypes
+    import numpy as np
+    import torch
+    from bioseq_amd import capi, synth
+    lib = capi.load()
+    desc = capi.make_desc(key, *flags)
+    ora = oracle.OracleTokenizer(key, *flags)
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(dtype.encode(), ctypes.byref(dt)))
+    tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt.value]
+    for B, P, cuts in ((1000, 130, (0, 333, 334, 1000)), (70000, 40, (0, 4096, 30000, 30002, 70000)), (8192, 64, (0, 4096, 8192))):
+        chars, offs = synth.synth_packed(B + P, B, 0, P - 2, synth.DIRTY)
+        exp = ora.tokenize_packed(chars, offs, P, dtype, False)
+        dchars, doffs = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+        guard = 64
+        blocks = list(zip(cuts[:-1], cuts[1:]))
+        for order in (blocks, blocks[::-1]):
+            buf = torch.full((P * B + 2 * guard,), 7, dtype=tdt, device=gpu)
+            full = buf[guard:guard + P * B].view(P, B)
+            for b0, b1 in order:
+                capi.check(lib.bsq_tokenize_block_device(ctypes.byref(desc), dchars.data_ptr(), doffs[b0:].data_ptr(), b1 - b0, P, dt,
+                                                         full[:, b0:b1].data_ptr(), B, None))
+            torch.cuda.synchronize()
+            host = buf.cpu().numpy()
+            assert (host[:guard] == 7).all() and (host[-guard:] == 7).all(), "wrote outside the matrix"
+            assert host[guard:-guard].tobytes() == exp.tobytes(), (key, dtype, B, P, order[0])
