@@ -114,7 +114,19 @@ def cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, cap_threads=Non
             model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
     except OSError:
         pass
-    return {"cpu_model": model, "value": total / dt / 1e9, "unit": "Gseq-chars/s", "cores": nthreads, "kind": kind,
+    cfg1_us = None
+    if ref is not None:  # BASELINE configs[0] as the reference runs it: 1000 DNA sequences, nthreads = 1 (its default), median of 50 calls
+        c1 = synth.CONFIGS["cfg1"]
+        ch, of = synth.synth_packed(c1["seed"], c1["n"], c1["lo"], c1["hi"], c1["letters"])
+        s1 = synth.unpack(ch, of, as_str=True)
+        t1 = ref.Tokenizer(c1["key"], bool(c1["eos"]), bool(c1["bos"]), bool(c1["padchar"]))
+        ts = []
+        for _ in range(55):
+            t0 = time.perf_counter()
+            t1.batch_tokenize(s1, padlen=c1["padlen"], batch_first=True, nthreads=1)
+            ts.append(time.perf_counter() - t0)
+        cfg1_us = float(np.median(ts[5:]) * 1e6)
+    return {"cpu_model": model, "value": total / dt / 1e9, "unit": "Gseq-chars/s", "cores": nthreads, "kind": kind, "cfg1_call_us": cfg1_us,
             "gb_per_s_written": nbytes / dt / 1e9, "seconds": dt, "host_cpus": cores,
             "opt": "-O3 without -march=native (oracle/Makefile); the reference itself ships -O0 -march=native (setup.py:50-55)",
             "sample": "the full batch of this workload (%d sequences, %d chars, %.2f GB output), one call incl. "
@@ -183,7 +195,18 @@ def e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev):
         finally:
             capi.check(lib.bsq_tuning_set(b"host_pieces", 0))
 
-    out = {"nthreads": nthreads, "sequences": len(seqs), "host_cpus": os.cpu_count(),
+    def cfg1_call_us():
+        """BASELINE configs[0] -- the reference's own CPU-runnable case: pbeos_tokenizers['DNA'].batch_tokenize on 1000 sequences of
+        len <= 256, padlen 256, batch_first -- as a latency: one call -> numpy (the reference's return), one call -> device + sync.
+        A call this small is fixed costs; `cpu_baseline.cfg1_call_us` is the reference's own C++ on this box (nthreads = 1)."""
+        c1 = synth.CONFIGS["cfg1"]
+        ch, of = synth.synth_packed(c1["seed"], c1["n"], c1["lo"], c1["hi"], c1["letters"])
+        s1 = synth.unpack(ch, of, as_str=True)
+        t1 = bioseq_amd.Tokenizer(c1["key"], bool(c1["eos"]), bool(c1["bos"]), bool(c1["padchar"]))
+        return {"tokens_to_numpy_us": median_ms(lambda: t1.batch_tokenize(s1, padlen=c1["padlen"], batch_first=True), 200) * 1e3,
+                "tokens_to_device_sync_us": median_ms(lambda: t1.batch_tokenize(s1, padlen=c1["padlen"], batch_first=True, device=dev), 200) * 1e3}
+
+    out = {"nthreads": nthreads, "sequences": len(seqs), "host_cpus": os.cpu_count(), "cfg1_call": cfg1_call_us(),
            "list_to_device_sync_ms": median_ms(lambda: call(dev), 10),
            "list_to_device_sync_one_upload_one_encode_ms": whole_batch_ms(),
            "list_to_device_sync_default_nthreads_ms": median_ms(lambda: (tok.batch_onehot_encode(seqs, padlen=P, destchar=destchar, device=dev) if op == "onehot" else tok.batch_tokenize(seqs, padlen=P, destchar=destchar, batch_first=batch_first, device=dev)), 10),

@@ -157,6 +157,22 @@ bsq_status upload(InSlot &s, const uint8_t *chars, const int64_t *offsets, const
     if (st != BSQ_OK) return st;
     char *base = static_cast<char *>(s.d_in);
     g_upload_bytes.fetch_add(uint64_t(B + 1) * 8 + uint64_t(total) * (mask ? 2 : 1), std::memory_order_relaxed);
+    // A batch packed as offsets | chars | mask in ONE span of memory (what the pybind layer packs into bsq_pinned_scratch) goes up
+    // as one copy, the device pointers at the same distances: a call of BASELINE config 1's size (1000 sequences) is ~70 us of
+    // fixed costs, a hipMemcpyAsync 5-8 us of them.
+    const char *h0 = reinterpret_cast<const char *>(offsets), *h1 = reinterpret_cast<const char *>(chars),
+               *h2 = reinterpret_cast<const char *>(mask);
+    const size_t d1 = size_t(h1 - h0), d2 = mask ? size_t(h2 - h0) : 0;
+    const bool one_span = total && h1 >= h0 + size_t(B + 1) * 8 && d1 <= off_bytes && (!mask || (h2 >= h1 + total && d2 - d1 <= chr_bytes));
+    if (one_span) {
+        const size_t span = (mask ? d2 : d1) + total;
+        const hipError_t e1 = hipMemcpyAsync(base, offsets, span, hipMemcpyHostToDevice, stream);
+        if (e1 != hipSuccess) return bsq_internal::set_hip_error("hipMemcpyAsync(H2D)", e1);
+        db->offsets = reinterpret_cast<const int64_t *>(base);
+        db->chars = reinterpret_cast<const uint8_t *>(base + d1);
+        db->mask = mask ? reinterpret_cast<const uint8_t *>(base + d2) : nullptr;
+        return BSQ_OK;
+    }
     hipError_t e = hipMemcpyAsync(base, offsets, size_t(B + 1) * 8, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess && total) e = hipMemcpyAsync(base + off_bytes, chars, total, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess && mask && total)
@@ -358,12 +374,16 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
     }
     // Upload on the copy stream (the slot is idle: waited for above or in bsq_pinned_scratch), then make the
     // caller's stream wait for it: the copy overlaps whatever that stream is still running (the previous encode).
+    // (A small batch goes up on the caller's stream itself: nothing worth overlapping, and the event pair costs 4-6 us of a ~50-us call.)
     DeviceBatch db;
-    st = upload(*slot, chars, offsets, mask, B, s.copy_stream, &db);
+    const bool small = size_t(offsets[B]) * (mask ? 2 : 1) + size_t(B + 1) * 8 < (size_t(256) << 10);
+    st = upload(*slot, chars, offsets, mask, B, small ? stream : s.copy_stream, &db);
     if (st != BSQ_OK) return st;
-    hipError_t eu = hipEventRecord(s.uploaded, s.copy_stream);
-    if (eu == hipSuccess) eu = hipStreamWaitEvent(stream, s.uploaded, 0);
-    if (eu != hipSuccess) return bsq_internal::set_hip_error("upload -> encode dependency", eu);
+    if (!small) {
+        hipError_t eu = hipEventRecord(s.uploaded, s.copy_stream);
+        if (eu == hipSuccess) eu = hipStreamWaitEvent(stream, s.uploaded, 0);
+        if (eu != hipSuccess) return bsq_internal::set_hip_error("upload -> encode dependency", eu);
+    }
     void *dev_out = out;
     if (out_space == BSQ_SPACE_HOST) {
         st = grow_device(&s.d_out, &s.d_out_cap, out_bytes);

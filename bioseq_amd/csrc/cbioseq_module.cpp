@@ -391,6 +391,27 @@ struct OutBuf {
     }
 };
 
+// torch, looked up once (a call of BASELINE config 1's size is ~70 us of fixed costs; module / attribute lookups and the
+// torch.cuda.device context manager were ~15 of them).  Leaked on purpose: destroying py::objects at interpreter exit is not safe.
+struct TorchApi {
+    py::object device, empty, current_stream, current_device, cuda_device, dtypes[6];
+};
+const TorchApi &torch_api() {
+    static const TorchApi *api = [] {
+        py::module_ torch = py::module_::import("torch");
+        TorchApi *a = new TorchApi();
+        a->device = torch.attr("device");
+        a->empty = torch.attr("empty");
+        a->current_stream = torch.attr("cuda").attr("current_stream");
+        a->current_device = torch.attr("cuda").attr("current_device");
+        a->cuda_device = torch.attr("cuda").attr("device");
+        const char *names[6] = {"int8", "int16", "int32", "int64", "float32", "float64"};  // (BSQ_U64 -> int64: see below)
+        for (int i = 0; i < 6; ++i) a->dtypes[i] = torch.attr(names[i]);
+        return a;
+    }();
+    return *api;
+}
+
 void make_out(OutBuf &o, const std::vector<py::ssize_t> &shape, bsq_dtype t, const py::object &device) {
     if (device.is_none()) {
         py::array a(py::dtype(numpy_dtype_name(t)), shape);
@@ -399,18 +420,23 @@ void make_out(OutBuf &o, const std::vector<py::ssize_t> &shape, bsq_dtype t, con
         o.space = BSQ_SPACE_HOST;
         return;
     }
-    py::module_ torch = py::module_::import("torch");
-    py::object dev = torch.attr("device")(device);
+    const TorchApi &T = torch_api();
+    py::object dev = T.device(device);
     if (dev.attr("type").cast<std::string>() != "cuda")
         throw std::invalid_argument("device= must be a HIP ('cuda') device; omit it for a numpy result");
-    o.guard = torch.attr("cuda").attr("device")(dev);
-    o.guard.attr("__enter__")();
+    // make `device=` the current device for the staging buffers and the launch -- through torch's context manager only when it
+    // is not the current one already (the common case)
+    const py::object index = dev.attr("index");
+    if (!index.is_none() && index.cast<int>() != T.current_device().cast<int>()) {
+        o.guard = T.cuda_device(dev);
+        o.guard.attr("__enter__")();
+    }
     // 'l' / 'q' results are uint64 in numpy (the reference's type); as device tensors they are torch.int64 -- same
     // bits for token ids and 0/1, and torch.uint64 does not exist before torch 2.3 and supports almost no ops after
-    py::object ten = torch.attr("empty")(py::cast(shape), py::arg("dtype") = torch.attr(t == BSQ_U64 ? "int64" : numpy_dtype_name(t)),
-                                         py::arg("device") = dev);
+    static const int dtype_index[6] = {0, 1, 2, 3, 4, 5};  // bsq_dtype order: I8, I16, I32, U64, F32, F64
+    py::object ten = T.empty(py::cast(shape), py::arg("dtype") = T.dtypes[dtype_index[int(t)]], py::arg("device") = dev);
     o.ptr = reinterpret_cast<void *>(ten.attr("data_ptr")().cast<uintptr_t>());
-    o.stream = reinterpret_cast<void *>(torch.attr("cuda").attr("current_stream")().attr("cuda_stream").cast<uintptr_t>());
+    o.stream = reinterpret_cast<void *>(T.current_stream().attr("cuda_stream").cast<uintptr_t>());
     o.obj = ten;
     o.space = BSQ_SPACE_DEVICE;
 }
