@@ -170,12 +170,15 @@ class FlatFile:
         c0, c1 = int(self._offsets[start]), int(self._offsets[stop])
         return chars[c0:c1], o - o[0]
 
-    def gather_device(self, indices, device="cuda", validate=True):
+    def gather_device(self, indices, device="cuda", validate=True, distinct=False):
         """Packed batch (chars, offsets) of the sequences `indices` -- any order, repeats allowed -- rebuilt ON THE
         DEVICE from the uploaded store (`bsq_gather_packed_device`): what a shuffling sampler needs, with no host gather
         and no upload of characters.  `indices`: an int64 tensor already on `device` (nothing crosses PCIe at all) or a
         host list / array (range-checked here, 8 bytes per index uploaded).  The returned `chars` tensor may be longer
-        than the batch (device indices: sized by a bound); only its first offsets[-1] bytes belong to it."""
+        than the batch (device indices: sized by a bound); only its first offsets[-1] bytes belong to it.
+        validate=False: a device index tensor the caller vouches for (in range) -- nothing is read back, the call never
+        synchronises; with distinct=True (no index twice: a sampler's permutation) the buffer is sized by the n longest
+        sequences of the store instead of n times the longest."""
         import ctypes
         import torch
         from . import capi
@@ -199,7 +202,7 @@ class FlatFile:
         # call is repeated with the unconditional bound n * longest (unchecked lists, validate=False, start there).
         if not on_device:
             capacity = int((self._offsets[host + 1] - self._offsets[host]).sum()) if n else 0
-        elif validate and n <= self._n:
+        elif (validate or distinct) and n <= self._n:
             capacity = int(self._top_lengths_cumsum()[n - 1]) if n else 0
         else:
             capacity = n * self._longest

@@ -62,14 +62,15 @@ class FlatFileDataset(torch.utils.data.Dataset):
     def __len__(self):
         return self.ff.nseqs()
 
-    def _packed_device(self, start, stop, indices=None):
-        """The batch's own packed copy on the device (never the resident store when it is going to be mutated)."""
+    def _packed_device(self, start, stop, indices=None, trusted=False):
+        """The batch's own packed copy on the device (never the resident store when it is going to be mutated).
+        trusted: `indices` is this dataset's own permutation (in range, no repeats) -- nothing to check, nothing read back."""
         if indices is None:
             chars, offs = self.ff.packed_device(start, stop, self.device)
             if self.augment:
                 chars = chars.clone()  # never mutate the resident store
         else:  # arbitrary index set (a shuffling sampler): rebuilt on the device from the resident store, no host gather
-            chars, offs = self.ff.gather_device(indices, self.device)
+            chars, offs = self.ff.gather_device(indices, self.device, validate=not trusted, distinct=trusted)
         return chars, offs
 
     def _encode(self, chars, offs):
@@ -83,10 +84,12 @@ class FlatFileDataset(torch.utils.data.Dataset):
                 return blosum.augment_tokenize_packed(self.tokenizer, chars, offs, self.max_seq_len, self.token_dtype, True,
                                                       chain_len=self.augment, augment_frac=self.augment_frac, seed=seed)
             blosum.augment_packed(chars, offs, self.augment, self.augment_frac, seed)
+        # validate=False: every batch cut or gathered from the store has well-formed offsets and no sequence longer than
+        # ff.maxseqlen (= max_seq_len - bos - eos) -- the device-side check would only add a synchronising read-back (~30 us) per batch
         if self.cnn:
-            return self.tokenizer.onehot_packed(chars, offs, self.max_seq_len, "f", layout="bcl")
+            return self.tokenizer.onehot_packed(chars, offs, self.max_seq_len, "f", layout="bcl", validate=False)
         # int64 rows written by the kernel itself ('q'), not int8 + a .to(torch.long) pass over the matrix
-        return self.tokenizer.tokenize_packed(chars, offs, self.max_seq_len, self.token_dtype, True)
+        return self.tokenizer.tokenize_packed(chars, offs, self.max_seq_len, self.token_dtype, True, validate=False)
 
     def get_batch(self, start, stop):
         """Sequences [start, stop) as one encoded batch on the device."""
@@ -125,7 +128,7 @@ class FlatFileDataset(torch.utils.data.Dataset):
             idx = order[first:first + batch_size]
             if drop_last and idx.numel() < batch_size:
                 return
-            yield self._encode(*self._packed_device(0, 0, idx)) if shuffle else self.get_batch(first, min(n, first + batch_size))
+            yield self._encode(*self._packed_device(0, 0, idx, trusted=True)) if shuffle else self.get_batch(first, min(n, first + batch_size))
 
     def __getitem__(self, index):
         if isinstance(index, slice):

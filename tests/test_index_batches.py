@@ -135,8 +135,16 @@ def test_a_shuffled_epoch_copies_nothing_host_to_device(gpu, bsq, oracle, tmp_pa
         if not self.is_cuda:
             uploads.append(("cuda", self.numel() * self.element_size()))
         return real_cuda(self, *a, **k)
+    readbacks = []
+    real_item = torch.Tensor.item
+
+    def item(self):
+        if self.is_cuda:
+            readbacks.append("item")  # (a synchronising read-back: round 3 paid one per batch for the gather's status word)
+        return real_item(self)
     monkeypatch.setattr(torch.Tensor, "to", to)
     monkeypatch.setattr(torch.Tensor, "cuda", cuda)
+    monkeypatch.setattr(torch.Tensor, "item", item)
     before = lib.bsq_host_upload_bytes()
     g = torch.Generator(device=gpu).manual_seed(99)
     total, order = 0, []
@@ -149,6 +157,7 @@ def test_a_shuffled_epoch_copies_nothing_host_to_device(gpu, bsq, oracle, tmp_pa
     torch.cuda.synchronize()
     assert lib.bsq_host_upload_bytes() == before, "the library copied host -> device during the epoch"
     assert uploads == [], uploads
+    assert readbacks == [], "the epoch's own permutation needs no check: nothing is read back, no batch synchronises"
     monkeypatch.undo()
     assert total == 2048
     # the epoch is a permutation of the oracle's rows (same generator -> same order)
