@@ -4,7 +4,7 @@
 // the memory-mapped file, tokenises it on the host and lets the DataLoader stack the results; a shuffled epoch therefore
 // touches the host for every sample.  Here the whole FlatFile is uploaded once (FlatFile.to_device) and a batch of
 // arbitrary, repeated or empty sequence indices is rebuilt ON THE DEVICE as a packed batch (chars, offsets) that the
-// encode kernels consume as they are: three small launches, no host round trip, no H2D copy.
+// encode kernels consume as they are: three small launches (ONE for loader-sized batches: k_gather_small), no host round trip, no H2D copy.
 //   k_gather_lengths  out_offsets[i + 1] <- length of sequence index[i]   (bad indices: length 0, position recorded)
 //   k_gather_scan     in-place inclusive prefix sum -> out_offsets[i + 1] = end of output sequence i  (one workgroup;
 //                     a batch is 10^3 .. 10^6 sequences: 8 MB at most, microseconds)
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kThreads) void k_gather_lengths(const int64_t *offs
     if (j >= 0 && j < n_store) {
         len = offsets[j + 1] - offsets[j];
         if (len < 0) len = 0;
-    } else {
+    } else if (first_bad) {
         atomicMin(first_bad, static_cast<unsigned long long>(i));
     }
     out_offsets[i + 1] = len;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void k_gather_chars(const uint8_t *chars,
     const int64_t src0 = offsets[j], d0 = out_offsets[i];
     int64_t len = out_offsets[i + 1] - d0;
     if (d0 + len > capacity) {
-        if (sub == 0) atomicMin(first_bad, static_cast<unsigned long long>(n + i));
+        if (sub == 0 && first_bad) atomicMin(first_bad, static_cast<unsigned long long>(n + i));
         len = capacity > d0 ? capacity - d0 : 0;
     }
     const uint8_t *src = chars + src0;
@@ -88,6 +88,67 @@ __global__ __launch_bounds__(kThreads) void k_gather_chars(const uint8_t *chars,
     if (sub < (len & 15)) dst[body + sub] = src[body + sub];
 }
 
+// Loader-sized batches (n <= kSmallN: what a training step asks for) in ONE launch instead of memset + three: a workgroup owns 16
+// output sequences (16 lanes each, as k_gather_chars), sums the lengths of every sequence in front of its own -- all 256 threads,
+// every load of the sum independent of the others -- and then does lengths, offsets and characters of its 16.  n^2 / 16 length
+// look-ups in total (1 M at n = 4096, L2 hits) buy three launches' worth of latency per batch: the step of a shuffled epoch is
+// host- and launch-bound (profiles/r04/loader_step_lab.txt).  first_bad may be null (a caller that vouches for its indices).
+constexpr int64_t kSmallN = 4096;
+__global__ __launch_bounds__(kThreads) void k_gather_small(const uint8_t *chars, const int64_t *offsets, int64_t n_store, const int64_t *index,
+                                                           int64_t n, int64_t *out_offsets, uint8_t *out_chars, int64_t capacity,
+                                                           unsigned long long *first_bad) {
+    __shared__ int64_t s_part[kThreads / 64];
+    __shared__ int64_t s_len[16];
+    const int tid = threadIdx.x, sub = tid & 15, g = tid >> 4;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * 16;
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < int(kSmallN / kThreads); ++k) {
+        const int64_t j = tid + kThreads * k;
+        if (j < first) {
+            const int64_t src = index[j];
+            if (src >= 0 && src < n_store) {
+                const int64_t l = offsets[src + 1] - offsets[src];
+                acc += l > 0 ? l : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((tid & 63) == 0) s_part[tid >> 6] = acc;
+    const int64_t i = first + g;
+    const bool live = i < n;
+    const int64_t src = live ? index[i] : -1;
+    const bool ok = live && src >= 0 && src < n_store;
+    int64_t src0 = 0, len = 0;
+    if (ok) {
+        src0 = offsets[src];
+        len = offsets[src + 1] - src0;
+        if (len < 0) len = 0;
+    }
+    if (sub == 0) {
+        s_len[g] = len;
+        if (live && !ok && first_bad) atomicMin(first_bad, static_cast<unsigned long long>(i));
+    }
+    __syncthreads();
+    int64_t d0 = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    for (int q = 0; q < g; ++q) d0 += s_len[q];
+    if (tid == 0 && blockIdx.x == 0) out_offsets[0] = 0;
+    if (!live) return;
+    if (sub == 0) out_offsets[i + 1] = d0 + len;
+    if (!ok || !chars || !out_chars) return;
+    if (d0 + len > capacity) {
+        if (sub == 0 && first_bad) atomicMin(first_bad, static_cast<unsigned long long>(n + i));
+        len = capacity > d0 ? capacity - d0 : 0;
+    }
+    const uint8_t *sp = chars + src0;
+    uint8_t *dst = out_chars + d0;
+    const int64_t body = len & ~int64_t(15);
+    for (int64_t p = sub * 16; p < body; p += 256)
+        *reinterpret_cast<g_u32x4u *>(dst + p) = *reinterpret_cast<const g_u32x4u *>(sp + p);
+    if (sub < (len & 15)) dst[body + sub] = sp[body + sub];
+}
+
 }  // namespace
 
 extern "C" {
@@ -95,17 +156,26 @@ extern "C" {
 bsq_status bsq_gather_packed_device(const uint8_t *chars, const int64_t *offsets, int64_t n_store, const int64_t *index,
                                     int64_t n, uint8_t *out_chars, int64_t out_capacity, int64_t *out_offsets,
                                     int64_t *status_dev, void *hip_stream) {
-    if (!offsets || !out_offsets || !status_dev || n_store < 0 || n < 0 || out_capacity < 0 || (n > 0 && !index))
+    if (!offsets || !out_offsets || n_store < 0 || n < 0 || out_capacity < 0 || (n > 0 && !index))
         return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_gather_packed_device: null pointer or negative size");
     if ((n + kThreads - 1) / kThreads >= (int64_t(1) << 31) || (n + 15) / 16 >= (int64_t(1) << 31))
         return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "index list too long");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    hipError_t e = hipMemsetAsync(status_dev, 0xFF, sizeof(int64_t), s);  // -1 = every index valid, everything fitted
+    hipError_t e = hipSuccess;
+    // status_dev == NULL: the caller vouches for its indices and its capacity (bad indices still read nothing, an overflow is still cut)
+    if (status_dev) e = hipMemsetAsync(status_dev, 0xFF, sizeof(int64_t), s);  // -1 = every index valid, everything fitted
     if (e != hipSuccess) return bsq_internal::set_hip_error("hipMemsetAsync(gather status)", e);
     unsigned long long *bad = reinterpret_cast<unsigned long long *>(status_dev);
     if (n == 0) {
         e = hipMemsetAsync(out_offsets, 0, sizeof(int64_t), s);
         if (e != hipSuccess) return bsq_internal::set_hip_error("hipMemsetAsync(gather offsets)", e);
+        return BSQ_OK;
+    }
+    if (n <= kSmallN && bsq_internal::tuning().gather_small != 1) {
+        hipLaunchKernelGGL(k_gather_small, dim3(unsigned((n + 15) / 16)), dim3(kThreads), 0, s, chars, offsets, n_store, index, n, out_offsets,
+                           out_chars, out_chars ? out_capacity : 0, bad);
+        e = hipGetLastError();
+        if (e != hipSuccess) return bsq_internal::set_hip_error("k_gather_small", e);
         return BSQ_OK;
     }
     hipLaunchKernelGGL(k_gather_lengths, dim3(unsigned((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, offsets, n_store,

@@ -213,7 +213,8 @@ class FlatFile:
             with torch.cuda.device(dev):
                 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
                 capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), self._n, idx.data_ptr(), n,
-                                                        out_chars.data_ptr(), capacity, out_offs.data_ptr(), status.data_ptr(), stream))
+                                                        out_chars.data_ptr(), capacity, out_offs.data_ptr(),
+                                                        status.data_ptr() if (on_device and validate) else None, stream))
             if not (on_device and validate):  # (host lists were range-checked above and sized exactly)
                 break
             bad = int(status.item())  # the only synchronising step, and only for index tensors nobody has checked

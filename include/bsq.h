@@ -223,7 +223,9 @@ void bsq_fused_status_clear(void);
  * repeat, in any order; empty sequences are fine.  Stream-ordered, never synchronises: errors are left in *status_dev
  * (device int64): -1 = ok, i in [0, n) = index[i] was out of range (it contributes an empty sequence), n + i = output
  * sequence i did not fit into out_capacity bytes (the batch is cut there, nothing is written past the buffer).
- * out_capacity = n * (longest sequence of the store) always suffices.  out_chars may be NULL to get the offsets only. */
+ * out_capacity = n * (longest sequence of the store) always suffices.  out_chars may be NULL to get the offsets only;
+ * status_dev may be NULL when the caller vouches for its indices and capacity (nothing is reported; a bad index still reads
+ * nothing, an overflow is still cut).  Lists of up to 4096 indices -- a training step's batch -- take ONE launch. */
 bsq_status bsq_gather_packed_device(const uint8_t *chars, const int64_t *offsets, int64_t n_store, const int64_t *index,
                                     int64_t n, uint8_t *out_chars, int64_t out_capacity, int64_t *out_offsets,
                                     int64_t *status_dev, void *hip_stream);
