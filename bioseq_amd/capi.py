@@ -100,6 +100,9 @@ def load():
         "bsq_stage_begin": (i32, [i64, sz, i32, vp, vp, vp, vp, vp]),
         "bsq_stage_upload": (i32, [vp, i64, i64, vp, vp, vp]),
         "bsq_stage_end": (i32, [vp]),
+        "bsq_stage_result": (i32, [vp, sz, vp, vp]),
+        "bsq_stage_fetch": (i32, [vp, sz, sz, vp]),
+        "bsq_stage_wait": (i32, [vp, i32]),
         "bsq_stage_piece_hint": (i64, [i64, sz, sz, vp, vp, i64p]),
         "bsq_fastx_to_flatfile": (i32, [ctypes.c_char_p, ctypes.c_char_p, i64p, i64p]),
         "bsq_fastx_lengths": (i32, [ctypes.c_char_p, vp, i64, i64p]),

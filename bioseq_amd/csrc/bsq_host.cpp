@@ -57,8 +57,11 @@ struct Staging {
     hipStream_t copy_stream = nullptr;  // uploads run here, so that H2D of batch n + 1 overlaps the encode of batch n
     hipEvent_t uploaded = nullptr;
     hipEvent_t piece[8] = {};  // "piece j of this batch is on the device" (run_host in pieces; created on first use)
+    hipEvent_t fetched[8] = {};  // "fetch k of this staged batch has landed in the pinned result area" (bsq_stage_fetch)
     void *d_out = nullptr;
     size_t d_out_cap = 0;
+    void *h_result = nullptr;  // pinned landing area of a staged batch's HOST result (bsq_stage_result; grow-only)
+    size_t h_result_cap = 0;
     // device -> pageable host results: ring of pinned bounce slots (see download())
     void *bounce = nullptr;
     hipEvent_t slot_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -703,6 +706,7 @@ struct bsq_stage {
     size_t d_off_bytes = 0, d_chr_bytes = 0;
     int64_t uploaded = 0;  // sequences [0, uploaded) are on their way
     int pieces = 0;
+    int fetches = 0;
 };
 
 bsq_status bsq_stage_begin(int64_t max_seqs, size_t max_chars, int32_t with_mask, void *hip_stream, bsq_stage **stage,
@@ -786,6 +790,56 @@ bsq_status bsq_stage_end(bsq_stage *st) {
     return BSQ_OK;
 }
 
+bsq_status bsq_stage_result(bsq_stage *st, size_t nbytes, void **d_result, void **h_result) {
+    if (!st || !d_result || !h_result) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_result: null pointer");
+    Staging &s = *st->s;
+    bsq_status rc = grow_device(&s.d_out, &s.d_out_cap, nbytes);
+    if (rc != BSQ_OK) return rc;
+    if (nbytes > s.h_result_cap) {
+        if (s.h_result) (void)hipHostFree(s.h_result);
+        s.h_result = nullptr;
+        s.h_result_cap = 0;
+        const size_t want = round_up(nbytes + nbytes / 8, size_t(1) << 20);
+        const hipError_t e = hipHostMalloc(&s.h_result, want, hipHostMallocDefault);
+        if (e != hipSuccess) return bsq_internal::set_hip_error("hipHostMalloc(result)", e);
+        s.h_result_cap = want;
+    }
+    *d_result = s.d_out;
+    *h_result = s.h_result;
+    return BSQ_OK;
+}
+
+bsq_status bsq_stage_fetch(bsq_stage *st, size_t offset, size_t nbytes, int32_t *ticket) {
+    if (ticket) *ticket = -1;
+    if (!st) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_fetch: null stage");
+    Staging &s = *st->s;
+    if (!s.d_out || !s.h_result || offset > s.h_result_cap || nbytes > s.h_result_cap - offset || offset + nbytes > s.d_out_cap)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_fetch: outside the result of bsq_stage_result");
+    if (nbytes == 0) return BSQ_OK;
+    const hipError_t e = hipMemcpyAsync(static_cast<char *>(s.h_result) + offset, static_cast<const char *>(s.d_out) + offset, nbytes,
+                                        hipMemcpyDeviceToHost, st->stream);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("bsq_stage_fetch", e);
+    constexpr int kEvents = int(sizeof(s.fetched) / sizeof(s.fetched[0]));
+    if (ticket && st->fetches < kEvents) {  // (a ninth fetch of one batch gets no ticket: wait for everything)
+        hipEvent_t &ev = s.fetched[st->fetches];
+        hipError_t e2 = hipSuccess;
+        if (!ev) e2 = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e2 == hipSuccess) e2 = hipEventRecord(ev, st->stream);
+        if (e2 != hipSuccess) return bsq_internal::set_hip_error("bsq_stage_fetch: event", e2);
+        *ticket = st->fetches++;
+    }
+    return BSQ_OK;
+}
+
+bsq_status bsq_stage_wait(bsq_stage *st, int32_t ticket) {
+    if (!st) return BSQ_OK;
+    constexpr int kEvents = int(sizeof(st->s->fetched) / sizeof(st->s->fetched[0]));
+    const hipError_t e = ticket >= 0 && ticket < kEvents && ticket < st->fetches ? hipEventSynchronize(st->s->fetched[ticket])
+                                                                               : hipStreamSynchronize(st->stream);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("bsq_stage_wait", e);
+    return BSQ_OK;
+}
+
 int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, const void *out, void *hip_stream, int64_t *head_seqs) {
     int64_t head = 0;
     const int64_t seqs = piece_sequences(B, nchars, block_row_bytes, out, static_cast<hipStream_t>(hip_stream), &head);
@@ -811,7 +865,10 @@ void bsq_release_staging(void) {
         if (s.uploaded) (void)hipEventDestroy(s.uploaded);
         for (hipEvent_t ev : s.piece)
             if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : s.fetched)
+            if (ev) (void)hipEventDestroy(ev);
         if (s.d_out) (void)hipFree(s.d_out);
+        if (s.h_result) (void)hipHostFree(s.h_result);
         if (s.bounce) (void)hipHostFree(s.bounce);
         for (hipEvent_t ev : s.slot_done)
             if (ev) (void)hipEventDestroy(ev);

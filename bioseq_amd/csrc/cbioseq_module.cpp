@@ -527,26 +527,12 @@ class Tokenizer {
     // batch, numpy result, knob host_pieces = 1): nothing has been scanned, the caller goes on with the whole-batch path.
     // The GIL stays held as it is during every pack (the items must stay alive and unchanged); nothing in here blocks on the
     // GPU except the wait for the staging slot used three calls ago.
-    template <typename BlockFn>
-    bool staged(const Scan &sc, Gathered &g, py::ssize_t padlen, int nthreads, const OutBuf &out, bool splittable, size_t block_row_bytes,
-                bool onehot, BlockFn block) const {
-        const int64_t maxlen = int64_t(padlen) - desc.bos - desc.eos;  // a longer item is an error anyway
-        if (out.space != BSQ_SPACE_DEVICE || sc.n < 16384 || maxlen <= 0) return false;
-        const size_t max_chars = size_t(sc.n) * size_t(maxlen);
-        if (max_chars > (size_t(1) << 30)) return false;
-        int64_t head = 0;  // sequences in front of the first piece boundary (column blocks of a result that is not 4-KiB aligned)
-        int64_t seqs = splittable ? bsq_stage_piece_hint(sc.n, max_chars / 2, block_row_bytes, out.ptr, out.stream, &head) : 0;
-        if (seqs < 0) return false;                  // knob host_pieces = 1: the whole-batch path of rounds 1-3
-        if (seqs == 0 || seqs > sc.n) seqs = sc.n;   // one piece (busy stream, misaligned result, ...): still one scan + pack job
-        bsq_stage *stage = nullptr;
-        Packed p;
-        p.B = sc.n;
-        bsq_status st = bsq_stage_begin(sc.n, max_chars, g.has_mask ? 1 : 0, out.stream, &stage, &p.offsets, &p.chars, &p.mask);
-        if (st != BSQ_OK) throw_status(st);
-        struct End {
-            bsq_stage *s;
-            ~End() { (void)bsq_stage_end(s); }
-        } end{stage};
+    // The piece loop of both staged paths: items [lo, hi) scanned + packed (one pool job, or the general passes), uploaded, then
+    // `per_piece(lo, hi, d_chars, d_offsets, d_mask)` (device pointers of the whole batch; d_offsets at sequence lo).
+    template <typename PerPiece>
+    void staged_pieces(const Scan &sc, Gathered &g, const Packed &p, bsq_stage *stage, int64_t head, int64_t seqs, py::ssize_t padlen, int nthreads,
+                       bool onehot, PerPiece per_piece) const {
+        const int64_t maxlen = int64_t(padlen) - desc.bos - desc.eos;
         for (int64_t lo = 0, want = head + seqs; lo < sc.n; lo += want, want = seqs) {
             const int64_t hi = std::min<int64_t>(sc.n, lo + want);
             int64_t bad = -1;
@@ -561,11 +547,118 @@ class Tokenizer {
             if (bad >= 0) throw_too_long(p.offsets, bad, padlen, onehot);
             const int64_t *d_offsets = nullptr;
             const uint8_t *d_chars = nullptr, *d_mask = nullptr;
-            st = bsq_stage_upload(stage, lo, hi, &d_offsets, &d_chars, &d_mask);
-            const int64_t lead = lo == 0 && head < hi ? head : 0;
-            if (st == BSQ_OK && lead) st = block(d_chars, d_offsets, d_mask, 0, lead);
-            if (st == BSQ_OK) st = block(d_chars, d_offsets + lead, d_mask, lo + lead, hi - lo - lead);
+            bsq_status st = bsq_stage_upload(stage, lo, hi, &d_offsets, &d_chars, &d_mask);
+            if (st == BSQ_OK) st = per_piece(lo, hi, d_chars, d_offsets, d_mask);
             if (st != BSQ_OK) throw_status(st);
+        }
+    }
+
+    struct StageEnd {
+        bsq_stage *s;
+        ~StageEnd() { (void)bsq_stage_end(s); }
+    };
+
+    template <typename BlockFn>
+    bool staged(const Scan &sc, Gathered &g, py::ssize_t padlen, int nthreads, const OutBuf &out, bool splittable, size_t block_row_bytes,
+                bool onehot, BlockFn block) const {
+        const int64_t maxlen = int64_t(padlen) - desc.bos - desc.eos;  // a longer item is an error anyway
+        if (out.space != BSQ_SPACE_DEVICE || sc.n < 16384 || maxlen <= 0) return false;
+        const size_t max_chars = size_t(sc.n) * size_t(maxlen);
+        if (max_chars > (size_t(1) << 30)) return false;
+        int64_t head = 0;  // sequences in front of the first piece boundary (column blocks of a result that is not 4-KiB aligned)
+        int64_t seqs = splittable ? bsq_stage_piece_hint(sc.n, max_chars / 2, block_row_bytes, out.ptr, out.stream, &head) : 0;
+        if (seqs < 0) return false;                  // knob host_pieces = 1: the whole-batch path of rounds 1-3
+        if (seqs == 0 || seqs > sc.n) seqs = sc.n;   // one piece (busy stream, misaligned result, ...): still one scan + pack job
+        bsq_stage *stage = nullptr;
+        Packed p;
+        p.B = sc.n;
+        const bsq_status st0 = bsq_stage_begin(sc.n, max_chars, g.has_mask ? 1 : 0, out.stream, &stage, &p.offsets, &p.chars, &p.mask);
+        if (st0 != BSQ_OK) throw_status(st0);
+        StageEnd end{stage};
+        staged_pieces(sc, g, p, stage, head, seqs, padlen, nthreads, onehot,
+                      [&](int64_t lo, int64_t hi, const uint8_t *d_chars, const int64_t *d_offsets, const uint8_t *d_mask) {
+                          const int64_t lead = lo == 0 && head < hi ? head : 0;
+                          bsq_status st = BSQ_OK;
+                          if (lead) st = block(d_chars, d_offsets, d_mask, 0, lead);
+                          if (st == BSQ_OK) st = block(d_chars, d_offsets + lead, d_mask, lo + lead, hi - lo - lead);
+                          return st;
+                      });
+        return true;
+    }
+
+    // The same for a NUMPY result (the reference's default return) of up to 256 MB -- token matrices, small one-hots: every piece
+    // is encoded as a matrix of its own (`piece(d_chars, d_offsets, d_mask, n, dst)`: n sequences, per_seq_bytes each) in the staging
+    // area's device scratch and fetched into its pinned mirror while the next piece is packed and uploaded (PCIe runs both ways);
+    // at the end the pool copies the pinned pieces into the array -- straight (rows == 0: a piece is a contiguous slab of the result:
+    // (B, P), (B, C, P)) or row by row (a piece is `rows` x n x col_bytes of a (rows, B, col_bytes) result: (P, B), (P, B, C)).
+    template <typename PieceFn>
+    bool staged_host(const Scan &sc, Gathered &g, py::ssize_t padlen, int nthreads, const OutBuf &out, size_t per_seq_bytes, size_t rows,
+                     size_t col_bytes, bool onehot, PieceFn piece) const {
+        const int64_t maxlen = int64_t(padlen) - desc.bos - desc.eos;
+        const size_t total = size_t(sc.n) * per_seq_bytes;
+        if (out.space != BSQ_SPACE_HOST || sc.n < 16384 || maxlen <= 0 || total > (size_t(256) << 20)) return false;
+        const size_t max_chars = size_t(sc.n) * size_t(maxlen);
+        if (max_chars > (size_t(1) << 30)) return false;
+        int64_t head = 0;
+        int64_t seqs = bsq_stage_piece_hint(sc.n, max_chars / 2, 0, nullptr, nullptr, &head);
+        if (seqs < 0) return false;
+        if (seqs == 0 || seqs > sc.n) seqs = sc.n;
+        bsq_stage *stage = nullptr;
+        Packed p;
+        p.B = sc.n;
+        bsq_status st = bsq_stage_begin(sc.n, max_chars, g.has_mask ? 1 : 0, nullptr, &stage, &p.offsets, &p.chars, &p.mask);
+        if (st != BSQ_OK) throw_status(st);
+        StageEnd end{stage};
+        void *d_res = nullptr, *h_res = nullptr;
+        st = bsq_stage_result(stage, total, &d_res, &h_res);
+        if (st != BSQ_OK) throw_status(st);
+        static const bool prof = std::getenv("BSQ_PROFILE_HOST") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        char *dst = static_cast<char *>(out.ptr);
+        const char *src = static_cast<const char *>(h_res);
+        const int nt = std::max(1, std::min(nthreads, 64));
+        const size_t B = size_t(sc.n);
+        // piece [lo, hi) of the pinned area into the array: straight (rows == 0) or its rows side by side with the other pieces'
+        auto land = [&](int64_t lo, int64_t hi) {
+            const size_t off = size_t(lo) * per_seq_bytes, len = size_t(hi - lo) * per_seq_bytes, n = size_t(hi - lo);
+            if (rows == 0) {
+                pool().parallel_for(nt, [&](int t) {
+                    const size_t a = len * size_t(t) / size_t(nt) / 4096 * 4096, b = t + 1 == nt ? len : len * size_t(t + 1) / size_t(nt) / 4096 * 4096;
+                    if (b > a) std::memcpy(dst + off + a, src + off + a, b - a);
+                });
+            } else {
+                pool().parallel_for(nt, [&](int t) {
+                    for (size_t r = rows * size_t(t) / size_t(nt), r1 = rows * size_t(t + 1) / size_t(nt); r < r1; ++r)
+                        std::memcpy(dst + (r * B + size_t(lo)) * col_bytes, src + off + r * n * col_bytes, n * col_bytes);
+                });
+            }
+        };
+        struct Pending {
+            int64_t lo, hi;
+            int32_t ticket;
+        };
+        std::vector<Pending> pending;
+        size_t landed = 0;  // pieces [0, landed) are in the array
+        staged_pieces(sc, g, p, stage, 0, seqs, padlen, nthreads, onehot,
+                      [&](int64_t lo, int64_t hi, const uint8_t *d_chars, const int64_t *d_offsets, const uint8_t *d_mask) {
+                          bsq_status s1 = piece(d_chars, d_offsets, d_mask, hi - lo, static_cast<char *>(d_res) + size_t(lo) * per_seq_bytes);
+                          int32_t ticket = -1;
+                          if (s1 == BSQ_OK) s1 = bsq_stage_fetch(stage, size_t(lo) * per_seq_bytes, size_t(hi - lo) * per_seq_bytes, &ticket);
+                          pending.push_back(Pending{lo, hi, ticket});
+                          return s1;
+                      });
+        const auto t1 = std::chrono::steady_clock::now();
+        // the pieces land in the array as their fetches complete: the copy (and the page faults of a fresh array) of piece j runs
+        // while pieces j + 1 ... are still on the bus
+        for (; landed < pending.size(); ++landed) {
+            st = bsq_stage_wait(stage, pending[landed].ticket);
+            if (st != BSQ_OK) throw_status(st);
+            land(pending[landed].lo, pending[landed].hi);
+        }
+        if (prof) {
+            auto us = [](auto x, auto y) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(y - x).count(); };
+            std::fprintf(stderr, "[bsq host] numpy result in pieces: scan + pack + upload + launch + fetch %ld us, waits + copies into the array %ld us\n",
+                         us(t0, t1), us(t1, std::chrono::steady_clock::now()));
         }
         return true;
     }
@@ -577,7 +670,15 @@ class Tokenizer {
         check_padlen(padlen);
         Gathered g;
         const Scan sc = scan_begin(batch, py::none(), g, nthreads);  // (resolves nthreads = 0 to the automatic count)
-        if (device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);   // (item errors before the result is allocated, as ever)
+        // numpy results: small batches scan first (item errors before the result is allocated, as ever); large ones that fit the
+        // staged path (<= 256 MB of result) are scanned piece by piece in staged_host
+        const size_t row_bytes = size_t(padlen) * bsq_dtype_size(t);
+        const bool host_stage = device.is_none() && sc.n >= 16384 && size_t(sc.n) * row_bytes <= (size_t(256) << 20);
+        bool scanned = false;
+        if (device.is_none() && !host_stage) {
+            scan_range(sc, g, 0, sc.n, nthreads);
+            scanned = true;
+        }
         PackLock lock;
         OutBuf out;  // first: it makes `device=` the current device, so the pinned scratch and the staging
                      // buffers used by pack() and by the encode call belong to the same device
@@ -596,7 +697,13 @@ class Tokenizer {
                                                         out.stream);
                    }))
             return out.obj;
-        if (!device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);
+        // numpy result of up to 256 MB: the pieces are encoded on the device and fetched while the next one is packed and uploaded
+        if (host_stage && staged_host(sc, g, padlen, nthreads, out, row, batch_first ? 0 : size_t(padlen), tsz, false,
+                                            [&](const uint8_t *chars, const int64_t *offsets, const uint8_t *, int64_t n, void *dst) {
+                                                return bsq_tokenize_device(&desc, chars, offsets, n, padlen, batch_first, t, dst, nullptr);
+                                            }))
+            return out.obj;
+        if (!scanned) scan_range(sc, g, 0, sc.n, nthreads);
         const Packed p = pack(g, nthreads);
         int64_t bad = -1;
         bsq_status st;
@@ -626,7 +733,13 @@ class Tokenizer {
         const auto t0 = std::chrono::steady_clock::now();
         Gathered g;
         const Scan sc = scan_begin(batch, mask, g, nthreads);
-        if (device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);  // (item errors before the result is allocated, as ever)
+        const size_t per_seq = size_t(padlen) * size_t(bsq_alphabet_size(&desc)) * bsq_dtype_size(t);
+        const bool host_stage = device.is_none() && sc.n >= 16384 && size_t(sc.n) * per_seq <= (size_t(256) << 20);  // (see batch_tokenize)
+        bool scanned = false;
+        if (device.is_none() && !host_stage) {
+            scan_range(sc, g, 0, sc.n, nthreads);
+            scanned = true;
+        }
         const auto t1 = std::chrono::steady_clock::now();
         PackLock lock;
         OutBuf out;  // before pack(): see batch_tokenize
@@ -652,7 +765,13 @@ class Tokenizer {
                                    us(t0, t1), us(t1, t2), (unsigned long)(reinterpret_cast<uintptr_t>(out.ptr) % 4096), us(t2, std::chrono::steady_clock::now()));
             return out.obj;
         }
-        if (!device.is_none()) scan_range(sc, g, 0, sc.n, nthreads);
+        if (host_stage && staged_host(sc, g, padlen, nthreads, out, per_seq, bcl ? 0 : size_t(padlen), row, true,
+                                      [&](const uint8_t *chars, const int64_t *offsets, const uint8_t *m, int64_t n, void *dst) {
+                                          return bcl ? bsq_onehot_bcl_device(&desc, chars, offsets, m, n, padlen, t, dst, nullptr)
+                                                     : bsq_onehot_device(&desc, chars, offsets, m, n, padlen, t, dst, nullptr);
+                                      }))
+            return out.obj;
+        if (!scanned) scan_range(sc, g, 0, sc.n, nthreads);
         const Packed p = pack(g, nthreads);
         const auto t3 = std::chrono::steady_clock::now();
         int64_t bad = -1;

@@ -274,13 +274,26 @@ bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const in
  *                     with a call of its own.  Knob "host_pieces"; automatic = pieces of ~8 MB when the batch is large and hip_stream is idle (a busy
  *                     stream means the caller is not waiting for this batch: one upload costs the host less than several).
  * What it buys (list of 65 536 bytes objects, 35 MB -> f32 one-hot on the device, synchronous): 2.1 ms as one pack + one
- * upload + one encode, 1.5 ms with the encode and the pack of the pieces under the uploads (profiles/r04/host_pieces_lab.txt). */
+ * upload + one encode, 1.5 ms with the encode and the pack of the pieces under the uploads (profiles/r04/host_pieces_lab.txt).
+ *
+ * A result that has to end up in HOST memory (the reference's default return is a numpy array):
+ *   bsq_stage_result  a device scratch of nbytes for the pieces' results + a PINNED host area of the same size (both owned by the
+ *                     staging area, valid until bsq_stage_end); encode piece j to d_result + offset_j with any *_device entry;
+ *   bsq_stage_fetch   enqueue the copy of [offset, offset + nbytes) of the device scratch to the same offsets of the pinned area
+ *                     on hip_stream (behind the encode of that piece; the upload of the next piece runs the other way meanwhile);
+ *                     *ticket (may be NULL) names this fetch for bsq_stage_wait (-1: none left, wait for everything);
+ *   bsq_stage_wait    block until fetch `ticket` has landed (ticket < 0: until everything enqueued on hip_stream has happened).
+ * The caller then copies the pinned bytes where it wants them (the pybind layer: into the numpy array, with its worker pool).
+ * list of 65 536 items -> numpy int8 (P, B) tokens, the reference's literal default call: 3.4 -> 2.3 ms (profiles/r04/default_call_lab.txt). */
 typedef struct bsq_stage bsq_stage;
 bsq_status bsq_stage_begin(int64_t max_seqs, size_t max_chars, int32_t with_mask, void *hip_stream, bsq_stage **stage,
                            int64_t **offsets, uint8_t **chars, uint8_t **mask);
 bsq_status bsq_stage_upload(bsq_stage *stage, int64_t first, int64_t last, const int64_t **d_offsets, const uint8_t **d_chars,
                             const uint8_t **d_mask);
 bsq_status bsq_stage_end(bsq_stage *stage);
+bsq_status bsq_stage_result(bsq_stage *stage, size_t nbytes, void **d_result, void **h_result);
+bsq_status bsq_stage_fetch(bsq_stage *stage, size_t offset, size_t nbytes, int32_t *ticket);
+bsq_status bsq_stage_wait(bsq_stage *stage, int32_t ticket);
 int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, const void *out, void *hip_stream, int64_t *head_seqs);
 
 /* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer): returns a buffer of
