@@ -707,6 +707,7 @@ struct bsq_stage {
     int64_t uploaded = 0;  // sequences [0, uploaded) are on their way
     int pieces = 0;
     int fetches = 0;
+    size_t result_bytes = 0;  // of THIS batch (bsq_stage_result); the buffers themselves outlive it
 };
 
 bsq_status bsq_stage_begin(int64_t max_seqs, size_t max_chars, int32_t with_mask, void *hip_stream, bsq_stage **stage,
@@ -804,6 +805,7 @@ bsq_status bsq_stage_result(bsq_stage *st, size_t nbytes, void **d_result, void 
         if (e != hipSuccess) return bsq_internal::set_hip_error("hipHostMalloc(result)", e);
         s.h_result_cap = want;
     }
+    st->result_bytes = nbytes;
     *d_result = s.d_out;
     *h_result = s.h_result;
     return BSQ_OK;
@@ -813,8 +815,8 @@ bsq_status bsq_stage_fetch(bsq_stage *st, size_t offset, size_t nbytes, int32_t 
     if (ticket) *ticket = -1;
     if (!st) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_fetch: null stage");
     Staging &s = *st->s;
-    if (!s.d_out || !s.h_result || offset > s.h_result_cap || nbytes > s.h_result_cap - offset || offset + nbytes > s.d_out_cap)
-        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_fetch: outside the result of bsq_stage_result");
+    if (offset > st->result_bytes || nbytes > st->result_bytes - offset)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_stage_fetch: outside the result of this batch's bsq_stage_result");
     if (nbytes == 0) return BSQ_OK;
     const hipError_t e = hipMemcpyAsync(static_cast<char *>(s.h_result) + offset, static_cast<const char *>(s.d_out) + offset, nbytes,
                                         hipMemcpyDeviceToHost, st->stream);

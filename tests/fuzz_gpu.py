@@ -89,8 +89,14 @@ def run(budget=120.0, seed=1):
                 assert g.tobytes() == e.tobytes(), "list -> device onehot"
                 g = tok.batch_onehot_encode(seqs, padlen=P, destchar=d, mask=ml, device="cuda", layout="bcl").cpu().numpy()
                 assert g.tobytes() == np.ascontiguousarray(e.transpose(1, 2, 0)).tobytes(), "list -> device onehot bcl"
+                et = ora.tokenize_packed(chars, offs, P, d, bf)
                 g = u64(tok.batch_tokenize(seqs, padlen=P, destchar=d, batch_first=bf, device="cuda").cpu().numpy())
-                assert g.tobytes() == ora.tokenize_packed(chars, offs, P, d, bf).tobytes(), ("list -> device tokens", bf)
+                assert g.tobytes() == et.tobytes(), ("list -> device tokens", bf)
+                # numpy results (<= 256 MB: pieces fetched back while the next ones go up)
+                g = tok.batch_tokenize(seqs, padlen=P, destchar=d, batch_first=bf)
+                assert g.dtype == et.dtype and g.shape == et.shape and g.tobytes() == et.tobytes(), ("list -> numpy tokens", bf)
+                g = tok.batch_onehot_encode(seqs, padlen=P, destchar=d, mask=ml, layout="bcl" if bf else "tbc")
+                assert g.tobytes() == (np.ascontiguousarray(e.transpose(1, 2, 0)) if bf else e).tobytes(), ("list -> numpy onehot", bf)
         except AssertionError as ex:
             raise AssertionError("MISMATCH %s %r" % (ex, desc))
         n += 1
