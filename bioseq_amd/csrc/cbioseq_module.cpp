@@ -650,11 +650,15 @@ class Tokenizer {
         const auto t1 = std::chrono::steady_clock::now();
         // the pieces land in the array as their fetches complete: the copy (and the page faults of a fresh array) of piece j runs
         // while pieces j + 1 ... are still on the bus
-        for (; landed < pending.size(); ++landed) {
-            st = bsq_stage_wait(stage, pending[landed].ticket);
-            if (st != BSQ_OK) throw_status(st);
-            land(pending[landed].lo, pending[landed].hi);
+        // (no Python object is touched from here on -- pinned bytes into the array's buffer --: other Python threads may run)
+        {
+            py::gil_scoped_release nogil;
+            for (; landed < pending.size() && st == BSQ_OK; ++landed) {
+                st = bsq_stage_wait(stage, pending[landed].ticket);
+                if (st == BSQ_OK) land(pending[landed].lo, pending[landed].hi);
+            }
         }
+        if (st != BSQ_OK) throw_status(st);
         if (prof) {
             auto us = [](auto x, auto y) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(y - x).count(); };
             std::fprintf(stderr, "[bsq host] numpy result in pieces: scan + pack + upload + launch + fetch %ld us, waits + copies into the array %ld us\n",
