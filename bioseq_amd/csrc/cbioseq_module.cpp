@@ -529,28 +529,36 @@ class Tokenizer {
     // GPU except the wait for the staging slot used three calls ago.
     // The piece loop of both staged paths: items [lo, hi) scanned + packed (one pool job, or the general passes), uploaded, then
     // `per_piece(lo, hi, d_chars, d_offsets, d_mask)` (device pointers of the whole batch; d_offsets at sequence lo).
-    template <typename PerPiece>
-    void staged_pieces(const Scan &sc, Gathered &g, const Packed &p, bsq_stage *stage, int64_t head, int64_t seqs, py::ssize_t padlen, int nthreads,
-                       bool onehot, PerPiece per_piece) const {
-        const int64_t maxlen = int64_t(padlen) - desc.bos - desc.eos;
-        for (int64_t lo = 0, want = head + seqs; lo < sc.n; lo += want, want = seqs) {
-            const int64_t hi = std::min<int64_t>(sc.n, lo + want);
-            int64_t bad = -1;
-            if (!scan_pack_fast(sc, g, p, lo, hi, nthreads, maxlen, &bad)) {  // mask list / other item types: the general passes
-                scan_range(sc, g, lo, hi, nthreads);
-                for (int64_t i = lo; i < hi; ++i) {
-                    p.offsets[i + 1] = p.offsets[i] + int64_t(g.items[size_t(i)].len);
-                    if (int64_t(g.items[size_t(i)].len) > maxlen) throw_too_long(p.offsets, i, padlen, onehot);
-                }
-                pack_range(g, p, lo, hi, nthreads);
-            }
-            if (bad >= 0) throw_too_long(p.offsets, bad, padlen, onehot);
+    template <typename Produce, typename PerPiece>
+    static void piece_loop(int64_t n, bsq_stage *stage, int64_t head, int64_t seqs, Produce produce, PerPiece per_piece) {
+        for (int64_t lo = 0, want = head + seqs; lo < n; lo += want, want = seqs) {
+            const int64_t hi = std::min<int64_t>(n, lo + want);
+            produce(lo, hi);  // offsets[lo + 1 .. hi] and the characters of [lo, hi) into the pinned staging area (may throw)
             const int64_t *d_offsets = nullptr;
             const uint8_t *d_chars = nullptr, *d_mask = nullptr;
             bsq_status st = bsq_stage_upload(stage, lo, hi, &d_offsets, &d_chars, &d_mask);
             if (st == BSQ_OK) st = per_piece(lo, hi, d_chars, d_offsets, d_mask);
             if (st != BSQ_OK) throw_status(st);
         }
+    }
+    template <typename PerPiece>
+    void staged_pieces(const Scan &sc, Gathered &g, const Packed &p, bsq_stage *stage, int64_t head, int64_t seqs, py::ssize_t padlen, int nthreads,
+                       bool onehot, PerPiece per_piece) const {
+        const int64_t maxlen = int64_t(padlen) - desc.bos - desc.eos;
+        piece_loop(sc.n, stage, head, seqs,
+                   [&](int64_t lo, int64_t hi) {
+                       int64_t bad = -1;
+                       if (!scan_pack_fast(sc, g, p, lo, hi, nthreads, maxlen, &bad)) {  // mask list / other item types: the general passes
+                           scan_range(sc, g, lo, hi, nthreads);
+                           for (int64_t i = lo; i < hi; ++i) {
+                               p.offsets[i + 1] = p.offsets[i] + int64_t(g.items[size_t(i)].len);
+                               if (int64_t(g.items[size_t(i)].len) > maxlen) throw_too_long(p.offsets, i, padlen, onehot);
+                           }
+                           pack_range(g, p, lo, hi, nthreads);
+                       }
+                       if (bad >= 0) throw_too_long(p.offsets, bad, padlen, onehot);
+                   },
+                   per_piece);
     }
 
     struct StageEnd {
@@ -591,6 +599,70 @@ class Tokenizer {
     // area's device scratch and fetched into its pinned mirror while the next piece is packed and uploaded (PCIe runs both ways);
     // at the end the pool copies the pinned pieces into the array -- straight (rows == 0: a piece is a contiguous slab of the result:
     // (B, P), (B, C, P)) or row by row (a piece is `rows` x n x col_bytes of a (rows, B, col_bytes) result: (P, B), (P, B, C)).
+    // Host results of a staged batch: `loop(per_piece)` runs the piece loop; every piece is encoded by `piece(...)` as a matrix of its
+    // own (n sequences of per_seq_bytes) in the staging area's device scratch and fetched into its pinned mirror; the pieces land in
+    // `dst` as their fetches complete -- straight (rows == 0) or row by row (`rows` x n x col_bytes pieces of a (rows, B, col_bytes) result).
+    template <typename Loop, typename PieceFn>
+    static void fetch_and_land(bsq_stage *stage, int64_t B, size_t per_seq_bytes, size_t rows, size_t col_bytes, int nthreads, char *dst, Loop loop,
+                               PieceFn piece, bool gil_held) {
+        void *d_res = nullptr, *h_res = nullptr;
+        bsq_status st = bsq_stage_result(stage, size_t(B) * per_seq_bytes, &d_res, &h_res);
+        if (st != BSQ_OK) throw_status(st);
+        static const bool prof = std::getenv("BSQ_PROFILE_HOST") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        const char *src = static_cast<const char *>(h_res);
+        const int nt = std::max(1, std::min(nthreads, 64));
+        auto land = [&](int64_t lo, int64_t hi) {
+            const size_t off = size_t(lo) * per_seq_bytes, len = size_t(hi - lo) * per_seq_bytes, n = size_t(hi - lo);
+            if (rows == 0) {
+                pool().parallel_for(nt, [&](int t) {
+                    const size_t a = len * size_t(t) / size_t(nt) / 4096 * 4096, b = t + 1 == nt ? len : len * size_t(t + 1) / size_t(nt) / 4096 * 4096;
+                    if (b > a) std::memcpy(dst + off + a, src + off + a, b - a);
+                });
+            } else {
+                pool().parallel_for(nt, [&](int t) {
+                    for (size_t r = rows * size_t(t) / size_t(nt), r1 = rows * size_t(t + 1) / size_t(nt); r < r1; ++r)
+                        std::memcpy(dst + (r * size_t(B) + size_t(lo)) * col_bytes, src + off + r * n * col_bytes, n * col_bytes);
+                });
+            }
+        };
+        struct Pending {
+            int64_t lo, hi;
+            int32_t ticket;
+        };
+        std::vector<Pending> pending;
+        loop([&](int64_t lo, int64_t hi, const uint8_t *d_chars, const int64_t *d_offsets, const uint8_t *d_mask) {
+            bsq_status s1 = piece(d_chars, d_offsets, d_mask, hi - lo, static_cast<char *>(d_res) + size_t(lo) * per_seq_bytes);
+            int32_t ticket = -1;
+            if (s1 == BSQ_OK) s1 = bsq_stage_fetch(stage, size_t(lo) * per_seq_bytes, size_t(hi - lo) * per_seq_bytes, &ticket);
+            pending.push_back(Pending{lo, hi, ticket});
+            return s1;
+        });
+        const auto t1 = std::chrono::steady_clock::now();
+        // the pieces land in the array as their fetches complete: the copy (and the page faults of a fresh array) of piece j runs
+        // while pieces j + 1 ... are still on the bus.  No Python object is touched: other Python threads may run meanwhile.
+        auto land_all = [&] {
+            for (const Pending &q : pending) {
+                st = bsq_stage_wait(stage, q.ticket);
+                if (st != BSQ_OK) return;
+                land(q.lo, q.hi);
+            }
+        };
+        if (gil_held) {
+            py::gil_scoped_release nogil;
+            land_all();
+        } else {
+            land_all();
+        }
+        if (st != BSQ_OK) throw_status(st);
+        if (prof) {
+            auto us = [](auto x, auto y) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(y - x).count(); };
+            std::fprintf(stderr, "[bsq host] host result in pieces: produce + upload + launch + fetch %ld us, waits + copies into the result %ld us\n",
+                         us(t0, t1), us(t1, std::chrono::steady_clock::now()));
+        }
+    }
+
+    // A NUMPY result (the reference's default return) of up to 256 MB -- token matrices, small one-hots -- from a list: see fetch_and_land.
     template <typename PieceFn>
     bool staged_host(const Scan &sc, Gathered &g, py::ssize_t padlen, int nthreads, const OutBuf &out, size_t per_seq_bytes, size_t rows,
                      size_t col_bytes, bool onehot, PieceFn piece) const {
@@ -606,64 +678,47 @@ class Tokenizer {
         bsq_stage *stage = nullptr;
         Packed p;
         p.B = sc.n;
-        bsq_status st = bsq_stage_begin(sc.n, max_chars, g.has_mask ? 1 : 0, nullptr, &stage, &p.offsets, &p.chars, &p.mask);
+        const bsq_status st = bsq_stage_begin(sc.n, max_chars, g.has_mask ? 1 : 0, nullptr, &stage, &p.offsets, &p.chars, &p.mask);
         if (st != BSQ_OK) throw_status(st);
         StageEnd end{stage};
-        void *d_res = nullptr, *h_res = nullptr;
-        st = bsq_stage_result(stage, total, &d_res, &h_res);
+        fetch_and_land(stage, sc.n, per_seq_bytes, rows, col_bytes, nthreads, static_cast<char *>(out.ptr),
+                       [&](auto per_piece) { staged_pieces(sc, g, p, stage, 0, seqs, padlen, nthreads, onehot, per_piece); }, piece, true);
+        return true;
+    }
+
+    // The same for a PACKED batch in host memory (numpy arrays, a memory-mapped FlatFile): the pieces are copied into the pinned
+    // staging area (no Python object involved: the GIL is released by the caller).  Lengths have been validated.
+    template <typename PieceFn>
+    bool staged_host_packed(const uint8_t *chars, const int64_t *offs, const uint8_t *mask, int64_t B, int nthreads, char *dst, size_t per_seq_bytes,
+                            size_t rows, size_t col_bytes, PieceFn piece) const {
+        const size_t total = size_t(B) * per_seq_bytes, nchars = size_t(offs[B] - offs[0]);
+        if (B < 16384 || total > (size_t(256) << 20) || nchars > (size_t(1) << 30)) return false;
+        int64_t head = 0;
+        int64_t seqs = bsq_stage_piece_hint(B, nchars, 0, nullptr, nullptr, &head);
+        if (seqs < 0) return false;
+        if (seqs == 0 || seqs > B) seqs = B;
+        bsq_stage *stage = nullptr;
+        Packed p;
+        p.B = B;
+        const bsq_status st = bsq_stage_begin(B, nchars, mask ? 1 : 0, nullptr, &stage, &p.offsets, &p.chars, &p.mask);
         if (st != BSQ_OK) throw_status(st);
-        static const bool prof = std::getenv("BSQ_PROFILE_HOST") != nullptr;
-        const auto t0 = std::chrono::steady_clock::now();
-        char *dst = static_cast<char *>(out.ptr);
-        const char *src = static_cast<const char *>(h_res);
+        StageEnd end{stage};
         const int nt = std::max(1, std::min(nthreads, 64));
-        const size_t B = size_t(sc.n);
-        // piece [lo, hi) of the pinned area into the array: straight (rows == 0) or its rows side by side with the other pieces'
-        auto land = [&](int64_t lo, int64_t hi) {
-            const size_t off = size_t(lo) * per_seq_bytes, len = size_t(hi - lo) * per_seq_bytes, n = size_t(hi - lo);
-            if (rows == 0) {
-                pool().parallel_for(nt, [&](int t) {
-                    const size_t a = len * size_t(t) / size_t(nt) / 4096 * 4096, b = t + 1 == nt ? len : len * size_t(t + 1) / size_t(nt) / 4096 * 4096;
-                    if (b > a) std::memcpy(dst + off + a, src + off + a, b - a);
-                });
-            } else {
-                pool().parallel_for(nt, [&](int t) {
-                    for (size_t r = rows * size_t(t) / size_t(nt), r1 = rows * size_t(t + 1) / size_t(nt); r < r1; ++r)
-                        std::memcpy(dst + (r * B + size_t(lo)) * col_bytes, src + off + r * n * col_bytes, n * col_bytes);
-                });
-            }
+        const int64_t base = offs[0];
+        auto produce = [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) p.offsets[i + 1] = offs[i + 1] - base;
+            const size_t c0 = size_t(offs[lo] - base), len = size_t(offs[hi] - offs[lo]);
+            pool().parallel_for(len >= (size_t(1) << 20) ? nt : 1, [&](int t) {
+                const int k = len >= (size_t(1) << 20) ? nt : 1;
+                const size_t a = len * size_t(t) / size_t(k), b = len * size_t(t + 1) / size_t(k);
+                if (b > a) {
+                    std::memcpy(p.chars + c0 + a, chars + size_t(offs[lo]) + a, b - a);
+                    if (mask) std::memcpy(p.mask + c0 + a, mask + size_t(offs[lo]) + a, b - a);
+                }
+            });
         };
-        struct Pending {
-            int64_t lo, hi;
-            int32_t ticket;
-        };
-        std::vector<Pending> pending;
-        size_t landed = 0;  // pieces [0, landed) are in the array
-        staged_pieces(sc, g, p, stage, 0, seqs, padlen, nthreads, onehot,
-                      [&](int64_t lo, int64_t hi, const uint8_t *d_chars, const int64_t *d_offsets, const uint8_t *d_mask) {
-                          bsq_status s1 = piece(d_chars, d_offsets, d_mask, hi - lo, static_cast<char *>(d_res) + size_t(lo) * per_seq_bytes);
-                          int32_t ticket = -1;
-                          if (s1 == BSQ_OK) s1 = bsq_stage_fetch(stage, size_t(lo) * per_seq_bytes, size_t(hi - lo) * per_seq_bytes, &ticket);
-                          pending.push_back(Pending{lo, hi, ticket});
-                          return s1;
-                      });
-        const auto t1 = std::chrono::steady_clock::now();
-        // the pieces land in the array as their fetches complete: the copy (and the page faults of a fresh array) of piece j runs
-        // while pieces j + 1 ... are still on the bus
-        // (no Python object is touched from here on -- pinned bytes into the array's buffer --: other Python threads may run)
-        {
-            py::gil_scoped_release nogil;
-            for (; landed < pending.size() && st == BSQ_OK; ++landed) {
-                st = bsq_stage_wait(stage, pending[landed].ticket);
-                if (st == BSQ_OK) land(pending[landed].lo, pending[landed].hi);
-            }
-        }
-        if (st != BSQ_OK) throw_status(st);
-        if (prof) {
-            auto us = [](auto x, auto y) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(y - x).count(); };
-            std::fprintf(stderr, "[bsq host] numpy result in pieces: scan + pack + upload + launch + fetch %ld us, waits + copies into the array %ld us\n",
-                         us(t0, t1), us(t1, std::chrono::steady_clock::now()));
-        }
+        fetch_and_land(stage, B, per_seq_bytes, rows, col_bytes, nthreads, dst,
+                       [&](auto per_piece) { piece_loop(B, stage, 0, seqs, produce, per_piece); }, piece, false);
         return true;
     }
 
@@ -860,12 +915,24 @@ class Tokenizer {
                 if (offs[i + 1] < offs[i]) throw std::invalid_argument("offsets must be non-decreasing");
             {
                 py::gil_scoped_release nogil;
-                st = onehot ? (bcl ? bsq_onehot_bcl_host : bsq_onehot_host)(
-                                  &desc, static_cast<const uint8_t *>(chars.ptr), offs,
-                                  has_mask ? static_cast<const uint8_t *>(mask.ptr) : nullptr, B, padlen, t, out.ptr,
-                                  out.space, out.stream, &bad)
-                            : bsq_tokenize_host(&desc, static_cast<const uint8_t *>(chars.ptr), offs, B, padlen,
-                                                batch_first, t, out.ptr, out.space, out.stream, &bad);
+                const uint8_t *cp = static_cast<const uint8_t *>(chars.ptr), *mp = has_mask ? static_cast<const uint8_t *>(mask.ptr) : nullptr;
+                st = bsq_validate_lengths(offs, B, padlen, desc.bos, desc.eos, &bad);
+                bool done = false;
+                // a numpy result of up to 256 MB: pieces go up, are encoded and fetched back while the next ones go up (staged_host_packed)
+                if (st == BSQ_OK && out.space == BSQ_SPACE_HOST && B >= 16384) {
+                    const size_t sz = bsq_dtype_size(t), per_seq = size_t(padlen) * sz * (onehot ? size_t(C) : 1);
+                    const bool columns = onehot ? !bcl : !batch_first;
+                    done = staged_host_packed(cp, offs, mp, B, resolve_threads(0, B), static_cast<char *>(out.ptr), per_seq, columns ? size_t(padlen) : 0,
+                                              onehot ? size_t(C) * sz : sz,
+                                              [&](const uint8_t *dc, const int64_t *dof, const uint8_t *dm, int64_t n, void *dst) {
+                                                  if (!onehot) return bsq_tokenize_device(&desc, dc, dof, n, padlen, batch_first, t, dst, nullptr);
+                                                  return bcl ? bsq_onehot_bcl_device(&desc, dc, dof, dm, n, padlen, t, dst, nullptr)
+                                                             : bsq_onehot_device(&desc, dc, dof, dm, n, padlen, t, dst, nullptr);
+                                              });
+                }
+                if (st == BSQ_OK && !done)
+                    st = onehot ? (bcl ? bsq_onehot_bcl_host : bsq_onehot_host)(&desc, cp, offs, mp, B, padlen, t, out.ptr, out.space, out.stream, &bad)
+                                : bsq_tokenize_host(&desc, cp, offs, B, padlen, batch_first, t, out.ptr, out.space, out.stream, &bad);
             }
             if (st == BSQ_ERR_SEQ_TOO_LONG) throw_too_long(offs, bad, padlen, onehot);
         }
