@@ -846,7 +846,7 @@ int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, c
     int64_t head = 0;
     const int64_t seqs = piece_sequences(B, nchars, block_row_bytes, out, static_cast<hipStream_t>(hip_stream), &head);
     if (head_seqs) *head_seqs = head;
-    return head_seqs || head == 0 ? seqs : 0;  // (a caller that cannot take a head gets one piece)
+    return seqs;  // (a caller that takes no head still gets pieces: bsq_onehot_block_device splits a large misaligned block itself)
 }
 
 void bsq_release_staging(void) {

@@ -271,7 +271,8 @@ bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const in
  *                     -1 = the knob asks for the whole-batch path (host_pieces = 1).  *head_seqs: sequences the FIRST piece holds
  *                     in front of that (pieces [0, head + n), [head + n, head + 2n), ...): column blocks run fastest when they
  *                     start where a 4-KiB chunk of the result starts, and `out` is rarely aligned that far -- encode the head
- *                     with a call of its own.  Knob "host_pieces"; automatic = pieces of ~8 MB when the batch is large and hip_stream is idle (a busy
+ *                     with a call of its own (head_seqs may be NULL: pieces [0, n), [n, 2n), ..., each split inside
+ *                     bsq_onehot_block_device where it must be).  Knob "host_pieces"; automatic = pieces of ~8 MB when the batch is large and hip_stream is idle (a busy
  *                     stream means the caller is not waiting for this batch: one upload costs the host less than several).
  * What it buys (list of 65 536 bytes objects, 35 MB -> f32 one-hot on the device, synchronous): 2.1 ms as one pack + one
  * upload + one encode, 1.5 ms with the encode and the pack of the pieces under the uploads (profiles/r04/host_pieces_lab.txt).
