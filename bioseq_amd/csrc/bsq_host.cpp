@@ -67,7 +67,7 @@ struct Staging {
     hipEvent_t slot_done[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 constexpr int kSlots = 4;
-constexpr size_t kSlotBytes = size_t(8) << 20;
+constexpr size_t kSlotMin = size_t(8) << 20, kSlotMax = size_t(32) << 20;  // bytes of a bounce slot: see download()
 constexpr int kMaxDevices = 16;
 Staging g_staging[kMaxDevices];
 std::mutex g_mu;
@@ -190,7 +190,7 @@ bsq_status upload(InSlot &s, const uint8_t *chars, const int64_t *offsets, const
 // Result -> caller's (pageable) host buffer.  A plain hipMemcpy into pageable memory runs at ~16 GB/s on
 // the MI355X box (the runtime bounces through its own staging, and the first touch of a fresh numpy
 // buffer page-faults inside that single thread).  Here the copy is pipelined instead: the stream DMAs
-// 8-MiB pieces into a ring of 4 pinned slots while `nthreads` workers memcpy finished slots into the
+// 8 ... 32-MiB pieces into a ring of 4 pinned slots while `nthreads` workers memcpy finished slots into the
 // destination (every worker takes its 1/n of each piece, so the page faults of the destination are spread
 // over the workers too).  Small results take the plain path.  Knob "host_copy_threads" (default 8, 1 = plain).
 bsq_status download(Staging &s, void *out, const void *dev_out, size_t nbytes, hipStream_t stream) {
@@ -199,14 +199,17 @@ bsq_status download(Staging &s, void *out, const void *dev_out, size_t nbytes, h
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw && unsigned(nthreads) > hw) nthreads = int(hw);
     hipError_t e = hipSuccess;
-    if (nbytes < 4 * kSlotBytes || nthreads < 2) {
+    // piece size: 1/16 of the result between 8 and 32 MiB -- 5.4 GB came back in 107.9 ms through 8-MiB pieces, in 101.9 through 32-MiB
+    // ones (1.34 GB: 28.7 -> 26.9 ms; 64 MiB: no further gain; profiles/r04/default_call_lab.txt)
+    const size_t kSlotBytes = std::min(kSlotMax, std::max(kSlotMin, round_up(nbytes / 16, size_t(1) << 20)));
+    if (nbytes < 4 * kSlotMin || nthreads < 2) {
         e = hipMemcpyAsync(out, dev_out, nbytes, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return bsq_internal::set_hip_error("D2H copy of the result", e);
         return BSQ_OK;
     }
     if (!s.bounce) {
-        e = hipHostMalloc(&s.bounce, kSlots * kSlotBytes, hipHostMallocDefault);
+        e = hipHostMalloc(&s.bounce, kSlots * kSlotMax, hipHostMallocDefault);
         for (int i = 0; i < kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s.slot_done[i], hipEventDisableTiming);
         if (e != hipSuccess) return bsq_internal::set_hip_error("pinned bounce buffer", e);
     }
