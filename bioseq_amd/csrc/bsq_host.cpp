@@ -201,7 +201,12 @@ bsq_status download(Staging &s, void *out, const void *dev_out, size_t nbytes, h
     hipError_t e = hipSuccess;
     // piece size: 1/16 of the result between 8 and 32 MiB -- 5.4 GB came back in 107.9 ms through 8-MiB pieces, in 101.9 through 32-MiB
     // ones (1.34 GB: 28.7 -> 26.9 ms; 64 MiB: no further gain; profiles/r04/default_call_lab.txt)
-    const size_t kSlotBytes = std::min(kSlotMax, std::max(kSlotMin, round_up(nbytes / 16, size_t(1) << 20)));
+    static const size_t slot_cap = [] {  // BSQ_D2H_SLOT_MAX_MB = 8 ... 32 (measurement)
+        const char *e = std::getenv("BSQ_D2H_SLOT_MAX_MB");
+        const size_t mb = e && *e ? size_t(std::atoi(e)) : 32;
+        return std::min(kSlotMax, std::max(kSlotMin, mb << 20));
+    }();
+    const size_t kSlotBytes = std::min(slot_cap, std::max(kSlotMin, round_up(nbytes / 16, size_t(1) << 20)));
     if (nbytes < 4 * kSlotMin || nthreads < 2) {
         e = hipMemcpyAsync(out, dev_out, nbytes, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
