@@ -192,3 +192,36 @@ def test_scan_and_pack_in_pieces_without_a_device(bsq):
     assert chars.tobytes()[:want_off[12288]] == want[:want_off[12288]]  # (the pieces before the one that holds item 15000; of that one only the offsets)
     off, chars, bad, fast = cbioseq._pack_list_in_pieces([], 4096, maxlen, 8)
     assert bad == -1 and off.tolist() == [0] and chars.size == 0
+
+
+def test_piece_hint_arithmetic_without_a_device():
+    """bsq_stage_piece_hint with the piece count forced (knob host_pieces >= 2: no HIP call): every piece boundary of a column-block
+    result starts a 4-KiB chunk -- head + k * step sequences from a base that is only 512-byte (or less) aligned --, steps are
+    multiples of 4096 sequences, contiguous blocks need no head, rows under 16 bytes / unreachable alignments give one piece."""
+    import ctypes
+    from bioseq_amd import capi
+    lib = capi.load()
+    head = ctypes.c_int64(-1)
+    capi.check(lib.bsq_tuning_set(b"host_pieces", 4))
+    try:
+        for rb in (16, 20, 28, 80, 88, 92, 160, 2048):
+            for mis in (0, 8, 16, 512, 1536, 2560, 4088):
+                B = 65536
+                step = lib.bsq_stage_piece_hint(B, 35 << 20, rb, ctypes.c_void_p((1 << 30) + mis), None, ctypes.byref(head))
+                g = np.gcd(rb, 4096)
+                if mis % g:  # no sequence boundary is chunk-aligned
+                    assert step == 0 and head.value == 0, (rb, mis)
+                    continue
+                assert step > 0 and step % 4096 == 0 and 0 <= head.value <= 4096 // g, (rb, mis, step, head.value)
+                assert (mis + head.value * rb) % 4096 == 0 and (step * rb) % 4096 == 0
+                assert head.value + step < B
+                if mis == 0:
+                    assert head.value == 0
+        assert lib.bsq_stage_piece_hint(65536, 35 << 20, 7, ctypes.c_void_p(1 << 30), None, ctypes.byref(head)) == 0   # rows < 16 bytes
+        step = lib.bsq_stage_piece_hint(65536, 35 << 20, 0, ctypes.c_void_p((1 << 30) + 3), None, ctypes.byref(head))  # contiguous blocks
+        assert step == 16384 and head.value == 0
+        assert lib.bsq_stage_piece_hint(5000, 1 << 20, 0, None, None, ctypes.byref(head)) == 0                          # too small to split
+        capi.check(lib.bsq_tuning_set(b"host_pieces", 1))
+        assert lib.bsq_stage_piece_hint(65536, 35 << 20, 80, ctypes.c_void_p(1 << 30), None, ctypes.byref(head)) == -1  # whole-batch path asked for
+    finally:
+        capi.check(lib.bsq_tuning_set(b"host_pieces", 0))
