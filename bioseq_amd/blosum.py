@@ -75,8 +75,8 @@ def augment_packed(chars, offsets, chain_len=1, augment_frac=1.0, seed=0):
     B = offsets.numel() - 1
     if chars.numel() == 0:
         return chars  # a batch of empty sequences: nothing to mutate
-    with torch.cuda.device(chars.device):
-        stream = torch.cuda.current_stream().cuda_stream
+    with capi.on_device(chars.device):
+        stream = capi.raw_stream(chars.device)
         capi.check(_lib.bsq_augment_device(chars.data_ptr(), offsets.data_ptr(), B, int(chain_len), float(augment_frac),
                                            ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), stream))
     return chars
@@ -124,8 +124,8 @@ def augment_tokenize_packed(tokenizer, chars, offsets, padlen, destchar="b", bat
     elif tuple(out.shape) != shape or out.dtype != tdt or not out.is_contiguous() or out.device != chars.device:
         raise ValueError("out must be a contiguous %s tensor of shape %r on the device of chars" % (tdt, shape))
     desc = capi.make_desc(tokenizer.key, tokenizer.includes_eos(), tokenizer.includes_bos(), tokenizer.is_padded())
-    with torch.cuda.device(chars.device):
-        stream = torch.cuda.current_stream().cuda_stream
+    with capi.on_device(chars.device):
+        stream = capi.raw_stream(chars.device)
         capi.check(_lib.bsq_augment_tokenize_device(ctypes.byref(desc), chars.data_ptr(), offsets.data_ptr(), B, int(padlen),
                                                     int(bool(batch_first)), dt, out.data_ptr(), int(chain_len) if chars.numel() else 0, float(augment_frac),
                                                     ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), stream))

@@ -127,3 +127,34 @@ def make_desc(key: str, eos=False, bos=False, padchar=False) -> Desc:
     d = Desc()
     check(load().bsq_desc_init(ctypes.byref(d), key.encode(), int(bool(eos)), int(bool(bos)), int(bool(padchar))))
     return d
+
+
+class _NoContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_CONTEXT = _NoContext()
+
+
+def on_device(device):
+    """Context that makes `device` the current HIP device -- torch.cuda.device(device), but nothing at all when it is the current
+    one already (the context manager and `torch.cuda.current_stream()` cost ~20 us of a loader batch's ~30: profiles/r04/loader_step_lab.txt)."""
+    import torch
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_CONTEXT
+    return torch.cuda.device(device)
+
+
+def raw_stream(device=None):
+    """The current stream of `device` (default: the current device) as the integer the C ABI takes."""
+    import torch
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    fast = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if fast is not None:
+        return fast(idx)
+    return torch.cuda.current_stream(idx).cuda_stream

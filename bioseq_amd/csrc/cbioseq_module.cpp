@@ -394,7 +394,7 @@ struct OutBuf {
 // torch, looked up once (a call of BASELINE config 1's size is ~70 us of fixed costs; module / attribute lookups and the
 // torch.cuda.device context manager were ~15 of them).  Leaked on purpose: destroying py::objects at interpreter exit is not safe.
 struct TorchApi {
-    py::object device, empty, current_stream, current_device, cuda_device, dtypes[6];
+    py::object device, empty, current_stream, current_device, cuda_device, raw_stream, dtypes[6];  // raw_stream: None when torch has none
 };
 const TorchApi &torch_api() {
     static const TorchApi *api = [] {
@@ -405,6 +405,8 @@ const TorchApi &torch_api() {
         a->current_stream = torch.attr("cuda").attr("current_stream");
         a->current_device = torch.attr("cuda").attr("current_device");
         a->cuda_device = torch.attr("cuda").attr("device");
+        // torch._C._cuda_getCurrentRawStream(device_index) -> int: what torch.cuda.current_stream() wraps in ~9 us of Python
+        a->raw_stream = py::getattr(torch.attr("_C"), "_cuda_getCurrentRawStream", py::none());
         const char *names[6] = {"int8", "int16", "int32", "int64", "float32", "float64"};  // (BSQ_U64 -> int64: see below)
         for (int i = 0; i < 6; ++i) a->dtypes[i] = torch.attr(names[i]);
         return a;
@@ -427,7 +429,8 @@ void make_out(OutBuf &o, const std::vector<py::ssize_t> &shape, bsq_dtype t, con
     // make `device=` the current device for the staging buffers and the launch -- through torch's context manager only when it
     // is not the current one already (the common case)
     const py::object index = dev.attr("index");
-    if (!index.is_none() && index.cast<int>() != T.current_device().cast<int>()) {
+    const int current = T.current_device().cast<int>(), want = index.is_none() ? current : index.cast<int>();
+    if (want != current) {
         o.guard = T.cuda_device(dev);
         o.guard.attr("__enter__")();
     }
@@ -436,7 +439,8 @@ void make_out(OutBuf &o, const std::vector<py::ssize_t> &shape, bsq_dtype t, con
     static const int dtype_index[6] = {0, 1, 2, 3, 4, 5};  // bsq_dtype order: I8, I16, I32, U64, F32, F64
     py::object ten = T.empty(py::cast(shape), py::arg("dtype") = T.dtypes[dtype_index[int(t)]], py::arg("device") = dev);
     o.ptr = reinterpret_cast<void *>(ten.attr("data_ptr")().cast<uintptr_t>());
-    o.stream = reinterpret_cast<void *>(T.current_stream().attr("cuda_stream").cast<uintptr_t>());
+    o.stream = reinterpret_cast<void *>(T.raw_stream.is_none() ? T.current_stream().attr("cuda_stream").cast<uintptr_t>()
+                                                               : T.raw_stream(want).cast<uintptr_t>());
     o.obj = ten;
     o.space = BSQ_SPACE_DEVICE;
 }

@@ -207,14 +207,14 @@ class FlatFile:
         else:
             capacity = n * self._longest
         out_offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
-        status = torch.empty(1, dtype=torch.int64, device=dev)
+        status = torch.empty(1, dtype=torch.int64, device=dev) if (on_device and validate) else None
         while True:
             out_chars = torch.empty(max(capacity, 1), dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            with capi.on_device(dev):
+                stream = ctypes.c_void_p(capi.raw_stream(dev))
                 capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), self._n, idx.data_ptr(), n,
                                                         out_chars.data_ptr(), capacity, out_offs.data_ptr(),
-                                                        status.data_ptr() if (on_device and validate) else None, stream))
+                                                        status.data_ptr() if status is not None else None, stream))
             if not (on_device and validate):  # (host lists were range-checked above and sized exactly)
                 break
             bad = int(status.item())  # the only synchronising step, and only for index tensors nobody has checked
