@@ -225,17 +225,17 @@ def device_passes(tokenizer, padlen: int, destchar: str, device):
         out = torch.empty((padlen, Bg), dtype=torch.uint8, device=dev)
         if Bg == 0:
             return out
-        with torch.cuda.device(dev):
+        with capi.on_device(dev):
             capi.check(lib.bsq_raw_tokens_device(ctypes.byref(desc), ch.data_ptr(), of.data_ptr(), None, Bg, padlen,
-                                                 out.data_ptr(), Bg, torch.cuda.current_stream().cuda_stream))
+                                                 out.data_ptr(), Bg, capi.raw_stream()))
         return out
 
     def expand(tokens):
         P, B = int(tokens.shape[0]), int(tokens.shape[1])
         out = torch.empty((P, B, C), dtype=tdt, device=tokens.device)
-        with torch.cuda.device(tokens.device):
+        with capi.on_device(tokens.device):
             capi.check(lib.bsq_onehot_from_raw_tokens_device(tokens.data_ptr(), B, B, P, C, dt, out.data_ptr(),
-                                                             torch.cuda.current_stream().cuda_stream))
+                                                             capi.raw_stream()))
         return out
 
     return raw_tokens, expand
@@ -341,8 +341,8 @@ def _store_shard(lib, desc, dt, full, shard_chars, shard_offsets, b0, B, padlen,
         # 'tbc': this rank's sequences are a COLUMN BLOCK of every position row of the (P, B, C) tensor
         slab = full[:, b0:b0 + nb] if layout in ("tbc", "tokens_sf") else full[b0:b0 + nb]
         assert layout in ("tbc", "tokens_sf") or (slab.is_contiguous() and slab.shape[0] == nb)
-        with torch.cuda.device(dev):
-            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        with capi.on_device(dev):
+            stream = ctypes.c_void_p(capi.raw_stream())
             if validate:
                 bad = ctypes.c_int64(-1)
                 capi.check(lib.bsq_validate_packed_device(of.data_ptr(), nb, padlen, desc.bos, desc.eos, ch.numel(), ctypes.byref(bad), stream))
