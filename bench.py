@@ -278,7 +278,7 @@ def golden_folds():
 class Batch:
     """One workload's batch resident in HBM + its step through the C ABI."""
 
-    def __init__(self, name, lib, dev, stream, n=None, first=0):
+    def __init__(self, name, lib, dev, stream, n=None, first=0, fold_key=None):
         import ctypes
         import torch
         from bioseq_amd import capi, synth
@@ -288,6 +288,8 @@ class Batch:
         self.P = cfg["padlen"]
         self.n = cfg["n"] if n is None else n
         self.full_size = self.n == cfg["n"] and first == 0
+        self.first = first
+        self.fold_key = fold_key  # a sub-batch that has reference-made folds of its own (the `<w>_shardN` entries of bench_folds.json)
         self.chars, self.offsets = synth.synth_packed(cfg["seed"], self.n, cfg["lo"], cfg["hi"], cfg["letters"], first=first)
         self.total = int(self.offsets[-1])
         self.desc = capi.make_desc(cfg["key"], cfg["eos"], cfg["bos"], cfg["padchar"])
@@ -337,6 +339,28 @@ class Batch:
         self.step_calls += 1
         self.run(self.d_chars, self.d_offs, self.out, self.n)
 
+    def run_into_root(self, root, b0, n_full):
+        """This batch as sequences [b0, b0 + n) of a job of n_full sequences, written straight into the job's whole-batch tensor
+        `root` (what sharding.store_shard_into_root does through a peer mapping): seq-first layouts are COLUMN BLOCKS at the root's
+        row pitch (bsq_onehot_block_device / bsq_tokenize_block_device), batch-first ones contiguous slabs of rows."""
+        import ctypes
+        from bioseq_amd import capi
+        lib, desc, n, P, C, sz = self.lib, self.desc, self.n, self.P, self.C, self.sz
+        base = root.data_ptr()
+        if self.op == "onehot":
+            st = lib.bsq_onehot_block_device(ctypes.byref(desc), self.d_chars.data_ptr(), self.d_offs.data_ptr(), None, n, P, self.dt_code,
+                                             base + b0 * C * sz, n_full, self.sh)
+        elif self.op == "tokenize" and not self.batch_first:
+            st = lib.bsq_tokenize_block_device(ctypes.byref(desc), self.d_chars.data_ptr(), self.d_offs.data_ptr(), n, P, self.dt_code,
+                                               base + b0 * sz, n_full, self.sh)
+        else:  # rows [b0, b0 + n) of a batch-first result are contiguous: the whole-tensor entry point at an offset
+            rows = root[b0:b0 + n]
+            assert rows.is_contiguous()
+            self.run(self.d_chars, self.d_offs, rows, n)
+            return
+        if st:
+            capi.check(st)
+
     def check(self):
         """Untimed: one step into a buffer filled with 7, then (a) a size-independent property, (b) at full size the folds of the
         output against those of the REFERENCE's output (tests/golden/bench_folds.json; cfg5aug: the reference's tokens of the numpy
@@ -371,12 +395,15 @@ class Batch:
             assert 0.4 * n < changed < 0.6 * n, ("augment+tokenize sanity failed: mutations", changed, n)
             res["mutated_sequences"] = changed
             capi.check(lib.bsq_fused_status(None))
-        g = golden_folds().get(self.name)
-        if self.full_size and g:
+        g = golden_folds().get(self.fold_key or self.name)
+        if g and self.fold_key:
+            assert g.get("sequences") == n and self.first == 0, ("not the batch these folds were made from", self.fold_key, n, self.first)
+        if (self.full_size or self.fold_key) and g:
             x, sm, ws = fold_device(self.out)
             ok = (x, sm, ws) == (g["xor"], g["sum"], g["wsum"]) and self.out_bytes == g["nbytes"]
             assert ok, ("output differs from the reference's (folds)", self.name, (x, sm, ws), g)
-            res.update({"vs": "tests/golden/bench_folds.json (folds of the reference's output at full size)", "xor": x, "sum": sm, "wsum": ws, "ok": True})
+            res.update({"vs": "tests/golden/bench_folds.json (folds of the reference's output %s)" % ("of this shard as a batch of its own" if self.fold_key else "at full size"),
+                        "xor": x, "sum": sm, "wsum": ws, "ok": True})
             if self.op == "augment+tokenize":
                 gm = g["mutated_chars"]
                 xm = fold_device(self.d_chars)
@@ -542,6 +569,96 @@ def cold_regime(b, steps, min_s, stream, verify=True):
     return res
 
 
+SHARD_CONFIGS = ["cfg3", "cfg4f", "cfg4b", "cfg5aug"]  # their rank-0 shard of an 8-rank strong split rides in the driver's line as `<w>_shard8`
+
+
+def run_shard(name, world, lib, dev, stream, steps, warmup, full_ms=None, full_cold_ms=None, rank=0):
+    """The per-GPU term of the 1/2/4/8 strong-scaling curve, measured on ONE GPU (missing #1): rank `rank`'s
+    sharding.shard_bounds share of the workload's batch -- a 1/world-size launch -- (i) as a tensor of its own and (ii) written
+    straight into a whole-batch root tensor (column block at the root's pitch for seq-first layouts, slab of rows otherwise; rank 0's
+    position and the middle rank's, whose column offset need not be chunk-aligned).  Rank 0's stand-alone output is checked against
+    reference-made folds (`<w>_shard8` in tests/golden/bench_folds.json); every block against the stand-alone tensor, and the root
+    around it for stray writes.  predicted_strong_scaling_efficiency = t(full batch) / (world * t(shard))."""
+    import torch
+    from bioseq_amd.sharding import shard_bounds
+    from bioseq_amd import synth
+    t0 = time.perf_counter()
+    cfg_name, op, _, batch_first = WORKLOADS[name]
+    n_full = synth.CONFIGS[cfg_name]["n"]
+    b0, b1 = shard_bounds(n_full, world, rank)
+    key = "%s_shard%d" % (name, world)
+    b = Batch(name, lib, dev, stream, n=b1 - b0, first=b0, fold_key=key if (rank == 0 and key in golden_folds()) else None)
+    res = {"workload": b.describe(), "shard_of": world, "rank": rank, "sequences": b.n, "job_sequences": n_full,
+           "kernel": b.kernel_name(), "algorithmic_bytes_per_launch": b.algo_bytes}
+    res["check"] = b.check()
+    ramp(b.step, stream)
+    loop_ms = timed_loop(b.step, steps, warmup, stream)
+    if op == "augment+tokenize":
+        b.d_chars.copy_(torch.from_numpy(b.chars).to(dev))
+    sus = sustained_loop(b, 0.25, steps, loop_ms, stream)
+    res.update({"ms_per_step": loop_ms, "frac": b.algo_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "frac_sustained": sus["frac"],
+                "sustained_ms_per_step": sus["kernel_avg_ms"]})
+    if full_ms:
+        res["full_batch_ms_per_step"] = full_ms
+        res["predicted_strong_scaling_efficiency"] = full_ms / (world * loop_ms)
+    if op in ("tokenize", "augment+tokenize"):
+        cold = cold_regime(b, steps, 0.25, stream)
+        res["cold"] = cold
+        res["frac_cache_resident"], res["ms_per_step_cache_resident"] = res["frac"], res["ms_per_step"]
+        res["frac"], res["ms_per_step"] = cold["frac"], cold["ms_per_step"]
+        res["regime"] = "cold (inputs and outputs of > 512 MiB of distinct shards in turn); the cache-resident loop is beside it"
+        if full_cold_ms:
+            res["full_batch_cold_ms_per_step"] = full_cold_ms
+            res["predicted_strong_scaling_efficiency_cold"] = full_cold_ms / (world * cold["ms_per_step"])
+    # (ii) into the root's whole-batch tensor
+    seq_first = op == "onehot" or (op == "tokenize" and not batch_first)
+    root = torch.empty(b.out_shape(n_full), dtype=b.tdt, device=dev)
+    b.aug_seed = 0
+    b.step()  # the stand-alone tensor once more from the pristine batch (seed 1): what every block must equal
+    want = b.out.clone()
+    if op == "augment+tokenize":
+        b.d_chars.copy_(torch.from_numpy(b.chars).to(dev))
+    ranks = [rank] if world < 3 or rank != 0 else [0, world // 2]
+    for r in ranks:
+        # (timing only needs a position: the middle rank's block is THIS shard's sequences at that rank's column / row offset)
+        p0 = shard_bounds(n_full, world, r)[0]
+        if p0 + b.n > n_full:
+            continue
+        root.fill_(7)
+        b.aug_seed = 0
+        b.run_into_root(root, p0, n_full)
+        torch.cuda.synchronize()
+        got = root[:, p0:p0 + b.n] if seq_first else root[p0:p0 + b.n]
+        assert torch.equal(got, want), ("a block written into the root differs from the stand-alone shard", name, r)
+        seven = torch.tensor(7, dtype=b.tdt, device=dev)
+        left = root[:, :p0] if seq_first else root[:p0]
+        right = root[:, p0 + b.n:] if seq_first else root[p0 + b.n:]
+        assert bool((left == seven).all()) and bool((right == seven).all()), ("a block wrote outside its columns / rows", name, r)
+        if op == "augment+tokenize":
+            b.d_chars.copy_(torch.from_numpy(b.chars).to(dev))
+        blk = lambda: b.run_into_root(root, p0, n_full)
+        ramp(blk, stream)
+        ms = timed_loop(blk, steps, warmup, stream)
+        if op == "augment+tokenize":
+            b.d_chars.copy_(torch.from_numpy(b.chars).to(dev))
+        e = {"ms_per_step": ms, "frac": b.algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "first_sequence": p0,
+             "byte_offset_in_root_mod_4096": (p0 * (b.C if op == "onehot" else 1) * b.sz if seq_first else p0 * b.out_bytes // b.n) % 4096,
+             "what": ("column block of the (P, %d%s) root at its row pitch" % (n_full, ", C" if op == "onehot" else "")) if seq_first
+                     else "rows [%d, %d) of the root: a contiguous slab" % (p0, p0 + b.n),
+             "check": "== the stand-alone shard tensor; the rest of the root untouched"}
+        if full_ms:
+            e["predicted_strong_scaling_efficiency"] = full_ms / (world * ms)
+        res["into_root" if r == rank else "into_root_at_rank%d" % r] = e
+    if op == "augment+tokenize":
+        from bioseq_amd import capi
+        torch.cuda.synchronize()
+        capi.check(lib.bsq_fused_status(None))
+    res["seconds"] = time.perf_counter() - t0
+    del b, root, want
+    torch.cuda.empty_cache()
+    return res
+
+
 def traffic_of(workload):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -572,7 +689,17 @@ def run_config(name, lib, dev, stream, steps, warmup):
     res["gb_per_s_written"] = b.out_bytes / (loop_ms * 1e-3) / 1e9
     res["traffic"] = traffic_of(name)
     if b.op in ("tokenize", "augment+tokenize"):
-        res["cold"] = cold_regime(b, steps, 0.5, stream)
+        # The token workloads' working sets (35 + 64 MiB, 71 + 128 MiB) fit the 256-MiB Infinity Cache, and a training loop never
+        # encodes one batch twice: their PRIMARY figures are the cold regime's; the loop over one resident
+        # batch stays beside them, labelled.
+        cold = res["cold"] = cold_regime(b, steps, 0.5, stream)
+        res["frac_cache_resident"], res["ms_per_step_cache_resident"] = res["frac"], res["ms_per_step"]
+        res["frac_sustained_cache_resident"] = res["frac_sustained"]
+        res["frac"], res["ms_per_step"], res["frac_sustained"] = cold["frac"], cold["ms_per_step"], cold["frac_sustained"]
+        res["gseq_chars_per_s"] = b.total / (cold["ms_per_step"] * 1e-3) / 1e9
+        res["gb_per_s_written"] = b.out_bytes / (cold["ms_per_step"] * 1e-3) / 1e9
+        res["regime"] = ("cold: the step cycling over %d distinct batches (%.0f MB of inputs, %.0f MB of outputs), nothing cache-resident; "
+                         "`*_cache_resident` = the same step looped over ONE batch" % (cold["batches"], cold["input_bytes_total"] / 1e6, cold["output_bytes_total"] / 1e6))
     if b.op == "augment+tokenize":
         from bioseq_amd import capi
         torch.cuda.synchronize()
@@ -616,6 +743,10 @@ def main():
                          "default workload: %s), 'none', or a comma-separated list" % ",".join(DEFAULT_CONFIGS))
     ap.add_argument("--no-configs", action="store_true", help="same as --configs none")
     ap.add_argument("--cold", action="store_true", help="N = 1: add the cold-input regime of THIS workload (token workloads) as `cold`")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="N",
+                    help="N = 1 GPU: additionally measure rank 0's share of this workload's batch split over N ranks (a 1/N-size launch), as a "
+                         "tensor of its own and written into a whole-batch root tensor, as `shard` (the per-GPU term of the strong-scaling curve)")
+    ap.add_argument("--shard-rank", type=int, default=0, help="which rank's share --shard-of measures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive timings of the Python surface (N = 1 only)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 1 s sustained loop (N = 1 only)")
@@ -917,14 +1048,25 @@ def main():
         # every other BASELINE workload in the same line (N = 1; default: only beside the headline workload)
         which = "none" if args.no_configs else (args.configs if args.configs is not None else ("all" if args.workload == "cfg3" else "none"))
         names = DEFAULT_CONFIGS if which == "all" else [] if which == "none" else [w for w in which.split(",") if w]
-        if world == 1 and names:
+        if world == 1 and (names or args.shard_of > 1):
             del b, d_chars, d_offs, out, step
             torch.cuda.empty_cache()
+        if world == 1 and args.shard_of > 1:
+            res["shard"] = run_shard(args.workload, args.shard_of, lib, dev, stream, args.steps, args.warmup, full_ms=loop_ms,
+                                     full_cold_ms=(cold or {}).get("ms_per_step"), rank=args.shard_rank)
+        if world == 1 and names:
             res["configs"] = {}
             for wname in names:
                 if wname not in WORKLOADS:
                     raise SystemExit("unknown workload in --configs: %r" % wname)
                 res["configs"][wname] = run_config(wname, lib, dev, stream, args.steps, args.warmup)
+            if which == "all":
+                # the per-GPU term of the 8-rank strong-scaling curve, on this one GPU (no multi-GPU node has been offered to the driver)
+                for wname in SHARD_CONFIGS:
+                    full = res["configs"].get(wname)
+                    full_ms = loop_ms if wname == args.workload else (full or {}).get("ms_per_step_cache_resident", (full or {}).get("ms_per_step"))
+                    full_cold = ((full or {}).get("cold") or {}).get("ms_per_step")
+                    res["configs"]["%s_shard8" % wname] = run_shard(wname, 8, lib, dev, stream, args.steps, args.warmup, full_ms=full_ms, full_cold_ms=full_cold)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -29,10 +29,10 @@ except ImportError as _e:  # fail loudly: the HIP extension IS the product
         "`python bioseq_amd/build.py` (needs hipcc; gfx950 code objects cross-compile without a GPU)." % (_e,)
     ) from _e
 
-from .cbioseq import Threading, Tokenizer, get_num_threads, set_num_threads  # noqa: F401
+from .cbioseq import Threading, Tokenizer, get_host_threads, get_num_threads, set_host_threads, set_num_threads  # noqa: F401
 from . import synth  # noqa: F401
 from . import blosum, sharding  # noqa: F401
-from .flatfile import FlatFile, getstats  # noqa: F401  (bioseq.FlatFile / getstats, /root/reference/src/fxstats.cpp:166-219)
+from .flatfile import FlatFile, FlatFileIterator, getstats  # noqa: F401  (bioseq.FlatFile / getstats, /root/reference/src/fxstats.cpp:166-219)
 
 __version__ = "0.1.0"
 
@@ -161,4 +161,4 @@ __all__ = ["onehot_encode", "cbioseq", "f_encode", "Tokenizer", "make_embedding"
            "pos_tokenizers", "default_tokenizers", "total_tokenizer_dict", "get_tokenizer_dict", "DNATokenizer",
            "AmineTokenizer", "Reduced6Tokenizer", "Reduced8Tokenizer", "Reduced10Tokenizer", "Reduced14Tokenizer",
            "DayhoffTokenizer", "LIATokenizer", "LIBTokenizer", "torchify", "set_num_threads", "get_num_threads",
-           "Threading", "device_count", "synth", "blosum", "sharding", "FlatFile", "getstats", "loaders"]
+           "Threading", "device_count", "synth", "blosum", "sharding", "FlatFile", "FlatFileIterator", "getstats", "loaders", "set_host_threads", "get_host_threads"]

@@ -377,11 +377,24 @@ bsq_status run_host(const bsq_desc *d, const uint8_t *chars, const int64_t *offs
     }
     if (block.seqs > 0 && out_space == BSQ_SPACE_DEVICE && block.seqs < B) {
         st = run_pieces(s, *slot, chars, offsets, mask, B, out, stream, block);
-        if (st != BSQ_OK) return st;
-        const hipError_t eb = hipEventRecord(slot->busy, stream);
-        if (eb != hipSuccess) return bsq_internal::set_hip_error("hipEventRecord", eb);
-        slot->busy_pending = true;
-        return BSQ_OK;
+        // Whatever run_pieces returned: the copies and kernels of the pieces in front of a failing one are enqueued and read this slot's
+        // pinned and device areas, so the slot is marked busy on EVERY exit (an early return left it looking idle and
+        // the next call could overwrite what those kernels were still reading).  After a failure the copy stream is folded in first.
+        hipError_t eb = hipSuccess;
+        if (st != BSQ_OK) {
+            eb = hipEventRecord(s.uploaded, s.copy_stream);
+            if (eb == hipSuccess) eb = hipStreamWaitEvent(stream, s.uploaded, 0);
+        }
+        if (eb == hipSuccess) eb = hipEventRecord(slot->busy, stream);
+        if (eb == hipSuccess) {
+            slot->busy_pending = true;
+        } else {  // no event to wait for later: wait now
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(s.copy_stream);
+            (void)hipStreamSynchronize(stream);
+            if (st == BSQ_OK) return bsq_internal::set_hip_error("hipEventRecord", eb);
+        }
+        return st;
     }
     // Upload on the copy stream (the slot is idle: waited for above or in bsq_pinned_scratch), then make the
     // caller's stream wait for it: the copy overlaps whatever that stream is still running (the previous encode).

@@ -75,11 +75,33 @@ WorkerPool &pool() {
     return *p;
 }
 
-// nthreads of a batch call: the reference's default is 1 and an explicit value is honoured; the DEFAULT here is 0 =
-// automatic: one thread for small batches, min(get_num_threads(), 16) host threads for the scan + pack of >= 8192 items
-// (the encode itself runs on the GPU whatever the value).
+// nthreads of a batch call.  The SIGNATURE default is the reference's 1 (src/tokenize.cpp:81,98) -- inspect.signature of both batch
+// methods equals the reference's for every reference parameter -- and in the reference that 1 sizes the OpenMP team of the encode
+// loops.  Here the encode runs on the GPU whatever the value; what is left for host threads is the scan + pack of the Python items,
+// and that is governed by a MODULE-LEVEL policy the reference's default defers to (round 5; was a signature default of 0):
+//   * nthreads > 1   an explicit request: honoured as it is;
+//   * nthreads <= 1  (the reference's default, and <= 0, which the reference maps to 1: tokenize.h:384) -> set_host_threads(n) /
+//                    BSQ_HOST_THREADS: n > 0 exactly n threads (1 = strictly serial), 0 (default) automatic: one thread below
+//                    8192 items, min(get_num_threads(), 16) workers above.
+// Results never depend on any of this (tests/test_gpu_parity.py: nthreads sweep).
+std::atomic<int> g_host_threads{-1};  // -1: not set yet (the environment decides at first use), 0 automatic, > 0 fixed
+int host_threads_policy() {
+    int t = g_host_threads.load();
+    if (t < 0) {
+        const char *e = std::getenv("BSQ_HOST_THREADS");
+        int v = e ? std::atoi(e) : 0;
+        if (v < 0) v = 0;
+        if (v > 1024) v = 1024;
+        int expect = -1;
+        g_host_threads.compare_exchange_strong(expect, v);
+        t = g_host_threads.load();
+    }
+    return t;
+}
 int resolve_threads(int nthreads, Py_ssize_t nitems) {
-    if (nthreads > 0) return nthreads;
+    if (nthreads > 1) return nthreads;
+    const int policy = host_threads_policy();
+    if (policy > 0) return policy;
     if (nitems < 8192) return 1;
     const int t = default_threads();
     return t > 16 ? 16 : (t < 1 ? 1 : t);
@@ -231,7 +253,33 @@ struct Packed {
     uint8_t *chars = nullptr;
     uint8_t *mask = nullptr;
     int64_t B = 0;
+    size_t cap = SIZE_MAX;  // characters the area behind `chars` holds (staged batches: sized from an ESTIMATE, see estimate_chars)
 };
+
+// A staged batch whose characters outgrow the estimate its staging area was sized for: the piece loop stops before a byte of the
+// offending piece is copied and the caller falls back to the whole-batch path (which measures the batch before it allocates).
+struct StageOverflow {};
+
+// What a list batch will need in the pinned / device staging areas, from the lengths of <= 512 evenly spaced items (object headers
+// only) x 1.5 + 1 MiB, never more than the longest legal batch n * maxlen.  Round 4 sized the areas for n * maxlen itself (capped at
+// 1 GiB): 16 384 sequences of ~200 characters under padlen 65 536 then pinned 3 x 1.25 GiB of host memory and as much on the device
+// where a few MB were needed.  An under-estimate costs a fallback (StageOverflow), never a wrong result.
+size_t estimate_chars(const Scan &sc, int64_t maxlen, size_t *mean_total) {
+    const size_t n = size_t(sc.n), worst = n * size_t(maxlen);
+    const size_t samples = std::min<size_t>(n, 512);
+    size_t sum = 0;
+    for (size_t k = 0; k < samples; ++k) {
+        PyObject *o = sc.objs[k * n / samples];
+        Item it{nullptr, 0};
+        size_t len = size_t(maxlen);  // other item types (numpy arrays, non-ASCII str, subclasses): assume the longest legal one
+        if (fast_item(o, &it)) len = it.len;
+        else if (PyUnicode_Check(o) && PyUnicode_IS_READY(o)) len = size_t(PyUnicode_GET_LENGTH(o)) * 2;
+        sum += std::min(len, size_t(maxlen));
+    }
+    const size_t est = samples ? size_t(double(sum) / double(samples) * double(n)) : 0;
+    if (mean_total) *mean_total = std::min(worst, est);
+    return std::min(worst, est + est / 2 + (size_t(1) << 20));
+}
 
 size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
 
@@ -289,7 +337,7 @@ void pack_range(const Gathered &g, const Packed &p, int64_t first, int64_t last,
 // is a mask list) and nothing usable was written -- the caller takes scan_range + pack_range for this piece.  An item longer than
 // maxlen stops everything before a byte is copied: *too_long = the first such item and p.offsets[*too_long + 1] holds its end.
 bool scan_pack_fast(const Scan &sc, Gathered &g, const Packed &p, int64_t first, int64_t last, int nthreads, int64_t maxlen, int64_t *too_long) {
-    *too_long = -1;
+    *too_long = -1;  // (throws StageOverflow when the piece does not fit behind p.chars: nothing of it has been copied then)
     const int64_t n = last - first;
     const int nt = int(std::min<int64_t>(std::min(nthreads, 64), n / 256));  // (every task of the job needs a thread of its own: barrier)
     if (sc.mask_is_list || nt < 2) return false;
@@ -299,7 +347,7 @@ bool scan_pack_fast(const Scan &sc, Gathered &g, const Packed &p, int64_t first,
         char pad[40];
     };
     std::vector<Part> part(size_t(nt), Part{});
-    std::atomic<int> arrived{0}, verdict{0};  // verdict: 1 go on, 2 stop
+    std::atomic<int> arrived{0}, verdict{0};  // verdict: 1 go on, 2 stop, 3 stop: the piece does not fit (p.cap)
     PyObject **objs = sc.objs;
     pool().parallel_for(nt, [&](int t) {
         const int64_t i0 = first + n * t / nt, i1 = first + n * (t + 1) / nt;
@@ -316,8 +364,12 @@ bool scan_pack_fast(const Scan &sc, Gathered &g, const Packed &p, int64_t first,
         part[size_t(t)] = mine;
         if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nt) {  // the last one in decides for all
             bool go = true;
-            for (const Part &q : part) go = go && q.odd < 0 && q.too_long < 0;
-            verdict.store(go ? 1 : 2, std::memory_order_release);
+            size_t end = size_t(p.offsets[first]);
+            for (const Part &q : part) {
+                go = go && q.odd < 0 && q.too_long < 0;
+                end += q.sum;
+            }
+            verdict.store(!go ? 2 : (end > p.cap ? 3 : 1), std::memory_order_release);
         }
         int v;
         for (unsigned spins = 0; (v = verdict.load(std::memory_order_acquire)) == 0; ++spins) {
@@ -336,6 +388,7 @@ bool scan_pack_fast(const Scan &sc, Gathered &g, const Packed &p, int64_t first,
     });
     for (const Part &q : part)
         if (q.odd >= 0) return false;
+    if (verdict.load(std::memory_order_acquire) == 3) throw StageOverflow{};
     for (const Part &q : part)
         if (q.too_long >= 0) {  // the first too-long item: lengths up to it are all known
             int64_t at = p.offsets[first];
@@ -558,6 +611,7 @@ class Tokenizer {
                                p.offsets[i + 1] = p.offsets[i] + int64_t(g.items[size_t(i)].len);
                                if (int64_t(g.items[size_t(i)].len) > maxlen) throw_too_long(p.offsets, i, padlen, onehot);
                            }
+                           if (size_t(p.offsets[hi]) > p.cap) throw StageOverflow{};
                            pack_range(g, p, lo, hi, nthreads);
                        }
                        if (bad >= 0) throw_too_long(p.offsets, bad, padlen, onehot);
@@ -575,27 +629,40 @@ class Tokenizer {
                 bool onehot, BlockFn block) const {
         const int64_t maxlen = int64_t(padlen) - desc.bos - desc.eos;  // a longer item is an error anyway
         if (out.space != BSQ_SPACE_DEVICE || sc.n < 16384 || maxlen <= 0) return false;
-        const size_t max_chars = size_t(sc.n) * size_t(maxlen);
+        size_t likely = 0;
+        const size_t max_chars = estimate_chars(sc, maxlen, &likely);  // (an estimate: see StageOverflow)
         if (max_chars > (size_t(1) << 30)) return false;
         int64_t head = 0;  // sequences in front of the first piece boundary (column blocks of a result that is not 4-KiB aligned)
-        int64_t seqs = splittable ? bsq_stage_piece_hint(sc.n, max_chars / 2, block_row_bytes, out.ptr, out.stream, &head) : 0;
+        int64_t seqs = splittable ? bsq_stage_piece_hint(sc.n, likely, block_row_bytes, out.ptr, out.stream, &head) : 0;
         if (seqs < 0) return false;                  // knob host_pieces = 1: the whole-batch path of rounds 1-3
         if (seqs == 0 || seqs > sc.n) seqs = sc.n;   // one piece (busy stream, misaligned result, ...): still one scan + pack job
         bsq_stage *stage = nullptr;
         Packed p;
         p.B = sc.n;
+        p.cap = max_chars;
         const bsq_status st0 = bsq_stage_begin(sc.n, max_chars, g.has_mask ? 1 : 0, out.stream, &stage, &p.offsets, &p.chars, &p.mask);
         if (st0 != BSQ_OK) throw_status(st0);
         StageEnd end{stage};
-        staged_pieces(sc, g, p, stage, head, seqs, padlen, nthreads, onehot,
-                      [&](int64_t lo, int64_t hi, const uint8_t *d_chars, const int64_t *d_offsets, const uint8_t *d_mask) {
-                          const int64_t lead = lo == 0 && head < hi ? head : 0;
-                          bsq_status st = BSQ_OK;
-                          if (lead) st = block(d_chars, d_offsets, d_mask, 0, lead);
-                          if (st == BSQ_OK) st = block(d_chars, d_offsets + lead, d_mask, lo + lead, hi - lo - lead);
-                          return st;
-                      });
+        try {
+            staged_pieces(sc, g, p, stage, head, seqs, padlen, nthreads, onehot,
+                          [&](int64_t lo, int64_t hi, const uint8_t *d_chars, const int64_t *d_offsets, const uint8_t *d_mask) {
+                              const int64_t lead = lo == 0 && head < hi ? head : 0;
+                              bsq_status st = BSQ_OK;
+                              if (lead) st = block(d_chars, d_offsets, d_mask, 0, lead);
+                              if (st == BSQ_OK) st = block(d_chars, d_offsets + lead, d_mask, lo + lead, hi - lo - lead);
+                              return st;
+                          });
+        } catch (const StageOverflow &) {
+            // more characters than the sampled estimate allowed for: the blocks encoded so far are valid and will simply be written
+            // again, in stream order, by the whole-batch path the caller goes on with (it scans everything before it allocates)
+            reset_scan(g);
+            return false;
+        }
         return true;
+    }
+
+    static void reset_scan(Gathered &g) {  // forget a partial scan (the pieces in front of a StageOverflow); `keep` only grows
+        g.total = 0;
     }
 
     // The same for a NUMPY result (the reference's default return) of up to 256 MB -- token matrices, small one-hots: every piece
@@ -673,20 +740,27 @@ class Tokenizer {
         const int64_t maxlen = int64_t(padlen) - desc.bos - desc.eos;
         const size_t total = size_t(sc.n) * per_seq_bytes;
         if (out.space != BSQ_SPACE_HOST || sc.n < 16384 || maxlen <= 0 || total > (size_t(256) << 20)) return false;
-        const size_t max_chars = size_t(sc.n) * size_t(maxlen);
+        size_t likely = 0;
+        const size_t max_chars = estimate_chars(sc, maxlen, &likely);
         if (max_chars > (size_t(1) << 30)) return false;
         int64_t head = 0;
-        int64_t seqs = bsq_stage_piece_hint(sc.n, max_chars / 2, 0, nullptr, nullptr, &head);
+        int64_t seqs = bsq_stage_piece_hint(sc.n, likely, 0, nullptr, nullptr, &head);
         if (seqs < 0) return false;
         if (seqs == 0 || seqs > sc.n) seqs = sc.n;
         bsq_stage *stage = nullptr;
         Packed p;
         p.B = sc.n;
+        p.cap = max_chars;
         const bsq_status st = bsq_stage_begin(sc.n, max_chars, g.has_mask ? 1 : 0, nullptr, &stage, &p.offsets, &p.chars, &p.mask);
         if (st != BSQ_OK) throw_status(st);
         StageEnd end{stage};
-        fetch_and_land(stage, sc.n, per_seq_bytes, rows, col_bytes, nthreads, static_cast<char *>(out.ptr),
-                       [&](auto per_piece) { staged_pieces(sc, g, p, stage, 0, seqs, padlen, nthreads, onehot, per_piece); }, piece, true);
+        try {
+            fetch_and_land(stage, sc.n, per_seq_bytes, rows, col_bytes, nthreads, static_cast<char *>(out.ptr),
+                           [&](auto per_piece) { staged_pieces(sc, g, p, stage, 0, seqs, padlen, nthreads, onehot, per_piece); }, piece, true);
+        } catch (const StageOverflow &) {  // (nothing has landed in the array yet: pieces land after the loop)
+            reset_scan(g);
+            return false;
+        }
         return true;
     }
 
@@ -1200,7 +1274,14 @@ PYBIND11_MODULE(cbioseq, m) {
     m.doc() = "bioseq_amd.cbioseq: MI355X-native drop-in for the reference's cbioseq tokenizer module";
     m.attr("abi_version") = bsq_abi_version();
     m.def("device_count", [] { return bsq_device_count(); }, "Number of visible HIP devices");
-    m.def("release_staging", [] { bsq_release_staging(); });
+    m.def("release_staging", [] {
+        // g_mu (inside the library) is held by a staged batch from bsq_stage_begin to bsq_stage_end, and that thread releases the GIL
+        // while its pieces land: taking g_mu here with the GIL held would deadlock against it.  Same order as every
+        // other entry: PackLock (GIL released while waiting), then the library call without the GIL.
+        PackLock lock;
+        py::gil_scoped_release nogil;
+        bsq_release_staging();
+    });
     // The host half of the staged path without a device (tests, sanitizer runs): scan + pack `batch` piece by piece exactly as
     // Tokenizer::staged does -- scan_pack_fast per piece, the general passes where it declines -- into ordinary memory.
     // Returns (offsets int64[n + 1], chars uint8[total], first item longer than maxlen or -1, pieces that took the fast job).
@@ -1245,6 +1326,10 @@ PYBIND11_MODULE(cbioseq, m) {
         if (n > 0) g_threads.store(int(n));
     });
     m.def("get_num_threads", [] { return py::ssize_t(default_threads()); });
+    m.def("set_host_threads", [](py::ssize_t n) { g_host_threads.store(n < 0 ? 0 : (n > 1024 ? 1024 : int(n))); }, py::arg("n"),
+          "Host threads for the scan + pack of a list batch when a call leaves nthreads at the reference's default (1): n > 0 exactly n "
+          "(1 = serial), 0 = automatic (the default; also BSQ_HOST_THREADS).  An explicit nthreads > 1 always wins.");
+    m.def("get_host_threads", [] { return py::ssize_t(host_threads_policy()); });
     py::class_<Threading>(m, "Threading")
         .def(py::init<>())
         .def(py::init<py::ssize_t>())
@@ -1255,10 +1340,10 @@ PYBIND11_MODULE(cbioseq, m) {
         .def(py::init<std::string, bool, bool, bool>(), py::arg("key"), py::arg("eos") = false,
              py::arg("bos") = false, py::arg("padchar") = false)
         .def("batch_tokenize", &Tokenizer::batch_tokenize, py::arg("batch"), py::arg("padlen") = -1,
-             py::arg("destchar") = "B", py::arg("batch_first") = false, py::arg("nthreads") = 0, py::kw_only(),
+             py::arg("destchar") = "B", py::arg("batch_first") = false, py::arg("nthreads") = 1, py::kw_only(),
              py::arg("device") = py::none())
         .def("batch_onehot_encode", &Tokenizer::batch_onehot_encode, py::arg("batch"), py::arg("padlen") = -1,
-             py::arg("destchar") = "B", py::arg("nthreads") = 0, py::arg("mask") = py::none(), py::kw_only(),
+             py::arg("destchar") = "B", py::arg("nthreads") = 1, py::arg("mask") = py::none(), py::kw_only(),
              py::arg("device") = py::none(), py::arg("layout") = "tbc")
         .def("tokenize_packed",
              [](const Tokenizer &t, const py::object &chars, const py::object &offsets, py::ssize_t padlen,

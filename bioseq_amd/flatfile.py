@@ -73,7 +73,40 @@ def write_flatfile(seqs, path):
     return path
 
 
+class FlatFileIterator:
+    """What iterating a FlatFile yields -- the reference's `cbioseq.FlatFileIterator` (fxstats.cpp:136-160, bound at :163-168):
+    an object with the read-only properties `.seq` / `.sequence` (a fresh bytearray of the sequence it stands on), itself
+    iterable; `next()` advances and hands back a snapshot of the new position."""
+    __slots__ = ("_ff", "_pos", "_stop")
+
+    def __init__(self, ff, pos=-1, stop=None):
+        if isinstance(ff, FlatFileIterator):  # the reference's copy constructor (py::init<FlatFileIterator>)
+            ff, pos, stop = ff._ff, ff._pos, ff._stop
+        self._ff, self._pos = ff, int(pos)
+        self._stop = ff.nseqs() if stop is None else int(stop)
+
+    def __iter__(self):
+        return FlatFileIterator(self)
+
+    def __next__(self):
+        self._pos += 1
+        if self._pos >= self._stop:
+            raise StopIteration("End of iterator")
+        return FlatFileIterator(self)
+
+    @property
+    def sequence(self):
+        return self._ff.access(self._pos)
+
+    seq = sequence
+
+
 class FlatFile:
+    # The reference's iterator starts ON sequence 0 and pre-increments in __next__ (fxstats.cpp:143-146): `for x in ff` there
+    # never yields sequence 0 (probed on the compiled reference: 5 sequences -> 4 items; one sequence -> none).  Here iteration
+    # yields every sequence; set this to True to reproduce the reference's off-by-one bit for bit (DESIGN section 1, difference 10).
+    ITER_SKIPS_FIRST = False
+
     def __init__(self, inputfile, maxseqlen=-1):
         """FlatFile(path_to_ff, maxseqlen=-1) opens a store; FlatFile(fastx_path, out_path) builds one first
         (`out_path == ''` -> fastx_path + '.ff'), as the reference's two constructors do."""
@@ -141,8 +174,8 @@ class FlatFile:
         return self._one(idx)
 
     def __iter__(self):
-        for i in range(self._n):
-            yield self._one(i)
+        """FlatFileIterator objects (`.seq` / `.sequence`), as the reference yields them (fxstats.cpp:177) -- not bare bytearrays."""
+        return FlatFileIterator(self, 0 if (self.ITER_SKIPS_FIRST and self._n) else -1)
 
     # ---- zero-copy batch source -------------------------------------------------------------
     def packed(self, start=0, stop=None):

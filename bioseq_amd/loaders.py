@@ -49,6 +49,10 @@ class FlatFileDataset(torch.utils.data.Dataset):
             raise TypeError("FlatFileDataset expects a FlatFile")
         self.device = torch.device("cuda" if device is None else device)
         self.ff, self.tokenizer = ff, tokenizer
+        # FlatFile(path, maxseqlen=N) takes the caller's word for N; when a stored sequence is longer than that, max_seq_len is too
+        # short for it: the reference aborts on such a sequence (tokenize.h:359-362), so batches are then validated (and raise) instead
+        # of being trusted (unvalidated kernels would clamp the sequence silently)
+        self._trusted_lengths = ff.maxseqlen >= getattr(ff, "_longest", ff.maxseqlen + 1)
         # attribute names as in the reference's class (loaders.py:36-47)
         self.max_seq_len = self.maxseqlen = ff.maxseqlen + int(tokenizer.includes_bos()) + int(tokenizer.includes_eos())
         self.augment, self.augment_frac = augment, augment_frac
@@ -77,19 +81,21 @@ class FlatFileDataset(torch.utils.data.Dataset):
         """augment_seq, then encode (bioseq/loaders.py:83-84, :102-103) on the batch's own copy.  Token rows go through the
         one-call entry `blosum.augment_tokenize_packed` (one launch for int8 rows; the entry runs the two launches for the
         other types); the one-hot form augments, then encodes."""
+        trusted = self._trusted_lengths
         if self.augment:
             self._calls += 1
             seed = self._seed + self._calls
-            if not self.cnn:
+            if not self.cnn and trusted:
                 return blosum.augment_tokenize_packed(self.tokenizer, chars, offs, self.max_seq_len, self.token_dtype, True,
                                                       chain_len=self.augment, augment_frac=self.augment_frac, seed=seed)
             blosum.augment_packed(chars, offs, self.augment, self.augment_frac, seed)
-        # validate=False: every batch cut or gathered from the store has well-formed offsets and no sequence longer than
-        # ff.maxseqlen (= max_seq_len - bos - eos) -- the device-side check would only add a synchronising read-back (~30 us) per batch
+        # validate=False only when no stored sequence is longer than ff.maxseqlen (= max_seq_len - bos - eos): every batch cut or
+        # gathered from the store then has well-formed offsets and legal lengths, and the device-side check would only add a
+        # synchronising read-back (~30 us) per batch.  A store opened with a smaller maxseqlen is validated and raises.
         if self.cnn:
-            return self.tokenizer.onehot_packed(chars, offs, self.max_seq_len, "f", layout="bcl", validate=False)
+            return self.tokenizer.onehot_packed(chars, offs, self.max_seq_len, "f", layout="bcl", validate=not trusted)
         # int64 rows written by the kernel itself ('q'), not int8 + a .to(torch.long) pass over the matrix
-        return self.tokenizer.tokenize_packed(chars, offs, self.max_seq_len, self.token_dtype, True, validate=False)
+        return self.tokenizer.tokenize_packed(chars, offs, self.max_seq_len, self.token_dtype, True, validate=not trusted)
 
     def get_batch(self, start, stop):
         """Sequences [start, stop) as one encoded batch on the device."""
@@ -136,6 +142,45 @@ class FlatFileDataset(torch.utils.data.Dataset):
             return self.__getitems__(list(range(s, e, st)))
         index = self._index(index)
         return self.get_batch(index, index + 1)[0]
+
+    def fetch(self, index, return_items=False):
+        """The reference's `fetch` (loaders.py:65-84) with its return shapes, on top of the batch encode:
+
+        cnn=True   `index` a slice / index array / list -> (B, C, max_seq_len) float32 on the device ('length batch emb ->
+                   batch emb length' + .float(), written directly); a single int -> the single-sequence one-hot
+                   `tokenizer.onehot_encode(seq, padlen=max_seq_len)` as float32, (max(L, padlen) + bos + eos, C) -- no
+                   rearrangement, as in the reference.  return_items=True -> `(tensor, items)` with the (augmented) sequences
+                   as bytearrays.  (The reference returns None here unless return_items is set -- it only `return`s inside
+                   `if return_items:`; this returns the tensor.)
+        cnn=False  `index` an int: the token row (max_seq_len,) of that sequence (`return_items` is ignored, as in the reference)."""
+        if not self.cnn:
+            return self[index]
+        single = not isinstance(index, (slice, list, tuple, np.ndarray, torch.Tensor))
+        if single:
+            i = self._index(index)
+            chars, offs = self._packed_device(i, i + 1)
+        elif isinstance(index, slice):
+            s, e, st = index.indices(len(self))
+            idx = list(range(s, e, st))
+            contiguous = st == 1 and idx
+            chars, offs = self._packed_device(s, e) if contiguous else self._packed_device(0, 0, idx)
+        else:
+            on_dev = isinstance(index, torch.Tensor) and index.is_cuda
+            chars, offs = self._packed_device(0, 0, index if on_dev else [self._index(i) for i in np.asarray(index.cpu() if isinstance(index, torch.Tensor) else index).ravel()])
+        if self.augment:
+            self._calls += 1
+            blosum.augment_packed(chars, offs, self.augment, self.augment_frac, self._seed + self._calls)
+        items = None
+        if single or return_items:
+            ho = offs.cpu().numpy()
+            hc = chars[:int(ho[-1])].cpu().numpy()
+            items = [bytearray(hc[ho[k]:ho[k + 1]].tobytes()) for k in range(len(ho) - 1)]
+        if single:
+            ret = self.tokenizer.onehot_encode(items[0], padlen=self.max_seq_len, destchar="f", device=self.device)
+            items = items[0]
+        else:
+            ret = self.tokenizer.onehot_packed(chars, offs, self.max_seq_len, "f", layout="bcl", validate=not self._trusted_lengths)
+        return (ret, items) if return_items else ret
 
     def access(self, slc, stop=None, step=None):
         """Range accessor with the reference's convention (loaders.py:105-111): an int `slc` is the START of

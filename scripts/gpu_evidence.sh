@@ -15,7 +15,7 @@
 # Every rocprofv3 command runs `python3 bench.py ...` directly (no env / bash -c hop) under its own timeout; counters are never combined
 # with a trace domain.
 set -u
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 ALL="cfg3 cfg3b cfg2 cfg2sf cfg5 cfg5aug cfg4f cfg4b cfg3bcl"
 MODE=${1:-all}; shift || true

@@ -11,6 +11,10 @@ cfg5aug: the batch is first mutated by the numpy twin of the augmentation stream
 frac 0.5, exactly what bench.py's first step does), the fold of the mutated characters is stored too, and the tokens are the
 reference's batch_tokenize of the mutated sequences.
 
+`<w>_shard8` (round 5): rank 0's share (sharding.shard_bounds: the first n/8 sequences) of a STRONG-scaling split over 8 ranks of cfg3,
+cfg4f, cfg4b and cfg5aug -- the per-GPU term of the 1/2/4/8 curve, which bench.py measures on one GPU -- encoded by the reference as
+a batch of its own (`--shards-only` adds just these to the existing file).
+
 Writes tests/golden/bench_folds.json (data only).
 """
 import importlib.util
@@ -62,7 +66,39 @@ def twin_cfg5(chars, offs, seed, chain_len=1, frac=0.5):
     return ta.twin(chars, offs, chain_len, frac, seed, normrows)
 
 
+SHARD_WORKLOADS = {"cfg3": ("cfg3", "onehot", "f"), "cfg4f": ("cfg4", "onehot", "f"), "cfg4b": ("cfg4", "onehot", "B"),
+                   "cfg5aug": ("cfg5", "augment+tokenize", "B")}
+
+
+def shards(out, world=8):
+    for w, (cname, op, destchar) in SHARD_WORKLOADS.items():
+        c = synth.CONFIGS[cname]
+        base, extra = divmod(c["n"], world)
+        n = base + (1 if extra else 0)  # sharding.shard_bounds(n, world, 0)
+        chars, offs = synth.synth_packed(c["seed"], n, c["lo"], c["hi"], c["letters"])
+        tok = cbioseq.Tokenizer(c["key"], c["eos"], c["bos"], c["padchar"])
+        name = "%s_shard%d" % (w, world)
+        if op == "onehot":
+            out[name] = fold(tok.batch_onehot_encode(synth.unpack(chars, offs), padlen=c["padlen"], destchar=destchar, nthreads=8))
+        else:
+            mut = twin_cfg5(chars, offs, seed=1)
+            out[name] = fold(tok.batch_tokenize(synth.unpack(mut, offs), padlen=c["padlen"], batch_first=True, nthreads=8))
+            out[name]["mutated_chars"] = fold(mut)
+            out[name]["mutated_sequences"] = int((np.add.reduceat((mut != chars).astype(np.int64), offs[:-1]) > 0).sum())
+        out[name]["sequences"] = n
+        out[name]["what"] = "rank 0's shard (the first %d sequences) of %s split over %d ranks, encoded by the reference as its own batch" % (n, w, world)
+        print(name, "done", flush=True)
+
+
 def main():
+    if "--shards-only" in sys.argv:
+        path = os.path.join(HERE, "bench_folds.json")
+        out = json.load(open(path))
+        shards(out)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+        print("written", path)
+        return
     out = {"definition": "fold = (xor, sum mod 2^64, sum of w_i * (2 i + 1) mod 2^64) over the little-endian uint64 words of the "
                          "array's bytes in C order, zero-padded to a multiple of 8; hex"}
 
@@ -96,6 +132,7 @@ def main():
     out["cfg5aug"]["what"] = "seed 1, chain_len 1, augment_frac 0.5: numpy twin of the augmentation stream, then the reference's batch_tokenize"
     c, chars, offs, tok = batch("cfg1")
     out["cfg1oh"] = fold(tok.batch_onehot_encode(synth.unpack(chars, offs), padlen=c["padlen"], destchar="f"))
+    shards(out)
     with open(os.path.join(HERE, "bench_folds.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("written", os.path.join(HERE, "bench_folds.json"))

@@ -14,7 +14,7 @@ def test_reads_the_reference_written_file(golden_dir):
     assert len(ff) == ff.nseqs() == ff.size() == 5 and ff.maxseqlen == ff.max_seq_len == 25
     assert ff.seq_offset() == (5 + 2) * 8
     assert ff.indptr().dtype == np.uint64 and ff.indptr().tolist() == [0, 19, 19, 44, 49, 53]
-    assert [bytes(x) for x in ff] == EXPECT
+    assert [bytes(x.seq) for x in ff] == EXPECT and [bytes(x.sequence) for x in ff] == EXPECT
     assert isinstance(ff[0], bytearray) and bytes(ff[-1]) == b"WWWW" and bytes(ff.access(3)) == b"ACGTN"
     assert [bytes(x) for x in ff.access(0, 3)] == EXPECT[:3] and [bytes(x) for x in ff[1:4]] == EXPECT[1:4]
     assert [bytes(x) for x in ff.access(0, 5, 2)] == EXPECT[::2]
@@ -38,7 +38,7 @@ def test_writer_is_byte_identical_to_the_reference(golden_dir, tmp_path):
     with open(os.path.join(golden_dir, "flatfile_small.fa"), "rb") as a, gzip.open(gz, "wb") as b:
         shutil.copyfileobj(a, b)
     ff2 = FlatFile(gz, "")
-    assert ff2.path == gz + ".ff" and [bytes(x) for x in ff2] == EXPECT
+    assert ff2.path == gz + ".ff" and [bytes(x.seq) for x in ff2] == EXPECT
 
 
 @pytest.mark.gpu
