@@ -130,11 +130,19 @@ class FlatFileDataset(torch.utils.data.Dataset):
         n = len(self)
         order = (torch.randperm(n, device=self.device, generator=generator) if shuffle
                  else torch.arange(n, device=self.device))
-        for first in range(0, n, batch_size):
-            idx = order[first:first + batch_size]
-            if drop_last and idx.numel() < batch_size:
-                return
-            yield self._encode(*self._packed_device(0, 0, idx, trusted=True)) if shuffle else self.get_batch(first, min(n, first + batch_size))
+        fused = bool(self.augment) and not self.cnn and str(self.token_dtype)[:1].lower() == "b"  # int8 rows take the one-launch entry, whose in-kernel wait can (in theory) expire
+        try:
+            for first in range(0, n, batch_size):
+                idx = order[first:first + batch_size]
+                if drop_last and idx.numel() < batch_size:
+                    return
+                batch = self._encode(*self._packed_device(0, 0, idx, trusted=True)) if shuffle else self.get_batch(first, min(n, first + batch_size))
+                if fused:
+                    blosum.check_fused()  # host memory only: the launches that have completed so far (a poisoned batch raises here or below)
+                yield batch
+        finally:
+            if fused:  # the epoch's last batches: the one synchronising check, where an epoch synchronises anyway
+                blosum.check_fused(synchronize=True)
 
     def __getitem__(self, index):
         if isinstance(index, slice):

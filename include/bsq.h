@@ -202,9 +202,11 @@ bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B,
  * The one-launch form waits INSIDE the kernel, bounded (about a second).  A token wave whose wait expires -- never observed; it would
  * take a dispatcher that starts workgroups out of order -- overwrites its 4 KiB of `out` with 0xFF bytes (no token matrix contains
  * them) and counts itself in host-visible memory.  That count is STICKY: while it is non-zero bsq_augment_tokenize_device returns
- * BSQ_ERR_FUSED_WAIT at entry, and bsq_fused_status reports it.  Callers check bsq_fused_status after synchronising the stream (the
- * Python layer does at every sync it makes and raises RuntimeError); there is no state in which wrong tokens coexist with BSQ_OK
- * from that check.
+ * BSQ_ERR_FUSED_WAIT at entry, and bsq_fused_status reports it.  Callers check bsq_fused_status after synchronising the stream; there
+ * is no state in which wrong tokens coexist with BSQ_OK from that check.  What the Python layer checks by itself: every
+ * augment_tokenize_packed call at its entry (the sticky count: an earlier launch's failure), FlatFileDataset.batches() before it
+ * yields each batch (completed launches) and, synchronised, once the epoch's last batch has been handed out -- RuntimeError in each
+ * case; any other consumer calls blosum.check_fused(synchronize=True) before it trusts a batch.
  * bsq_fused_status: *failures (nullable) <- token waves that gave up since the last clear; BSQ_OK iff 0, else BSQ_ERR_FUSED_WAIT.
  * Reads host memory only: no synchronisation, callable at any time; it covers the launches that have COMPLETED.
  * bsq_fused_status_clear: forget the count (after the caller has discarded the poisoned outputs). */

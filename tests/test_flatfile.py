@@ -132,6 +132,63 @@ def test_native_fastx_reader_equals_the_compiled_reference(oracle, tmp_path):
         FlatFile(str(tmp_path / "does_not_exist.fa"), str(tmp_path / "o.ff"))
 
 
+def test_native_fastx_reader_long_lines_and_truncated_gzip(oracle, tmp_path):
+    """Differential against the compiled reference on what a streaming parser of untrusted text gets wrong first: lines around the
+    reader's buffer sizes (16 383 / 16 384 / 16 385 / 131 072 bytes, FASTA and FASTQ, with and without a final newline) and gzip
+    streams cut off at every kind of place.  Runs under ASan / UBSan in scripts/asan_host.sh."""
+    import gzip
+    import bioseq_amd
+    from bioseq_amd.flatfile import FlatFile
+    ref = oracle.load_reference()
+    if ref is None or not hasattr(ref, "FlatFile"):
+        pytest.skip("oracle/_ref (the compiled reference) is not present")
+    rng = np.random.default_rng(16384)
+
+    def same(src, tag):
+        want = ref.getstats([src])[0]
+        got = bioseq_amd.getstats([src])[0]
+        assert got.tolist() == want.tolist(), tag
+        a, b = str(tmp_path / "ref.ff"), str(tmp_path / "mine.ff")
+        ref.FlatFile(src, a)
+        FlatFile(src, b)
+        assert open(b, "rb").read() == open(a, "rb").read(), tag
+
+    texts = []
+    for n in (16383, 16384, 16385, 32767, 32768, 131072):
+        body = bytes(rng.choice(list(b"ACGTN"), size=n).astype(np.uint8))
+        for end in (b"\n", b""):
+            texts.append(b">long " + b"c" * (n % 7) + b"\n" + body + end)                                     # one line of n bytes
+            texts.append(b">a\nAC\n>two\n" + body[: n // 2] + b"\n" + body[n // 2:] + end)                    # split over two lines
+            texts.append(b"@q\n" + body + b"\n+\n" + b"I" * n + end)                                          # FASTQ, quality as long
+            texts.append(b">" + b"h" * n + b"\n" + body[:100] + b"\n>next\nACGT" + end)                        # a HEADER of n bytes
+    for i, text in enumerate(texts):
+        src = str(tmp_path / ("l%d.fx" % i))
+        with open(src, "wb") as f:
+            f.write(text)
+        same(src, ("plain", i))
+        if i % 3 == 0:
+            with gzip.open(src + ".gz", "wb", compresslevel=1) as f:
+                f.write(text)
+            same(src + ".gz", ("gz", i))
+            os.remove(src + ".gz")
+        os.remove(src)
+    # truncated gzip members: both readers see the same prefix of records (or both fail)
+    text = b"".join(b">r%d\n" % k + bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 300))).astype(np.uint8)) + b"\n" for k in range(400))
+    whole = gzip.compress(text, compresslevel=6)
+    for j, cut in enumerate([1, 9, 10, 11, 18, 64, len(whole) // 3, len(whole) // 2, len(whole) - 9, len(whole) - 8, len(whole) - 1]):
+        src = str(tmp_path / ("t%d.fa.gz" % j))
+        with open(src, "wb") as f:
+            f.write(whole[:cut])
+        try:
+            want = ref.getstats([src])[0].tolist()
+        except RuntimeError:
+            with pytest.raises(RuntimeError):
+                bioseq_amd.getstats([src])
+            continue
+        assert bioseq_amd.getstats([src])[0].tolist() == want, ("truncated", cut)
+        os.remove(src)
+
+
 def test_native_fastx_reader_streams_a_large_fastq(tmp_path):
     """200 000 reads of 150 bases (FASTQ-shaped, BASELINE config 4's source format, gzipped): the writer keeps only the offsets
     in memory; the result round-trips through the FlatFile surface."""
