@@ -669,6 +669,23 @@ def traffic_of(workload):
     return None
 
 
+def traffic_build_id(workload):
+    """build id (bsq_build_id()) of the library the committed counters of `workload` were measured on, or None"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return (t.get(workload) or {}).get("build_id") or t.get("_build_id")
+    except Exception:
+        return None
+
+
+def traffic_stale(workload, lib):
+    """True when profiles/traffic.json's counters of this workload come from ANOTHER build of the library than the one loaded
+    (a kernel change since the last profiling pass is then invisible in `traffic`); None when there are no counters."""
+    if traffic_of(workload) is None:
+        return None
+    return traffic_build_id(workload) != lib.bsq_build_id().decode()
+
+
 def run_config(name, lib, dev, stream, steps, warmup):
     """One of the OTHER BASELINE workloads inside the default run (N = 1): check, K-step loop, >= 0.25 s sustained, cold regime."""
     import torch
@@ -688,6 +705,7 @@ def run_config(name, lib, dev, stream, steps, warmup):
     res["gseq_chars_per_s"] = b.total / (loop_ms * 1e-3) / 1e9
     res["gb_per_s_written"] = b.out_bytes / (loop_ms * 1e-3) / 1e9
     res["traffic"] = traffic_of(name)
+    res["traffic_stale"] = traffic_stale(name, lib)
     if b.op in ("tokenize", "augment+tokenize"):
         # The token workloads' working sets (35 + 64 MiB, 71 + 128 MiB) fit the 256-MiB Infinity Cache, and a training loop never
         # encodes one batch twice: their PRIMARY figures are the cold regime's; the loop over one resident
@@ -1010,7 +1028,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "frac_wall": algo_bytes / (wall_max / args.steps) / 1e9 / HBM_PEAK_GBPS,  # from ms_per_step (host clock)
-                         "traffic": traffic, "kernel": kernel_name,
+                         "traffic": traffic, "traffic_stale": traffic_stale(args.workload, lib), "kernel": kernel_name,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_avg_ms": loop_ms,                    # the K timed steps between ONE pair of events, / K
                          "kernel_avg_ms_per_step_events": kern_avg_ms,  # second, untimed pass: one event pair per step
@@ -1025,6 +1043,7 @@ def main():
                          "frac_of_copy_mix": (achieved / mix_gbps) if mix_gbps else None},
         }
         res["check"] = check
+        res["build_id"] = lib.bsq_build_id().decode()  # of the loaded libbsq_hip.so (profiles/traffic.json records the one it was measured on)
         # which step() calls of this process were the K timed ones (the rocprofv3 summaries under profiles/ keep exactly those dispatches)
         res["timed"] = {"first_step_index": first_timed_step, "steps": args.steps, "step_calls_total": step_calls_main}
         if sustained is not None:

@@ -55,21 +55,32 @@ def build_lib(force=False):
     stamp = os.path.join(objdir, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(extra):
         force = True
+    # build id (bsq_build_id(), include/bsq_diag.h): sources + headers + flags; compiled into bsq_alphabet.cpp only
+    import hashlib
+    h = hashlib.sha256(" ".join(extra).encode())
+    for path in [os.path.join(CSRC, f) for f in LIB_SRCS] + headers:
+        h.update(os.path.basename(path).encode() + b"\0" + open(path, "rb").read())
+    build_id = h.hexdigest()[:16]
+    id_stamp = os.path.join(objdir, "build_id.txt")
+    id_changed = not os.path.exists(id_stamp) or open(id_stamp).read() != build_id
     jobs, objs = [], []
     for f in LIB_SRCS:
         src, obj = os.path.join(CSRC, f), os.path.join(objdir, f + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + headers):
+        if force or _newer(obj, [src] + headers) or (f == "bsq_alphabet.cpp" and id_changed):
             # gfx950 hands the first 14 kernel-argument dwords to a wave in SGPRs (no s_load round trip before its first
             # vector load): the fast token kernel's signature is laid out for it (bsq_tokens8.hip)
             lang = ["-x", "hip", "-mllvm", "-amdgpu-kernarg-preload-count=14"] if f.endswith(".hip") else []
             jobs.append([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-pthread",
-                         "-I" + INCLUDE, "-I" + CSRC] + extra + lang + ["-c", src, "-o", obj])
+                         "-I" + INCLUDE, "-I" + CSRC] + extra + lang + (['-DBSQ_BUILD_ID="%s"' % build_id] if f == "bsq_alphabet.cpp" else []) +
+                        ["-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("BSQ_BUILD_JOBS", "4")))) as ex:
             list(ex.map(_run, jobs))
         with open(stamp, "w") as fh:
             fh.write(" ".join(extra))
+        with open(id_stamp, "w") as fh:
+            fh.write(build_id)
     if jobs or not os.path.exists(LIB):
         _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-lz"])
     return LIB

@@ -49,6 +49,7 @@ def load():
     i64p = ctypes.POINTER(i64)
     sig = {
         "bsq_abi_version": (i32, []),
+        "bsq_build_id": (ctypes.c_char_p, []),
         "bsq_strerror": (ctypes.c_char_p, [i32]),
         "bsq_last_error": (ctypes.c_char_p, []),
         "bsq_device_count": (i32, []),

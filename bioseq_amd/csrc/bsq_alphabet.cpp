@@ -10,6 +10,7 @@
 // are therefore built from the comma groups alone; tests/test_oracle_golden.py and tests/test_host_surface.py pin
 // all 20 keys against tests/golden/alphabets.json (LUTs dumped from the compiled reference).
 #include "bsq.h"
+#include "bsq_diag.h"
 
 #include <cctype>
 #include <cstring>
@@ -83,6 +84,10 @@ int fill_table(const Spec &s, int8_t lut[256]) {
 extern "C" {
 
 int32_t bsq_abi_version(void) { return BSQ_ABI_VERSION; }
+#ifndef BSQ_BUILD_ID
+#define BSQ_BUILD_ID "unstamped"
+#endif
+const char *bsq_build_id(void) { return BSQ_BUILD_ID; }
 
 const char *bsq_strerror(bsq_status s) {
     switch (s) {

@@ -13,6 +13,11 @@
 extern "C" {
 #endif
 
+/* Build id of this library: the first 16 hex digits of sha256 over every source and header of csrc/ + include/ and the compiler
+ * flags, computed by bioseq_amd/build.py and compiled in.  profiles/traffic.json records the id its counters were measured on;
+ * bench.py prints `traffic_stale: true` when the loaded library's differs (the traffic figure in the line is then an old build's). */
+const char *bsq_build_id(void);
+
 /* Tuning knobs (kernel variants for A/B measurements; results never change).  Names and meaning:
  * bioseq_amd/csrc/bsq_internal.h.  Environment variables BSQ_<NAME> give the initial values. */
 bsq_status bsq_tuning_set(const char *name, int32_t value);

@@ -13,7 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 traffic = {"_note": "HBM bytes per step from separate rocprofv3 --pmc passes (WRITE_SIZE, FETCH_SIZE; units KB), summed over the "
@@ -67,6 +67,10 @@ for w in ("cfg3", "cfg3b", "cfg2", "cfg2sf", "cfg5", "cfg5aug", "cfg4f", "cfg4b"
     if wr:
         entry["hbm_bytes_per_launch"] = int((wr + 2 * fe) * 1024)
         entry["hbm_bytes_per_launch_fetch_undoubled"] = int((wr + fe) * 1024)
+    try:  # the build the counters were measured on (bench.py prints bsq_build_id(); it flags `traffic_stale` when the loaded library differs)
+        entry["build_id"] = json.loads(open(bt).read().strip().splitlines()[-1]).get("build_id")
+    except Exception:
+        entry["build_id"] = None
     rc = s.get("roofline_check")
     if rc:
         entry["algorithmic_bytes_per_launch"] = rc["algorithmic_bytes_per_launch"]
