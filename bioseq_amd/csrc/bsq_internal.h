@@ -59,6 +59,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //                         its lookup follows tokens8_lookup
 //   augment_fused         1: bsq_augment_tokenize_device never fuses its two launches
 //   expand_gate           k_expand_chunks: one pacing load in front of every wave (0 automatic: rows of 24 ... 63 bytes; 1 never; 2 always)
+//   expand_rows1          the LDS-free expansion k_expand_rows1 (one-byte elements, rows of 3 ... 15 bytes): 0 automatic, 1 never, 2 whenever it applies
 //   gather_small          bsq_gather_packed_device for n <= 4096: 0 one launch (k_gather_small), 1 the three launches of larger lists
 //   host_pieces           list / host batch -> seq-first one-hot on the device: upload + encode in pieces (0 automatic: 4 pieces when the
 //                         stream is idle and the batch large; 1 never; 2 ... 8 that many) -- bsq_host.cpp, piece_sequences()
@@ -74,7 +75,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
     X(nt_stores, 1) X(onehot_tb, 0) X(tile_order, 0) X(fill_mode, 0) X(onehot_path, 0) X(expand_pad, 0) X(tokenize_path, 0)   \
     X(fill_pad, 0) X(chunks_pad, 0) X(host_copy_threads, 0) X(tokenize_pad, 0) X(expand_slots, 0) X(tile_group, 0)             \
     X(bcl_path, 0) X(bcl_pad, 0) X(raw_mode, 0) X(workspace_cache, 0) X(tokens8, 0) X(tokens8_fast, 0) X(tokens8_lookup, 0)    \
-    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0) X(expand_gate, 0) X(host_pieces, 0) X(gather_small, 0)                                               \
+    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0) X(expand_gate, 0) X(host_pieces, 0) X(gather_small, 0) X(expand_rows1, 0)                                               \
     L(chunks_cpw, 0) L(tokenize_nch, 0) L(expand_mode, 0) L(xcd_claim, 0) L(chunk_math, 0) L(tokens8_abl, 0) L(augment_mode, 0)
 struct Tuning {
 #define BSQ_KNOB_FIELD(name, def) int32_t name = def;

@@ -734,6 +734,119 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     }
 }
 
+// k_expand_rows1 (round 5): the same chunk stream for ONE-BYTE elements with rows of 3 ... 15 bytes (int8 one-hots of DNA-sized
+// alphabets: BASELINE config 4's default dtype, 7-byte rows) WITHOUT the LDS image.  k_expand_chunks scatters one byte per row into
+// its image: 585 rows per chunk at 7 bytes = ten byte loads and ten ds_write_b8 per lane, more than half of its LDS cycles bank
+// conflicts (profiles/r04/cfg4b_sq_tcc_counters.txt), 4.4 TB/s.  Here a lane BUILDS its 16 output bytes in registers: they cover
+// at most NR = (rb + 14) / rb + 1 consecutive rows, whose ids come as one unaligned 8-byte load from the (P,B) id matrix; row j's
+// one-hot is the rb-bit string 1 << id (255 = no one: bit 31, masked off); the rows' strings concatenated, shifted right by the
+// lane's phase inside its first row, are the lane's 16 bytes as 16 BITS, and a nibble becomes four 0 / 1 bytes by one 24-bit
+// multiply: ((n * 0x204081) & 0x01010101).  ~35 vector instructions per 16 bytes, no LDS, no barrier; one wave = one aligned 4-KiB
+// chunk, class = blockIdx % 8, exactly as above.  Chunks that are clipped (first / last of the tensor), misaligned, or that run
+// over the end of a position row of a padded id matrix (Bp != B) take the byte loop at the end -- a few hundred chunks of a million.
+template <bool NT, int NR>
+__global__ __launch_bounds__(kThreads) void k_expand_rows1(const EParams p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int64_t slot = static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s;
+    const int64_t k = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot;
+    if (k >= p.nchunks) return;
+    const int32_t rb = p.C;  // bytes per row (one-byte elements)
+    const ChunkCoord cc = chunk_coord<0>(p, k, rb);
+    if (!cc.live) return;
+    const int32_t len = cc.len, skip = cc.skip;
+    const int32_t nr_s = __builtin_amdgcn_readfirstlane(cc.nr);
+    const uint8_t *tok = p.tok + cc.t_lo * p.Bp + cc.b_lo;
+    const int64_t wrap_at = p.B - cc.b_lo;  // rows i >= wrap_at belong to position t_lo + 1 (or later)
+    const bool wraps = p.Bp != p.B && wrap_at < nr_s;  // (wave-uniform) the chunk runs over the end of a position row of a PADDED id matrix
+    uint8_t *g = p.out + cc.lo + cc.t_lo * p.row_gap;
+    const uint32_t one = static_cast<uint32_t>(p.one_bits) & 0xFFu;
+    // address of the id of row i of the chunk (rows behind wrap_at lie in later position rows of the matrix, Bp - B bytes further each)
+    auto id_at = [&](uint32_t i) -> int64_t {
+        int64_t at = i;
+        if (static_cast<int64_t>(i) >= wrap_at) at += ((static_cast<int64_t>(i) - wrap_at) / p.B + 1) * (p.Bp - p.B);
+        return at;
+    };
+    if (len == kChunk && (reinterpret_cast<uintptr_t>(g) & 15) == 0 && nr_s >= 8) {
+        uint64_t ids[4];
+        uint32_t ph[4];
+        if (!wraps) {
+            typedef uint32_t u32x2u __attribute__((ext_vector_type(2), aligned(1)));
+            u32x2u w[4];
+            uint32_t sh[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // the four id windows of the lane in flight together
+                const uint32_t o = static_cast<uint32_t>(skip) + static_cast<uint32_t>(u * 1024 + lane * 16);
+                const uint32_t q = fast_div(o, p.rb_magic, p.rb_shift, p.rb_pow2);
+                ph[u] = o - q * static_cast<uint32_t>(rb);
+                // the last lanes' windows are pulled back to END at the chunk's last row: never a byte beyond the ids this chunk owns
+                const uint32_t off = q + 8u <= static_cast<uint32_t>(nr_s) ? q : static_cast<uint32_t>(nr_s) - 8u;
+                sh[u] = (q - off) * 8u;
+                w[u] = *reinterpret_cast<const u32x2u *>(tok + off);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ids[u] = ((static_cast<uint64_t>(w[u].y) << 32) | w[u].x) >> sh[u];
+        } else {  // one chunk per position row: the NR ids of a window one by one, across the padding (all 4 NR byte loads in flight together)
+            uint32_t b[4][NR];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t o = static_cast<uint32_t>(skip) + static_cast<uint32_t>(u * 1024 + lane * 16);
+                const uint32_t q = fast_div(o, p.rb_magic, p.rb_shift, p.rb_pow2);
+                ph[u] = o - q * static_cast<uint32_t>(rb);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) b[u][j] = q + j < static_cast<uint32_t>(nr_s) ? static_cast<uint32_t>(tok[id_at(q + j)]) : kNone;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ids[u] = 0;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) ids[u] |= static_cast<uint64_t>(b[u][j]) << (8 * j);
+            }
+        }
+        const uint32_t cmask = (1u << rb) - 1u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const uint32_t id = static_cast<uint32_t>(ids[u] >> (8 * j)) & 0xFFu;
+                const uint32_t m = (1u << (id & 31u)) & cmask;  // id 255 (no one) -> bit 31 -> 0
+                const int32_t at = j * rb;                      // wave-uniform; strings that start at bit >= 32 lie beyond the lane's bits
+                if (at < 32) bits |= m << at;
+            }
+            bits >>= ph[u];
+            uint4 o;
+            o.x = (((bits >> 0) & 15u) * 0x204081u) & 0x01010101u;
+            o.y = (((bits >> 4) & 15u) * 0x204081u) & 0x01010101u;
+            o.z = (((bits >> 8) & 15u) * 0x204081u) & 0x01010101u;
+            o.w = (((bits >> 12) & 15u) * 0x204081u) & 0x01010101u;
+            if (one != 1u) {
+                o.x *= one;
+                o.y *= one;
+                o.z *= one;
+                o.w *= one;
+            }
+            store16<NT>(g + u * 1024 + lane * 16, o);
+        }
+        return;
+    }
+    // the clipped first / last chunk of the tensor, a result that is not 16-byte aligned: byte by byte, eight independent ids at a time
+    for (int32_t o0 = lane; o0 < len; o0 += 64 * 8) {
+        uint32_t idv[8], cv[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int32_t o = o0 + 64 * m;
+            const uint32_t a = static_cast<uint32_t>(o + skip);
+            const uint32_t i = fast_div(a, p.rb_magic, p.rb_shift, p.rb_pow2);
+            cv[m] = a - i * static_cast<uint32_t>(rb);
+            idv[m] = o < len ? static_cast<uint32_t>(tok[id_at(i)]) : kNone;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            if (o0 + 64 * m < len) g[o0 + 64 * m] = idv[m] == cv[m] ? static_cast<uint8_t>(one) : uint8_t(0);
+    }
+}
+
 #ifdef BSQ_LABS  // an experiment that lost (knob expand_mode 2 / 9); not in the product binary
 // The same expansion for SMALL rows (a chunk holds hundreds of rows: 7-byte rows of int8 DNA, 28-byte rows of f32
 // DNA): a lane takes FOUR consecutive rows from one unaligned dword of tokens, every token dword of the wave's
@@ -2030,6 +2143,27 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
         return check_launch("k_expand_chunks<div64>");
     }
 #endif
+    // one-byte elements, rows of 3 ... 15 bytes: the LDS-free form (knob "expand_rows1": 0 automatic, 1 never, 2 whenever it applies)
+    if constexpr (sizeof(ST) == 1) {
+        const int rk = bsq_internal::tuning().expand_rows1;
+        const int rb = e.C;
+        if (rk != 1 && rb >= 3 && rb <= 15) {
+            const int nrows = (rb + 14) / rb + 1;  // rows a lane's 16 bytes can touch: 6, 5, 4, 4, 4, 3 ... 3, 2
+            const size_t rpad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : size_t(32768));  // (no static LDS here: 5 workgroups per CU)
+            const bool nt = bsq_internal::nontemporal_stores();
+#define BSQ_ROWS1(NRV)                                                                                       \
+    case NRV:                                                                                                \
+        if (nt) hipLaunchKernelGGL((k_expand_rows1<true, NRV>), grid, dim3(kThreads), rpad, s, e);           \
+        else hipLaunchKernelGGL((k_expand_rows1<false, NRV>), grid, dim3(kThreads), rpad, s, e);             \
+        break;
+            switch (nrows) {
+                BSQ_ROWS1(2) BSQ_ROWS1(3) BSQ_ROWS1(4) BSQ_ROWS1(5) BSQ_ROWS1(6)
+            default: return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "k_expand_rows1: rows per lane");
+            }
+#undef BSQ_ROWS1
+            return check_launch("k_expand_rows1");
+        }
+    }
     // knob "expand_gate": 0 automatic (rows of 24 ... 63 bytes), 1 never, 2 always (the scratch holds at least 256 bytes: Bp >= 256)
     const int gk = bsq_internal::tuning().expand_gate;
     const int64_t rowb = e.C * int64_t(sizeof(ST));
@@ -2260,9 +2394,12 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool m
         // 1.3 GB and behind below: profiles/r02/sweep_shapes_final.txt)
         if ((owner_big || owner_small) && total < (int64_t(3) << 29))
             path = 3;
-        else if ((rowbytes >= 16 && total >= (int64_t(192) << 20)) || ((pitch % 64 != 0 || misaligned_out) && total >= (int64_t(32) << 20)))
+        else if ((rowbytes >= (sz == 1 ? 8 : 16) && total >= (int64_t(192) << 20)) || ((pitch % 64 != 0 || misaligned_out) && total >= (int64_t(32) << 20)))
             path = 2;  // (second case: position rows that are not 64-byte aligned -- the tiles would share memory sectors or
-                       // fall to element stores: 250001 x 256 int8 DNA 187 -> 120 us, profiles/r02/path_unaligned.txt)
+                       // fall to element stores: 250001 x 256 int8 DNA 187 -> 120 us, profiles/r02/path_unaligned.txt; round 5: -> 94 us.
+                       // Round 5: one-byte rows of 8 ... 15 bytes too -- their expansion is k_expand_rows1: SEB14 131072 x 512 int8
+                       // 187 -> 156 us, SEB8 + BOS / EOS / PAD (11-byte rows) 281 -> 248 us; rows of 3 ... 7 bytes stay tiled unless
+                       // misaligned: cfg4 int8 225 us tiled, 240 two-pass -- profiles/r05/rows1_lab.txt)
         else
             path = 1;
     }
@@ -2279,10 +2416,11 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
         const int mode = bsq_internal::tuning().expand_mode;
         if (rb >= 4 && (mode == 2 || mode == 9)) return "k_tokens_raw+k_expand_small";
 #endif
-        (void)rb;
         // (unmasked: the raw-id pass runs in k_tokens_pb8_fast unless a knob keeps it in k_tokens_raw -- see launch_tokens_raw)
-        if (bsq_internal::tuning().raw_mode == 0 && bsq_internal::tuning().tokens_pb8 != 1) return "k_tokens_pb8_fast<raw>+k_expand_chunks";
-        return "k_tokens_raw+k_expand_chunks";
+        const bool rows1 = bsq_dtype_size(t) == 1 && rb >= 3 && rb <= 15 && bsq_internal::tuning().expand_rows1 != 1;
+        if (bsq_internal::tuning().raw_mode == 0 && bsq_internal::tuning().tokens_pb8 != 1)
+            return rows1 ? "k_tokens_pb8_fast<raw>+k_expand_rows1" : "k_tokens_pb8_fast<raw>+k_expand_chunks";
+        return rows1 ? "k_tokens_raw+k_expand_rows1" : "k_tokens_raw+k_expand_chunks";
     }
     case 3: return "k_onehot_chunks";
     default: return "k_onehot_generic";
@@ -2299,7 +2437,9 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     const size_t sz = bsq_dtype_size(t);
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
     // Limits of the LDS kernels: 8-bit token ids, 32-bit tile arithmetic, row images must fit in LDS.
-    const int path = choose_onehot_path(k.C, sz, B, P, reinterpret_cast<uintptr_t>(out) % 16 != 0);
+    // (a result that does not start on a 64-byte boundary -- a view into a larger tensor -- counts as misaligned: the tiled kernel's
+    //  row segments then straddle memory sectors, cfg4 int8 16 bytes off: 225 -> 330 us tiled, 242 us two-pass)
+    const int path = choose_onehot_path(k.C, sz, B, P, reinterpret_cast<uintptr_t>(out) % 64 != 0);
     if (path == 0) return bsq_onehot_device_generic(d, chars, offsets, mask_or_null, B, P, t, out, hip_stream);
     k.one_bits = one_bits_of(t);
     const int64_t pitch = B * k.C * int64_t(sz);
