@@ -48,7 +48,7 @@ def build_lib(force=False):
     # every header of csrc/ and include/ is a dependency of every object (a handful of files: an exact depfile graph would
     # save nothing, and a header missing from a hand-kept list once left two kernels disagreeing about a table layout)
     import glob
-    headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h")))
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "labs", "*.inc")) + glob.glob(os.path.join(INCLUDE, "*.h")))
     extra = os.environ.get("BSQ_EXTRA_HIPCC_FLAGS", "").split()
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)

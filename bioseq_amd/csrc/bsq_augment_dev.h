@@ -53,16 +53,18 @@ constexpr int kSeqPerWave = 64;
 // (virtual block `vblock` = 256 consecutive sequences; all 256 threads of a workgroup call it together: it holds a __syncthreads)
 // COHERENT (the fused launch of bsq_tokens8.hip): the mutated characters are stored at AGENT scope -- written through to where the
 // other XCDs' loads find them -- because waves of the SAME launch read them next.
-template <int K, bool COHERENT = false>
+// MAPPED (round 5, the same-XCD form of the fused launch): the lane's sequence is `b_mapped` (>= B: none) instead of the vblock's
+// 256 consecutive ones -- the stream is keyed by (seed, sequence), so WHICH lane mutates a sequence never changes a result.
+template <int K, bool COHERENT = false, bool MAPPED = false>
 __device__ __forceinline__ void augment_groups_body(uint32_t vblock, uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len,
-                                                    double frac, uint64_t seed, const AugTable *tab) {
+                                                    double frac, uint64_t seed, const AugTable *tab, int64_t b_mapped = 0) {
     __shared__ __align__(16) AugTable s_tab;
     __shared__ int64_t s_start[4][kSeqPerWave], s_len[4][kSeqPerWave];
     __shared__ uint64_t s_h0[4][kSeqPerWave];
     __shared__ uint32_t s_ctr[4][kSeqPerWave];
     __shared__ int32_t s_rem[4][kSeqPerWave], s_tries[4][kSeqPerWave];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t b = (static_cast<int64_t>(vblock) * 4 + wave) * kSeqPerWave + lane;
+    const int64_t b = MAPPED ? b_mapped : (static_cast<int64_t>(vblock) * 4 + wave) * kSeqPerWave + lane;
     // the spans first: their loads are in flight while the table is staged (round 3: the kernel is latency-bound --
     // 59 % of its wave cycles are waits, profiles/r03/augment_groups_pmc.txt -- and this was one dependent round trip more)
     int64_t start = 0, L = 0;

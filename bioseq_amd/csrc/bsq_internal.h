@@ -13,7 +13,7 @@ bsq_status set_error(bsq_status st, const char *msg);
 bsq_status set_hip_error(const char *what, hipError_t e);
 // Tuning / diagnostic knobs (bsq_tuning_set, or environment BSQ_<NAME> read once, at the first launch):
 // (speed only -- in the product build results never depend on them; every variant is covered by the GPU parity tests.
-//  LABS = exists only with -DBSQ_LABS: chunks_cpw, tokenize_nch, expand_mode, xcd_claim, chunk_math, tokens8_abl, augment_mode
+//  LABS = exists only with -DBSQ_LABS: chunks_cpw, tokenize_nch, expand_mode, xcd_claim, chunk_math, tokens8_abl, tokens8_ring, augment_mode
 //  (1: the round-1 one-lane-per-sequence k_augment), and the
 //  values 2 / 3 of raw_mode)
 //   nt_stores     1: `global_store ... nt` for the output streams (default 1)
@@ -57,9 +57,11 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokens_pb8            1: never use k_tokens_pb8_fast for the (P,B) token matrices (k_tokens_raw / k_tokenize_tile instead), 2: also
 //                         for 4-byte elements (automatic: 1-, 2- and 8-byte elements), 3: only when rows and output are 16-byte aligned;
 //                         its lookup follows tokens8_lookup
-//   augment_fused         1: bsq_augment_tokenize_device never fuses its two launches
+//   augment_fused         1: bsq_augment_tokenize_device never fuses its two launches; 2: fuses, but never in the same-XCD form (round 5), 3: the same-XCD form whenever it applies (automatic: <= 6144 chunks)
 //   expand_gate           k_expand_chunks: one pacing load in front of every wave (0 automatic: rows of 24 ... 63 bytes; 1 never; 2 always)
 //   expand_rows1          the LDS-free expansion k_expand_rows1 (one-byte elements, rows of 3 ... 15 bytes): 0 automatic, 1 never, 2 whenever it applies
+//   tokens8_ring          LABS: N > 0: the (B,P) int8 token matrix through k_tokens_bp8_pipe (every wave walks N chunks with its offsets and
+//                         characters arriving by LDS-DMA two / four chunks ahead) instead of k_tokens_bp8_fast; lost, profiles/r05/tokens8_pipeline_lost.txt
 //   gather_small          bsq_gather_packed_device for n <= 4096: 0 one launch (k_gather_small), 1 the three launches of larger lists
 //   host_pieces           list / host batch -> seq-first one-hot on the device: upload + encode in pieces (0 automatic: 4 pieces when the
 //                         stream is idle and the batch large; 1 never; 2 ... 8 that many) -- bsq_host.cpp, piece_sequences()
@@ -76,7 +78,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
     X(fill_pad, 0) X(chunks_pad, 0) X(host_copy_threads, 0) X(tokenize_pad, 0) X(expand_slots, 0) X(tile_group, 0)             \
     X(bcl_path, 0) X(bcl_pad, 0) X(raw_mode, 0) X(workspace_cache, 0) X(tokens8, 0) X(tokens8_fast, 0) X(tokens8_lookup, 0)    \
     X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0) X(expand_gate, 0) X(host_pieces, 0) X(gather_small, 0) X(expand_rows1, 0)                                               \
-    L(chunks_cpw, 0) L(tokenize_nch, 0) L(expand_mode, 0) L(xcd_claim, 0) L(chunk_math, 0) L(tokens8_abl, 0) L(augment_mode, 0)
+    L(chunks_cpw, 0) L(tokenize_nch, 0) L(expand_mode, 0) L(xcd_claim, 0) L(chunk_math, 0) L(tokens8_abl, 0) L(augment_mode, 0) L(tokens8_ring, 0)
 struct Tuning {
 #define BSQ_KNOB_FIELD(name, def) int32_t name = def;
     BSQ_KNOB_LIST(BSQ_KNOB_FIELD, BSQ_KNOB_FIELD)

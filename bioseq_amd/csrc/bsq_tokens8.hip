@@ -26,6 +26,7 @@
 #include "bsq.h"
 #include "bsq_augment_dev.h"
 #include "bsq_device.h"
+#include "bsq_diag.h"
 #include "bsq_internal.h"
 
 namespace {
@@ -91,6 +92,10 @@ __device__ __forceinline__ uint32_t nonletter_mask(uint32_t cw) {
     const uint32_t f = ((x >> 6) | (x >> 7)) & 0x01010101u;
     return (f << 8) - f;  // f * 0xFF
 }
+
+__device__ __forceinline__ uint32_t keep_word(const uint4 &k, int q) { return q == 0 ? k.x : (q == 1 ? k.y : (q == 2 ? k.z : k.w)); }
+typedef __attribute__((address_space(3))) void bsq_lds_void;
+typedef __attribute__((address_space(1))) const void bsq_glb_cvoid;
 
 // ABL (diagnostic instantiations only): 0 the kernel; 1 no alphabet lookup (characters stored as they are);
 // 2 no character loads; 3 no offsets loads either (synthetic sequence spans); 4 stores only; 5 character loads at
@@ -396,11 +401,12 @@ struct FusedWait {            // what a token wave of the fused launch needs fro
     uint32_t *failures;       // host-mapped, sticky: token waves that gave up waiting (their chunk is poisoned; the API reports it)
     uint32_t epoch;
     uint32_t spins, naps;     // polls before a wave gives up; s_sleep(2) per poll
+    uint32_t chunks_per_aug_wave;  // same-XCD form (FLAGS == 2): an augmentation wave mutates the rows of this many chunks of ITS class
 };
 // EOSV: the token at position bos + L (EOS) differs from the fill behind it.  Without it (cfg2, cfg5: no EOS) a store is
 // bfi(keep, tokens, fill) -- no constant half of the rule entry: 16 registers and four LDS reads less per lane, 66 -> <= 64 VGPRs =
 // EIGHT waves per SIMD instead of seven, which is what the cold-input regime (every character from HBM) is short of.
-template <bool NT, bool FLAGS, bool EOSV = true>
+template <bool NT, int FLAGS, bool EOSV = true>
 __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                  uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR, uint32_t magic,
                                                  uint32_t shift, int32_t room, uint32_t packed, const T8Tab &tab, const T8Rules &rules,
@@ -410,7 +416,7 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
     const uint32_t wave_s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(wave));
     const uint32_t k0 = (vblock & 7u) + 8u * ((vblock >> 3) * 4u + wave_s);  // class = block % 8 (XCD-pinned)
     if (k0 >= nchunks) return;
-    if constexpr (FLAGS) {
+    if constexpr (FLAGS != 0) {
         // The rows of this chunk: bc .. bc + nr (nr <= 32).  Their sequences were augmented by the waves (row / 64) of the
         // augmentation blocks, which are dispatched BEFORE every token block (lower block indices: the dispatcher hands blocks out
         // in order, as the decoupled look-back scans of rocPRIM rely on) and never wait for anything.  Protocol (hand-rolled release /
@@ -427,15 +433,29 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
         const uint32_t tcf = g0f - bcf * PPR;
         const uint32_t nrf = __umulhi(tcf + (kChunk / 16 - 1), magic) >> shift;
         const uint32_t lastrow = bcf + nrf < B ? bcf + nrf : B - 1;
-        const uint32_t f0 = bcf / 64u, f1 = lastrow / 64u;  // f1 - f0 <= 1
+        uint32_t f0 = bcf / 64u, f1 = lastrow / 64u;  // f1 - f0 <= 1
+        uint32_t want = (fw.epoch << 4) | 15u;  // (15: published with written-through stores, valid on every XCD)
+        if constexpr (FLAGS == 2) {
+            // Same-XCD form (round 5): the rows of this chunk -- whole rows, 4096 / padlen of them -- were mutated by ONE augmentation
+            // wave of this chunk's own class (= this XCD under round-robin placement): plain stores into the L2 this wave's loads go
+            // through, no write-through, no second fetch from the memory side.  The flag carries the XCD the augmentation wave ran
+            // on; on any other XCD the data is not visible here, so a mismatch fails LOUDLY (poison + count) like an expired wait.
+            const uint32_t m = (k0 >> 3) / fw.chunks_per_aug_wave;               // augmentation wave of class k0 % 8
+            f0 = f1 = (((m >> 2) * 8u + (k0 & 7u)) << 2) + (m & 3u);             // block (m / 4) * 8 + class, wave m % 4
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            want = (fw.epoch << 4) | (xcc & 15u);
+        }
         bool ok = true;
         if (static_cast<uint32_t>(lane) <= f1 - f0) {
             ok = false;
             for (uint32_t spin = 0; spin < fw.spins; ++spin) {  // (default 2^18 polls: ~1 s)
-                if (__hip_atomic_load(fw.flags + f0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fw.epoch) {
+                const uint32_t seen = __hip_atomic_load(fw.flags + f0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen == want) {
                     ok = true;
                     break;
                 }
+                if (FLAGS == 2 && (seen >> 4) == (want >> 4)) break;  // published from ANOTHER XCD: not ok, no point in waiting
                 // ~3.5 us between polls: 8192 resident chunk waves polling every ~60 ns slowed the augmentation's own memory
                 // operations down (cfg5aug 45.2 us; 60 naps: 42.8-43.1; one long nap, then short ones: 44-45 -- profiles/r03/augment_fused_flags_ab.txt)
                 for (uint32_t z = 0; z < fw.naps; ++z) __builtin_amdgcn_s_sleep(2);
@@ -522,7 +542,7 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
     u32x4u cw[4];
     if (can_vec) {
         const uint8_t *cbase = chars + (off0 + lo_b);  // wave-uniform, inside the buffer
-        if constexpr (FLAGS) {
+        if constexpr (FLAGS != 0) {
             // agent-scope loads (sc1: not served from this XCD's L2 or the CU's L1, where a line may predate the mutation of a
             // NEIGHBOURING sequence group).  One asm block with its own wait: the compiler must not touch the registers in between.
             asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -560,7 +580,7 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i)
                     if (j0[u] + i >= 0 && j0[u] + i < L[u])
-                        w[i >> 2] |= static_cast<uint32_t>(FLAGS ? __hip_atomic_load(chars + start + j0[u] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        w[i >> 2] |= static_cast<uint32_t>(FLAGS != 0 ? __hip_atomic_load(chars + start + j0[u] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                                  : chars[start + j0[u] + i]) << (8 * (i & 3));
                 cw[u] = u32x4u{w[0], w[1], w[2], w[3]};
             }
@@ -569,7 +589,7 @@ __device__ __forceinline__ void tokens_fast_body(uint32_t vblock, const int64_t 
     uint8_t *dst = out + static_cast<int64_t>(k0) * kChunk + lane * 16;
     // VT: the alphabet table and the selector constant in VECTOR registers (lookup4_perm_v: 12 instead of 18 vector instructions per
     // word) -- where the no-EOS form has the registers to spare
-    constexpr bool VT = !EOSV && !FLAGS;
+    constexpr bool VT = !EOSV && FLAGS == 0;
     uint32_t Tv[8], k3210 = 0x03020100u;
     if constexpr (VT) {
 #pragma unroll
@@ -615,8 +635,12 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
                                                               uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
                                                               uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
                                                               T8Tab tab, T8Rules rules) {
-    tokens_fast_body<NT, false, EOSV>(blockIdx.x, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, FusedWait{});
+    tokens_fast_body<NT, 0, EOSV>(blockIdx.x, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, FusedWait{});
 }
+
+#ifdef BSQ_LABS
+#include "labs/bsq_tokens8_pipe.inc"  // k_tokens_bp8_pipe: the per-wave LDS-DMA pipeline (round 5; lost: profiles/r05/tokens8_pipeline_lost.txt)
+#endif
 
 // BASELINE config 5 as ONE launch (round 3): BLOSUM62 augmentation (bsq_augment.hip) and the (B,P) int8 token matrix.  The first
 // `aug_blocks` workgroups (a multiple of 8, so that the token role's chunk classes stay pinned to their XCDs) are k_augment_groups
@@ -639,21 +663,38 @@ struct FusedAug {
     uint32_t *flags;          // aug_blocks * 4 words (one per augmentation wave)
     FusedWait wait;
 };
-template <bool NT, int K>
+template <bool NT, int K, bool SAMEXCD = false>
 __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t *__restrict__ offsets, const uint8_t *chars,
                                                                    uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
                                                                    uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
                                                                    T8Tab tab, T8Rules rules, FusedAug fa) {
     if (blockIdx.x < fa.aug_blocks) {
+        if constexpr (SAMEXCD) {
+            // block a = (m / 4) * 8 + class, wave m % 4: the rows of chunks class + 8 * (m * CW + i), i < CW = 64 / R chunks of R = 256 / PPR
+            // whole rows each -- lane i * R + r takes row r of chunk i.  Plain stores: the only readers are token waves of the same class.
+            const uint32_t R = 256u / PPR, CW = fa.wait.chunks_per_aug_wave;
+            const uint32_t m = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+            const uint32_t i = lane / R, r = lane - i * R;
+            const uint64_t k = (blockIdx.x & 7u) + 8ull * (static_cast<uint64_t>(m) * CW + i);
+            const int64_t b = k < nchunks ? static_cast<int64_t>(k * R + r) : fa.B;
+            bsq_aug::augment_groups_body<K, false, true>(blockIdx.x, fa.chars, offsets, fa.B, fa.chain_len, fa.frac, fa.seed, fa.tab, b < fa.B ? b : fa.B);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached its XCD's L2
+            if ((threadIdx.x & 63) == 0) {
+                uint32_t xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                __hip_atomic_store(fa.flags + blockIdx.x * 4u + (threadIdx.x >> 6), (fa.wait.epoch << 4) | (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
         bsq_aug::augment_groups_body<K, true>(blockIdx.x, fa.chars, offsets, fa.B, fa.chain_len, fa.frac, fa.seed, fa.tab);
         // this wave's character stores (agent scope: written through) have been acknowledged ... (no cache-wide release: a
         // buffer_wbl2 per wave made the launch take 326 us instead of 49)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if ((threadIdx.x & 63) == 0)                          // ... before its flag is published
-            __hip_atomic_store(fa.flags + blockIdx.x * 4u + (threadIdx.x >> 6), fa.wait.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fa.flags + blockIdx.x * 4u + (threadIdx.x >> 6), (fa.wait.epoch << 4) | 15u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    tokens_fast_body<NT, true>(blockIdx.x - fa.aug_blocks, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, fa.wait);
+    tokens_fast_body<NT, SAMEXCD ? 2 : 1>(blockIdx.x - fa.aug_blocks, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, fa.wait);
 }
 
 // k_tokens_pb8_fast: the (P,B) token matrix -- batch_tokenize's DEFAULT layout (batch_first=False, tokenize.cpp:82-98) --
@@ -1046,7 +1087,7 @@ static bsq_status fused_acquire(hipStream_t s, size_t flag_words, uint32_t **fla
         if (slot->dev != cur) (void)hipSetDevice(cur);
         slot->buf = nullptr;
     }
-    if (!slot->buf || slot->flag_words < flag_words || slot->epoch == 0xFFFFFFFFu) {
+    if (!slot->buf || slot->flag_words < flag_words || slot->epoch >= 0x0FFFFFFEu) {  // (a flag word is epoch << 4 | who-published: 28 bits of epoch)
         if (slot->buf) (void)hipFree(slot->buf);  // (synchronises the device: nothing in flight still reads it)
         slot->buf = nullptr;
         const size_t fcap = flag_words < 4096 ? 4096 : flag_words + flag_words / 2;
@@ -1141,12 +1182,28 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(s, &cap);
             const int64_t aug_blocks = ((B + 255) / 256 + 7) / 8 * 8;
-            if (cap == hipStreamCaptureStatusNone && aug_blocks + int64_t(grid.x) < (int64_t(1) << 31)) {  // (a replayed graph would replay the epoch)
+            if (cap == hipStreamCaptureStatusNone && 2 * aug_blocks + int64_t(grid.x) < (int64_t(1) << 31)) {  // (a replayed graph would replay the epoch)
                 const void *atab = nullptr;
                 bsq_status st = augment_device_table(&atab);
                 if (st != BSQ_OK) return st;
+                // Same-XCD form (round 5; knob "augment_fused" = 2: never): padlen divides 4096 (a chunk is 4096 / padlen WHOLE rows) and
+                // the dispatcher deals blocks round-robin over the XCDs (probed once per device): every chunk's rows are mutated by an
+                // augmentation wave of the chunk's own class, the hand-off stays inside one L2 (see tokens_fast_body, FLAGS == 2)
+                const uint32_t rows_per_chunk = uint32_t(P) <= 4096u && 4096u % uint32_t(P) == 0 ? 4096u / uint32_t(P) : 0u;
+                // (measured, profiles/r05/aug_same_xcd_lab.txt: 1 us ahead up to 32 768 sequences of cfg5's shape, 2.6 us BEHIND at 262 144 -- the
+                //  augmentation role's rows are then eight runs of eight sequences per wave and its offsets loads gathers; knob 3: whenever it applies)
+                const bool same_xcd = rows_per_chunk >= 1 && rows_per_chunk <= 64 && tuning().augment_fused != 2 &&
+                                      (c.nchunks <= 6144 || tuning().augment_fused == 3) && bsq_xcd_round_robin() == 1;
+                uint32_t cw = 0;
+                int64_t aug_blocks_x = aug_blocks;
+                if (same_xcd) {
+                    cw = 64u / rows_per_chunk;                                        // chunks per augmentation wave
+                    const int64_t per_class = (c.nchunks + 7) / 8;
+                    const int64_t aug_waves = (per_class + cw - 1) / cw;             // per class
+                    aug_blocks_x = (aug_waves + 3) / 4 * 8;
+                }
                 uint32_t *flags = nullptr, *failures = nullptr, epoch = 0;
-                st = fused_acquire(s, size_t(aug_blocks) * 4, &flags, &failures, &epoch);
+                st = fused_acquire(s, size_t(aug_blocks_x) * 4, &flags, &failures, &epoch);
                 if (st != BSQ_OK) return st;
                 if (!flags) return BSQ_OK;  // (fused_taken stays false)
                 FusedAug fa;
@@ -1156,21 +1213,25 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
                 fa.frac = fuse->frac;
                 fa.seed = fuse->seed;
                 fa.chain_len = fuse->chain_len;
-                fa.aug_blocks = uint32_t(aug_blocks);
+                fa.aug_blocks = uint32_t(aug_blocks_x);
                 fa.flags = flags;
                 fa.wait.flags = flags;
                 fa.wait.failures = failures;
                 fa.wait.epoch = epoch;
+                fa.wait.chunks_per_aug_wave = cw;
                 // knob "fused_spins" (fault injection for the tests): polls before a token wave gives up; 0 = 2^18 (~1 s)
                 fa.wait.spins = tuning().fused_spins > 0 ? uint32_t(tuning().fused_spins) : (1u << 18);
-                fa.wait.naps = 60;
-                const dim3 fgrid(unsigned(aug_blocks + int64_t(grid.x)));
-                if (nt)
-                    hipLaunchKernelGGL((k_augment_tokens_fused<true, 4>), fgrid, dim3(kThreads), 0, s, offsets, chars, c.out, uint32_t(c.nchunks),
-                                       uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules, fa);
-                else
-                    hipLaunchKernelGGL((k_augment_tokens_fused<false, 4>), fgrid, dim3(kThreads), 0, s, offsets, chars, c.out, uint32_t(c.nchunks),
-                                       uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules, fa);
+                // s_sleep(2) naps between two polls of a waiting token wave: 60 (~3.5 us) when 8192 chunk waves poll at once (cfg5), fewer
+                // for smaller launches -- the same polling traffic chip-wide, and a 1/8 shard (4096 chunks) no longer naps through half of its run
+                const int64_t nap = c.nchunks / 136;
+                fa.wait.naps = uint32_t(nap < 6 ? 6 : (nap > 60 ? 60 : nap));
+                const dim3 fgrid(unsigned(aug_blocks_x + int64_t(grid.x)));
+#define BSQ_FUSED(NTV, SX)                                                                                                          \
+    hipLaunchKernelGGL((k_augment_tokens_fused<NTV, 4, SX>), fgrid, dim3(kThreads), 0, s, offsets, chars, c.out, uint32_t(c.nchunks), \
+                       uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules, fa)
+                if (nt) { if (same_xcd) BSQ_FUSED(true, true); else BSQ_FUSED(true, false); }
+                else { if (same_xcd) BSQ_FUSED(false, true); else BSQ_FUSED(false, false); }
+#undef BSQ_FUSED
                 const hipError_t eff = hipGetLastError();
                 if (eff != hipSuccess) return set_hip_error("k_augment_tokens_fused", eff);
                 *fused_taken = true;
@@ -1179,6 +1240,24 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
         }
         if (fuse) return BSQ_OK;  // the caller runs the two launches (fused_taken stays false; nothing was launched)
         const bool eosv = (c.at_len_v & 0xFFu) != (c.fill_v & 0xFFu);
+#ifdef BSQ_LABS
+        // knob "tokens8_ring" = N > 0: the per-wave LDS-DMA pipeline, N chunks per wave (round 5 experiment; 0: the fast kernel)
+        if (tuning().tokens8_ring > 0 && !raw) {
+            const int32_t nsteps = tuning().tokens8_ring;
+            const int64_t per_class = (c.nchunks + 7) / 8;
+            const int64_t wgs = (per_class + 4 * int64_t(nsteps) - 1) / (4 * int64_t(nsteps));
+            const dim3 rgrid(unsigned(wgs * 8));
+#define BSQ_T8R(NTV, EV)                                                                                                                  \
+    hipLaunchKernelGGL((k_tokens_bp8_pipe<NTV, EV>), rgrid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks), uint32_t(B), \
+                       c.ppr, magic, shift, c.room, packed, tab, rules, nsteps)
+            if (nt) { if (eosv) BSQ_T8R(true, true); else BSQ_T8R(true, false); }
+            else { if (eosv) BSQ_T8R(false, true); else BSQ_T8R(false, false); }
+#undef BSQ_T8R
+            const hipError_t er = hipGetLastError();
+            if (er != hipSuccess) return set_hip_error("k_tokens_bp8_pipe", er);
+            return BSQ_OK;
+        }
+#endif
 #define BSQ_T8F(NTV, EV)                                                                                                                 \
     hipLaunchKernelGGL((k_tokens_bp8_fast<NTV, EV>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks), uint32_t(B), \
                        c.ppr, magic, shift, c.room, packed, tab, rules)

@@ -42,7 +42,10 @@ bsq_status bsq_fill_pattern_device(void *dst, int64_t rows, int64_t pitch, int32
 /* Read + write stream of the (B,P) token kernels' shape with none of their work: wave k writes the aligned 4-KiB chunk k
  * of dst (dst_bytes a multiple of 4096) and reads its share of src (src_bytes <= dst_bytes), coalesced 16-byte pieces.
  * mode 0: loads then stores of the loaded data; 1: an extra dependent load first (offsets -> characters); 2: stores
- * that do not wait for the loads; 3: the loads only (no store traffic).  The yardstick bench.py quotes cfg2 / cfg5 against. */
+ * that do not wait for the loads; 3: the loads only (no store traffic).  The yardstick bench.py quotes cfg2 / cfg5 against.
+ * Round 5, persistent workgroups (knob fill_mode = workgroups per CU, default 4): mode 4: every wave walks its XCD class's chunks with the
+ * loads of its next chunk issued before the stores of the current one; modes 5 / 6 / 7: one LDS-DMA loader wave (global_load_lds_dwordx4)
+ * stages the pieces of three consumer waves 1 / 2 / 3 steps ahead through an LDS ring.  (profiles/r05/persistent_stream_lab.txt) */
 bsq_status bsq_copy_mix_device(void *dst, size_t dst_bytes, const void *src, size_t src_bytes, int32_t mode, int32_t nt,
                                void *hip_stream);
 
