@@ -987,7 +987,13 @@ def main():
                 forms["store_into_root"] = {"ms": float("nan"), "what": "failed: %r" % (ex,)}
         for f in forms.values():
             f["gb_per_s_into_each_rank"] = recv_bytes / (f["ms"] * 1e-3) / 1e9
-        gather_info = {"bytes_received_per_rank": recv_bytes, "forms": forms, "note": "encode time excluded; mean of %d "
+        try:
+            nccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            nccl_version = None
+        gather_info = {"rccl_world_size": dist.get_world_size(), "backend": backend, "rccl_version": nccl_version,
+                       "shard_bytes_this_rank": out_bytes, "staging_cap_bytes_direct": 256 << 20,
+                       "bytes_received_per_rank": recv_bytes, "forms": forms, "note": "encode time excluded; mean of %d "
                        "assemblies after one warm-up, MAX over ranks" % args.gather,
                        "check": "every assembled batch (every form, every repetition, on every rank that receives it) has the three 64-bit folds "
                                 "of the single-rank encode of the whole job batch"}

@@ -30,9 +30,8 @@
 //                      (The (B,P) int8 matrix has its own kernel: k_tokens_bp8, bsq_tokens8.hip.)
 //   k_tokenize_rows    (B,P) tokens for odd padlen / unaligned bases.
 //   k_tokens_raw<value>, k_tokenize_tile   (P,B) tokens (int8 / wider types): tiled transpose through LDS.
-//   k_*_generic        one thread per output element; any shape / alignment / alphabet (BYTES has ids > 255).
-//                      Fallback and in-library cross-check of the fast kernels.
-//   k_first_too_long   device-side length validation.
+//   (k_*_generic -- one thread per output element, any shape / alignment / alphabet -- and the device-side length validation
+//    k_first_too_long live in bsq_generic.hip since round 5.)
 // (The write-bandwidth yardsticks, store-pattern diagnostics and probes of include/bsq_diag.h live in bsq_diag.hip.)
 #include <hip/hip_runtime.h>
 
@@ -251,37 +250,9 @@ __device__ __forceinline__ uint32_t finish4(const TokenRule p, const uint8_t *s_
     return w;
 }
 
-#ifdef BSQ_LABS  // helpers of k_tokens_raw2
-// The position rules of finish4 on an already looked-up word (bytes = positions tpos .. tpos + 3).
-__device__ __forceinline__ uint32_t rules4(const TokenRule p, uint32_t w, int32_t L, int32_t tpos) {
-    const int32_t j0 = tpos - p.bos;
-    const int32_t nv = L - j0;
-    const int32_t nvc = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
-    const uint32_t keep = static_cast<uint32_t>((uint64_t(1) << (8 * nvc)) - 1u);  // low nvc bytes
-    w = (w & keep) | ((p.fill_id * 0x01010101u) & ~keep);
-    const uint32_t at = (nv >= 0 && nv < 4) ? (0xFFu << (8 * nvc)) : 0u;
-    w = (w & ~at) | ((p.at_len_id * 0x01010101u) & at);
-    const uint32_t first = j0 < 0 ? 0xFFu : 0u;
-    w = (w & ~first) | (p.bos_id & first);
-    return w;
-}
-
-// Four lookups in the 32-entry folded table (index c & 31, eight dwords in registers): 4 + 2 + 1 v_perm_b32 over
-// bits 2:0, 3 and 4 of each byte (the same scheme as k_tokens_bp8, bsq_tokens8.hip).
-__device__ __forceinline__ uint32_t lookup4_folded(uint32_t cw, const uint32_t (&T)[8]) {
-    const uint32_t sel = cw & 0x07070707u;
-    const uint32_t r0 = __builtin_amdgcn_perm(T[1], T[0], sel);
-    const uint32_t r1 = __builtin_amdgcn_perm(T[3], T[2], sel);
-    const uint32_t r2 = __builtin_amdgcn_perm(T[5], T[4], sel);
-    const uint32_t r3 = __builtin_amdgcn_perm(T[7], T[6], sel);
-    const uint32_t s3 = ((cw >> 1) & 0x04040404u) | 0x03020100u;
-    const uint32_t lo = __builtin_amdgcn_perm(r1, r0, s3);
-    const uint32_t hi = __builtin_amdgcn_perm(r3, r2, s3);
-    const uint32_t s4 = ((cw >> 2) & 0x04040404u) | 0x03020100u;
-    return __builtin_amdgcn_perm(hi, lo, s4);
-}
-
-#endif  // BSQ_LABS
+#ifdef BSQ_LABS
+#include "labs/bsq_tokens_raw2_helpers.inc"  // helpers of k_tokens_raw2 (4 x 4 byte transposes in registers
+#endif
 
 __device__ __forceinline__ uint32_t resolve4(const TokenRule p, const uint8_t *s_lut, uint32_t start, int32_t L,
                                              int32_t tpos) {
@@ -626,17 +597,18 @@ __device__ __forceinline__ ChunkCoord chunk_coord(const EParams &p, int64_t k, i
 
 // (A variant with the four waves of a workgroup sharing one chunk -- the shape of the fastest plain fill --
 // measured 1.6x slower: every wave then pays the token-load latency for a single 1-KiB store.)
-// CLAIM = 1 (knob "xcd_claim", measurement only): the chunk class is not blockIdx % 8 but the XCD the workgroup
-// really runs on (HW_REG_XCC_ID), and its slot comes from that class's atomic counter (p.claim[class * 32], zeroed
-// before the launch); a class that has run out hands the workgroup on to the next one, so every slot is taken
-// exactly once whatever the placement.  No workgroup waits for another.
+// (-DBSQ_LABS builds add a CLAIM parameter: labs/bsq_expand_claim.inc.)
 // GATE (rows of 24 ... 63 bytes; knob "expand_gate"): every wave first issues ONE agent-scope load -- of the head of the token scratch, a
 // line that is always at the memory side -- and makes its token loads depend on it.  The load means nothing; what it does is pace the
 // waves: the small-row expansion runs at 5 workgroups per CU, all of whose waves otherwise reach their token loads and their 4 KiB of
 // stores in step.  Measured over 24 shapes (profiles/r04/expand_gate_sweep.txt): 28-byte rows (DNA f32: cfg4) +1-2 %, 32-byte rows +5.5 %,
 // 56-byte rows +4.7 %; rows of 64 bytes and more lose 5-7 % (cfg3 0.724 -> 0.774 ms), rows of 20 bytes and less lose 1-4 %: those
 // do not get it.  (Found as a by-product of the one-launch experiment, profiles/r04/onehot_fused_one_launch_lost.txt.)
-template <typename ST, bool NT, int MATH, int CLAIM = 0, bool GATE = false>
+#ifdef BSQ_LABS
+template <typename ST, bool NT, int MATH, bool GATE = false, int CLAIM = 0>
+#else
+template <typename ST, bool NT, int MATH, bool GATE = false>
+#endif
 __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     constexpr int PIECE = kChunk;             // bytes per wave
     constexpr int NS = PIECE / 1024;          // 16-byte stores per lane
@@ -651,28 +623,9 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     const int wave_s = MATH == 1 ? __builtin_amdgcn_readfirstlane(wave) : wave;
     int64_t group = static_cast<int64_t>(blockIdx.x >> 3);
     int32_t cls = static_cast<int32_t>(blockIdx.x & 7u);
-    if constexpr (CLAIM == 1) {
-        __shared__ int64_t s_claim[2];
-        if (threadIdx.x == 0) {
-            uint32_t id;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-            int32_t c = static_cast<int32_t>(id & 7u);
-            int64_t got = -1;
-            for (int tries = 0; tries < 8 && got < 0; ++tries, c = (c + 1) & 7) {
-                const unsigned int s = atomicAdd(p.claim + c * 32, 1u);
-                if (static_cast<int64_t>(s) < p.groups_per_class) {
-                    got = s;
-                    break;
-                }
-            }
-            s_claim[0] = got;
-            s_claim[1] = c;
-        }
-        __syncthreads();
-        group = s_claim[0];
-        cls = static_cast<int32_t>(s_claim[1]);
-        if (group < 0) return;
-    }
+#ifdef BSQ_LABS
+#include "labs/bsq_expand_claim.inc"  // CLAIM == 1: placement-independent chunk classes (measurement only)
+#endif
     const int64_t slot = group * 4 + wave_s;
     const int64_t k = static_cast<int64_t>(cls) + 8 * slot;
     if (k >= p.nchunks) return;
@@ -847,112 +800,9 @@ __global__ __launch_bounds__(kThreads) void k_expand_rows1(const EParams p) {
     }
 }
 
-#ifdef BSQ_LABS  // an experiment that lost (knob expand_mode 2 / 9); not in the product binary
-// The same expansion for SMALL rows (a chunk holds hundreds of rows: 7-byte rows of int8 DNA, 28-byte rows of f32
-// DNA): a lane takes FOUR consecutive rows from one unaligned dword of tokens, every token dword of the wave's
-// CPW chunks is in flight before the first one is used, and the chunks are then scattered / streamed one after
-// the other through the wave's LDS image (LDS operations of a wave execute in order, so the image is reused as
-// soon as its four ds_read_b128 are issued).  Measured (profiles/r02/expand_lab*.txt): with ~32 waves per CU the
-// write stream is saturated only while nearly every resident wave has stores in flight; the dependent token load
-// of a one-chunk wave leaves 30 % of them waiting (cfg4 int8: 0.235 ms vs 0.165 ms without token loads).
-template <typename ST, bool NT, int CPW, int MATH>
-__global__ __launch_bounds__(kThreads) void k_expand_small(const EParams p) {
-    __shared__ __align__(16) uint8_t s_img[4][kChunk];
-    constexpr int kSlots = 5;  // x 256 rows per chunk: rows of >= 4 bytes
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint8_t *img = s_img[wave];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
-    const int32_t rowbytes = p.C * static_cast<int32_t>(sizeof(ST));
-    const ST one = static_cast<ST>(p.one_bits);
-    const int wave_s = MATH == 1 ? __builtin_amdgcn_readfirstlane(wave) : wave;
-    const int64_t slot0 = (static_cast<int64_t>(blockIdx.x >> 3) * 4 + wave_s) * CPW;
-    const int64_t k0 = static_cast<int64_t>(blockIdx.x & 7u) + 8 * slot0;  // class = blockIdx % 8, CPW consecutive slots
-    if (k0 >= p.nchunks) return;
-
-    int64_t lo[CPW];
-    int32_t len[CPW], skip[CPW], nr[CPW];
-    const uint8_t *tok[CPW];
-    bool live[CPW], wraps[CPW];
-    uint32_t w[CPW][kSlots];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        const ChunkCoord cc = chunk_coord<MATH>(p, k0 + 8 * c, rowbytes);
-        live[c] = cc.live;  // wave-uniform
-        lo[c] = cc.lo;
-        len[c] = cc.len;
-        nr[c] = 0;
-        wraps[c] = false;
-        if (!live[c]) continue;
-        skip[c] = cc.skip;
-        nr[c] = __builtin_amdgcn_readfirstlane(cc.nr);
-        const int64_t b_lo = cc.b_lo;
-        tok[c] = p.tok + cc.t_lo * p.Bp + b_lo;
-        wraps[c] = p.B - b_lo < nr[c] || nr[c] < 4;  // runs over the end of position t_lo's rows (or tiny): byte path
-#pragma unroll
-        for (int q = 0; q < kSlots; ++q) {
-            w[c][q] = kNone * 0x01010101u;
-            const int32_t i = q * 256 + 4 * lane;
-            if (!wraps[c] && p.mode != 9 && q * 256 < nr[c] && i < nr[c]) {
-                // the last lane's dword is pulled back to END at the last needed token (never a byte beyond it)
-                const int32_t off = i + 4 <= nr[c] ? i : nr[c] - 4;
-                w[c][q] = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(tok[c] + off) >> (8 * (i - off));
-            }
-            if (p.mode == 9) w[c][q] = 0x03020100u;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        if (!live[c]) continue;
-        if (!wraps[c]) {
-#pragma unroll
-            for (int q = 0; q < kSlots; ++q) {
-                if (q * 256 >= nr[c]) break;
-                const int32_t i = q * 256 + 4 * lane;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t tk = (w[c][q] >> (8 * j)) & 0xFFu;
-                    const int32_t pos = (i + j) * rowbytes - skip[c] + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
-                    if (i + j < nr[c] && tk != kNone && pos >= 0 && pos < len[c]) *reinterpret_cast<ST *>(img + pos) = one;
-                }
-            }
-        } else {  // rare: byte loads, row by row, across the pitch padding of the scratch
-            const ChunkCoord cw = chunk_coord<MATH>(p, k0 + 8 * c, rowbytes);
-            const int64_t b_lo = cw.b_lo, t_lo = cw.t_lo;
-            for (int32_t i = lane; i < nr[c]; i += 64) {
-                int64_t b = b_lo + i, t = t_lo;
-                if (b >= p.B) {
-                    const int64_t q = b / p.B;
-                    t += q;
-                    b -= q * p.B;
-                }
-                const uint32_t tk = p.tok[t * p.Bp + b];
-                const int32_t pos = i * rowbytes - skip[c] + static_cast<int32_t>(tk) * static_cast<int32_t>(sizeof(ST));
-                if (tk != kNone && pos >= 0 && pos < len[c]) *reinterpret_cast<ST *>(img + pos) = one;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint8_t *g = p.out + lo[c];
-        if (len[c] == kChunk && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
-            uint4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4 *>(img + u * 1024 + lane * 16);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) store16<NT>(g + u * 1024 + lane * 16, v[u]);
-        } else {  // clipped first / last piece of the tensor
-            for (int32_t o = lane * static_cast<int32_t>(sizeof(ST)); o < len[c]; o += 64 * static_cast<int32_t>(sizeof(ST)))
-                *reinterpret_cast<ST *>(g + o) = *reinterpret_cast<const ST *>(img + o);
-        }
-        if (c + 1 < CPW) {  // wipe the image for the next chunk (in-order LDS: behind the reads above)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(img + u * 1024 + lane * 16) = uint4{0, 0, 0, 0};
-        }
-    }
-}
-#endif  // BSQ_LABS
+#ifdef BSQ_LABS
+#include "labs/bsq_expand_small.inc"  // k_expand_small
+#endif
 
 // Raw (P,B) uint8 tokens (kNone kept) for k_expand_chunks.  Workgroup = 256 sequences x 64 positions.
 // Phase 1: 4 characters per lane (two aligned words + alignbyte, 8 fetches of a thread in flight together),
@@ -1108,114 +958,9 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     }
 }
 
-#ifdef BSQ_LABS  // an experiment that lost (knob raw_mode 2 / 3); not in the product binary
-// Round-2 EXPERIMENT on the same tile (no mask; knob "raw_mode" 2 / 3; measured slower, see launch_tokens_raw).  The idea:
-// k_tokens_raw spends four ds_read_u8 lookups and four transposed ds_write_b8 per word of four tokens.  Here
-//   * the 4 x 4 byte transpose happens in registers: the four lanes l, l+16, l+32, l+48 hold the same four positions of
-//     four CONSECUTIVE sequences; v_permlane32_swap + v_perm_b32, then v_permlane16_swap + v_perm_b32 leave lane (g, s)
-//     with position 4g + s of those four sequences -- one ds_write_b32 instead of four byte writes;
-//   * PERM: the alphabet lookup runs in registers (32-entry folded table, v_perm_b32: see bsq_tokens8.hip), non-letters
-//     fixed on a wave-uniform slow path; otherwise the LDS byte table.
-template <bool RAW, bool PERM>
-__global__ __launch_bounds__(kThreads) void k_tokens_raw2(const KParams p) {
-    __shared__ __align__(16) uint8_t s_lut[256];
-    __shared__ __align__(16) SeqSpan s_span[kRawTB];
-    __shared__ __align__(16) uint8_t s_t[kTT * kRawStride];
-    const int tid = threadIdx.x;
-    int32_t tb, tt;
-    tile_of_block(p, tb, tt);
-    if (tb >= p.ntb) return;
-    const int64_t b0 = static_cast<int64_t>(tb) * kRawTB;
-    const int32_t t0 = tt * kTT;
-    if constexpr (!PERM) stage_lut(p, s_lut);
-    TokenRule rule = make_rule(p, b0, kRawTB);
-    stage_spans(p, rule, b0, kRawTB, s_span);
-    __syncthreads();
-    if (!RAW) {  // value space: "no token" is the memset 0 of tokenize.h:427
-        if constexpr (!PERM) {
-            if (tid < 64) {
-                uint32_t w = reinterpret_cast<uint32_t *>(s_lut)[tid];
-                uint32_t z = (~w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;   // bytes equal to 0xFF <=> ~byte == 0
-                z = ~(z | ~w | 0x7F7F7F7Fu);
-                reinterpret_cast<uint32_t *>(s_lut)[tid] = w & ~((z >> 7) * 0xFFu);
-            }
-            __syncthreads();
-        }
-        if (rule.fill_id == kNone) rule.fill_id = 0;
-        if (rule.at_len_id == kNone) rule.at_len_id = 0;
-    }
-    uint32_t T[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) T[i] = RAW ? p.tab_raw[i] : p.tab_val[i];
-    const uint32_t none_w = RAW ? 0xFFFFFFFFu : 0u;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int g = lane & 15, sq = lane >> 4;  // positions 4g .. 4g+3 of sequence 4m + sq
-    const int32_t tpos = t0 + 4 * g;
-    // byte selectors of the two transpose stages (v_perm_b32(S0, S1, sel): bytes 0-3 = S1, 4-7 = S0)
-    const uint32_t selA = lane < 32 ? 0x05040100u : 0x07060302u;
-    const uint32_t selB = (lane & 16) ? 0x07030501u : 0x06020400u;
-    constexpr int NI = kRawTB / 16, BATCH = 8;  // 16 steps of 16 sequences (4 per wave)
-#pragma unroll 1
-    for (int i0 = 0; i0 < NI; i0 += BATCH) {
-        Raw4 raw[BATCH];
-        int32_t len[BATCH];
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int sb = 4 * (wave + 4 * (i0 + k)) + sq;
-            const SeqSpan sp = s_span[sb];
-            len[k] = sp.len;
-            raw[k] = fetch4<0>(rule, sp.start, tpos);
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            uint32_t w;
-            if constexpr (PERM) {
-                const uint32_t cw = __builtin_amdgcn_alignbyte(raw[k].b, raw[k].a, raw[k].sh & 3u);
-                w = lookup4_folded(cw, T);
-                const uint32_t bad = (cw ^ 0x40404040u) & 0xC0C0C0C0u;
-                if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {  // some lane holds a non-letter (rare): exact masks
-                    const uint32_t f = ((bad >> 6) | (bad >> 7)) & 0x01010101u;
-                    const uint32_t nl = (f << 8) - f;
-                    w = (w & ~nl) | (none_w & nl);
-                }
-                w = rules4(rule, w, len[k], tpos);
-            } else {
-                w = finish4<0>(rule, s_lut, raw[k], len[k], tpos);
-            }
-            // 4 x 4 byte transpose over the lanes l, l + 16, l + 32, l + 48
-            auto a = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-            const uint32_t h = __builtin_amdgcn_perm(a[1], a[0], selA);
-            auto b = __builtin_amdgcn_permlane16_swap(h, h, false, false);
-            const uint32_t f4 = __builtin_amdgcn_perm(b[1], b[0], selB);  // position 4g + sq of sequences 4m .. 4m + 3
-            const int m = wave + 4 * (i0 + k);
-            *reinterpret_cast<uint32_t *>(s_t + (4 * g + sq) * kRawStride + 4 * m) = f4;  // columns >= B are never read
-        }
-    }
-    __syncthreads();
-    uint8_t *out = static_cast<uint8_t *>(p.out);
-    for (int f = tid; f < kTT * (kRawTB / 16); f += kThreads) {
-        const int32_t tl = f >> 4, q = f & 15;
-        const int64_t t = static_cast<int64_t>(t0) + tl;
-        if (t >= p.P) continue;
-        const uint8_t *src = s_t + tl * kRawStride + q * 16;
-        uint8_t *dst = out + t * p.out_pitch + b0 + q * 16;
-        if (p.aligned && b0 + q * 16 + 16 <= p.out_pitch) {
-            uint4 v;  // LDS rows are only 4-byte aligned (stride 260): four dword reads
-            v.x = *reinterpret_cast<const uint32_t *>(src);
-            v.y = *reinterpret_cast<const uint32_t *>(src + 4);
-            v.z = *reinterpret_cast<const uint32_t *>(src + 8);
-            v.w = *reinterpret_cast<const uint32_t *>(src + 12);
-            if constexpr (RAW)
-                *reinterpret_cast<uint4 *>(dst) = v;  // scratch: re-read by the expansion pass right away
-            else
-                store16<true>(dst, v);               // final token matrix: streamed once
-        } else {
-            for (int i = 0; i < 16; ++i)
-                if (b0 + q * 16 + i < p.B) dst[i] = src[i];
-        }
-    }
-}
-#endif  // BSQ_LABS
+#ifdef BSQ_LABS
+#include "labs/bsq_tokens_raw2.inc"  // k_tokens_raw2
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Tokens, (B,P) layout: one wave per sequence, 4 positions per lane per step, no transpose.
@@ -1662,110 +1407,6 @@ __global__ __launch_bounds__(kThreads) void k_expand_bcl(const BParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Generic one-thread-per-element kernels (ids up to 258, any alignment).
-// ------------------------------------------------------------------------------------------
-struct GParams {
-    int8_t lut[256];
-    const uint8_t *chars;
-    const int64_t *offsets;
-    const uint8_t *mask;
-    void *out;
-    int64_t B, P;
-    int32_t C, bos, eos, bos_id, eos_id, pad_id, padchar, batch_first;
-    int64_t row_seqs;  // (P, B, C) one-hot: sequences per position row of the destination (= B unless the batch is a column block)
-};
-
-__device__ __forceinline__ int32_t token_at(const GParams &p, int64_t b, int64_t t) {
-    const int64_t start = p.offsets[b];
-    int64_t L = p.offsets[b + 1] - start;
-    const int64_t room = p.P - p.bos - p.eos;
-    if (L > room) L = room;
-    if (L < 0) L = 0;
-    if (p.bos && t == 0) return p.bos_id;
-    const int64_t j = t - p.bos;
-    if (j < L) {
-        if (p.mask && p.mask[start + j] == 0) return -1;
-        const uint8_t c = p.chars[start + j];
-        return c < 128 ? static_cast<int32_t>(p.lut[c]) : -1;  // negative == unmapped
-    }
-    if (p.eos && j == L) return p.eos_id;
-    return p.padchar ? p.pad_id : -1;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_onehot_generic(const GParams p) {
-    const int64_t n = p.P * p.B * p.C;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
-    T *out = static_cast<T *>(p.out);
-    for (int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; e < n; e += stride) {
-        int64_t t, b;
-        int32_t c;
-        if (p.batch_first == 2) {  // (B, C, P)
-            const int64_t r = e / p.P;
-            t = e - r * p.P;
-            b = r / p.C;
-            c = static_cast<int32_t>(r - b * p.C);
-        } else {  // (P, B, C)
-            const int64_t r = e / p.C;
-            c = static_cast<int32_t>(e - r * p.C);
-            t = r / p.B;
-            b = r - t * p.B;
-        }
-        const int32_t tk = token_at(p, b, t);
-        out[p.batch_first == 2 ? e : (t * p.row_seqs + b) * p.C + c] = (tk == c) ? T(1) : T(0);
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_tokenize_generic(const GParams p) {
-    const int64_t n = p.P * p.B;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
-    T *out = static_cast<T *>(p.out);
-    for (int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; e < n; e += stride) {
-        int64_t b, t;
-        if (p.batch_first) {
-            b = e / p.P;
-            t = e - b * p.P;
-        } else {
-            t = e / p.B;
-            b = e - t * p.B;
-        }
-        const int32_t tk = token_at(p, b, t);
-        out[p.batch_first ? e : t * p.row_seqs + b] = tk >= 0 ? static_cast<T>(tk) : T(0);
-    }
-}
-
-// first_bad[0]: first sequence longer than `room`; first_bad[1]: first entry i with offsets[i] > offsets[i + 1],
-// offsets[0] < 0 (reported as 0) or offsets[B] > nchars (reported as B) -- only checked when nchars >= 0.
-// first_bad[2] counts the workgroups that are done: the LAST one copies the two minima to `report` -- host-mapped memory the caller
-// reads after synchronising the stream -- and puts the device words back to "none" for the next call: one launch per validation,
-// no memset in front of it and no device -> host copy behind it (round 3: 43 us per validated call, 31 of them these three stream
-// operations; a loader epoch paid them per batch).
-__global__ __launch_bounds__(kThreads) void k_first_too_long(const int64_t *offsets, int64_t B, int64_t room, int64_t nchars,
-                                                             unsigned long long *first_bad, unsigned long long *report) {
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < B; i += stride) {
-        const int64_t lo = offsets[i], hi = offsets[i + 1];
-        if (hi - lo > room) atomicMin(first_bad, static_cast<unsigned long long>(i));
-        if (nchars >= 0) {
-            if (hi < lo || (i == 0 && lo < 0)) atomicMin(first_bad + 1, static_cast<unsigned long long>(i));
-            if (i == B - 1 && hi > nchars) atomicMin(first_bad + 1, static_cast<unsigned long long>(B));
-        }
-    }
-    __syncthreads();  // (every atomicMin of this workgroup has been issued; device-scope atomics are ordered at the L2)
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(first_bad + 2, 1ull) + 1 == gridDim.x) {
-            __threadfence();
-            const unsigned long long a = atomicExch(first_bad, ~0ull), b = atomicExch(first_bad + 1, ~0ull);
-            atomicExch(first_bad + 2, 0ull);
-            __hip_atomic_store(report, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(report + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Launch helpers
 // ------------------------------------------------------------------------------------------
 // Blocks of a tiled launch (see tile_of_block).
@@ -1841,32 +1482,6 @@ bsq_status fill_common(KParams &k, const bsq_desc *d, const uint8_t *chars, cons
         k.foldable = ok;
     }
     return BSQ_OK;
-}
-
-void fill_generic(GParams &g, const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask,
-                  int64_t B, int64_t P, int batch_first, void *out) {
-    for (int i = 0; i < 256; ++i) g.lut[i] = d->lut[i];
-    g.chars = chars;
-    g.offsets = offsets;
-    g.mask = mask;
-    g.out = out;
-    g.B = B;
-    g.P = P;
-    g.C = bsq_alphabet_size(d);
-    g.bos = d->bos;
-    g.eos = d->eos;
-    g.bos_id = bsq_bos_id(d);
-    g.eos_id = bsq_eos_id(d);
-    g.pad_id = bsq_pad_id(d);
-    g.padchar = d->padchar;
-    g.batch_first = batch_first;
-    g.row_seqs = B;
-}
-
-unsigned generic_grid(int64_t n) {
-    const int64_t blocks = (n + kThreads - 1) / kThreads;
-    const int64_t cap = 256 * 32;
-    return static_cast<unsigned>(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
 template <typename ST, int TB>
@@ -2123,9 +1738,9 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
         ec.claim = counters[dev];
         ec.groups_per_class = groups;
         if (bsq_internal::nontemporal_stores())
-            hipLaunchKernelGGL((k_expand_chunks<ST, true, 0, 1>), grid, dim3(kThreads), pad, s, ec);
+            hipLaunchKernelGGL((k_expand_chunks<ST, true, 0, false, 1>), grid, dim3(kThreads), pad, s, ec);
         else
-            hipLaunchKernelGGL((k_expand_chunks<ST, false, 0, 1>), grid, dim3(kThreads), pad, s, ec);
+            hipLaunchKernelGGL((k_expand_chunks<ST, false, 0, false, 1>), grid, dim3(kThreads), pad, s, ec);
         return check_launch("k_expand_chunks<claim>");
     }
 #endif
@@ -2169,10 +1784,10 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     const int64_t rowb = e.C * int64_t(sizeof(ST));
     const bool gated = (gk == 2 || (gk == 0 && rowb >= 24 && rowb < 64)) && e.Bp >= 256;
     if (bsq_internal::nontemporal_stores()) {
-        if (gated) hipLaunchKernelGGL((k_expand_chunks<ST, true, 0, 0, true>), grid, dim3(kThreads), pad, s, e);
+        if (gated) hipLaunchKernelGGL((k_expand_chunks<ST, true, 0, true>), grid, dim3(kThreads), pad, s, e);
         else hipLaunchKernelGGL((k_expand_chunks<ST, true, 0>), grid, dim3(kThreads), pad, s, e);
     } else {
-        if (gated) hipLaunchKernelGGL((k_expand_chunks<ST, false, 0, 0, true>), grid, dim3(kThreads), pad, s, e);
+        if (gated) hipLaunchKernelGGL((k_expand_chunks<ST, false, 0, true>), grid, dim3(kThreads), pad, s, e);
         else hipLaunchKernelGGL((k_expand_chunks<ST, false, 0>), grid, dim3(kThreads), pad, s, e);
     }
     return check_launch("k_expand_chunks");
@@ -2358,11 +1973,6 @@ bsq_status launch_expand_bcl(const uint8_t *tokens, int64_t B, int64_t P, int32_
 
 }  // namespace
 
-static bsq_status onehot_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null, int64_t B,
-                                       int64_t P, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream);
-static bsq_status tokenize_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
-                                         int32_t batch_first, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream);
-
 extern "C" {
 
 // 0 generic, 1 tiled, 2 two-pass, 3 chunk-owner
@@ -2482,7 +2092,7 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
     if (sz == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
     if (reinterpret_cast<uintptr_t>(out) % sz) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output is not aligned to its element size");
     const int block_path = choose_onehot_path(k.C, sz, B, P, false);
-    if (block_path == 0) return onehot_generic_block(d, chars, offsets, mask_or_null, B, P, t, out, row_seqs, hip_stream);
+    if (block_path == 0) return bsq_internal::onehot_generic_block(d, chars, offsets, mask_or_null, B, P, t, out, row_seqs, hip_stream);
     k.one_bits = one_bits_of(t);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     // A block whose position rows are whole 4-KiB chunks (B * C * sizeof(T) and the address of its first element multiples of 4096: e.g.
@@ -2508,14 +2118,20 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
         const int64_t main = lead >= 0 && lead < B ? (B - lead) / m * m : 0;
         if (main > 0 && main * rb * P >= (int64_t(128) << 20)) {
             uint8_t *o = static_cast<uint8_t *>(out);
+            // (the two short pieces -- fewer than 4096 / gcd sequences each -- through the element kernel when they are small: the tiled
+            //  kernel has a ~15-us floor, and two of them in front of and behind a 90-us stream cost the 1/8 shard of cfg4 f32 a third of
+            //  its time, 127 vs 91 us: profiles/r05/bench_default.json, cfg4f_shard8.into_root)
+            auto side = [&](const int64_t *offs, int64_t n, uint8_t *dst) {
+                if (n * P * k.C <= (int64_t(1) << 21)) return bsq_internal::onehot_generic_block(d, chars, offs, mask_or_null, n, P, t, dst, row_seqs, hip_stream);
+                return bsq_onehot_block_device(d, chars, offs, mask_or_null, n, P, t, dst, row_seqs, hip_stream);
+            };
             if (lead > 0) {
-                st = bsq_onehot_block_device(d, chars, offsets, mask_or_null, lead, P, t, o, row_seqs, hip_stream);
+                st = side(offsets, lead, o);
                 if (st != BSQ_OK) return st;
             }
             st = bsq_onehot_block_device(d, chars, offsets + lead, mask_or_null, main, P, t, o + lead * rb, row_seqs, hip_stream);
             if (st != BSQ_OK || lead + main == B) return st;
-            return bsq_onehot_block_device(d, chars, offsets + lead + main, mask_or_null, B - lead - main, P, t, o + (lead + main) * rb, row_seqs,
-                                           hip_stream);
+            return side(offsets + lead + main, B - lead - main, o + (lead + main) * rb);
         }
     }
     if (block_path != 1 && rb >= 16 && block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0) {
@@ -2724,50 +2340,7 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
         default: return launch_tokenize_chunks<uint64_t, true>(k, s);
         }
     }
-    GParams g;
-    fill_generic(g, d, chars, offsets, mask_or_null, B, P, 2, out);
-    const unsigned grid = generic_grid(P * B * g.C);
-#define BSQ_GEN(T) hipLaunchKernelGGL((k_onehot_generic<T>), dim3(grid), dim3(kThreads), 0, s, g)
-    switch (t) {
-    case BSQ_I8: BSQ_GEN(int8_t); break;
-    case BSQ_I16: BSQ_GEN(int16_t); break;
-    case BSQ_I32: BSQ_GEN(int32_t); break;
-    case BSQ_U64: BSQ_GEN(uint64_t); break;
-    case BSQ_F32: BSQ_GEN(float); break;
-    case BSQ_F64: BSQ_GEN(double); break;
-    }
-#undef BSQ_GEN
-    return check_launch("k_onehot_generic<bcl>");
-}
-
-bsq_status bsq_onehot_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
-                                     const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out,
-                                     void *hip_stream) {
-    return onehot_generic_block(d, chars, offsets, mask_or_null, B, P, t, out, B, hip_stream);
-}
-
-static bsq_status onehot_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null, int64_t B,
-                                       int64_t P, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream) {
-    if (!d || B < 0 || P <= 0 || (B > 0 && (!offsets || !out)))  // (an EMPTY batch -- a rank without sequences -- has nothing to point at)
-        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
-    if (B == 0) return BSQ_OK;
-    GParams g;
-    fill_generic(g, d, chars, offsets, mask_or_null, B, P, 0, out);
-    g.row_seqs = row_seqs;
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const unsigned grid = generic_grid(P * B * g.C);
-#define BSQ_GEN(T) hipLaunchKernelGGL((k_onehot_generic<T>), dim3(grid), dim3(kThreads), 0, s, g)
-    switch (t) {
-    case BSQ_I8: BSQ_GEN(int8_t); break;
-    case BSQ_I16: BSQ_GEN(int16_t); break;
-    case BSQ_I32: BSQ_GEN(int32_t); break;
-    case BSQ_U64: BSQ_GEN(uint64_t); break;
-    case BSQ_F32: BSQ_GEN(float); break;
-    case BSQ_F64: BSQ_GEN(double); break;
-    default: return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
-    }
-#undef BSQ_GEN
-    return check_launch("k_onehot_generic");
+    return bsq_internal::onehot_generic_bcl(d, chars, offsets, mask_or_null, B, P, t, out, hip_stream);
 }
 
 bsq_status bsq_augment_tokenize_device(const bsq_desc *d, uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
@@ -2806,12 +2379,6 @@ bsq_status bsq_fused_status(uint32_t *failures) {
 }
 void bsq_fused_status_clear(void) { bsq_internal::fused_failures_clear(); }
 
-bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
-                                       int64_t B, int64_t P, int32_t batch_first, bsq_dtype t, void *out,
-                                       void *hip_stream) {
-    return tokenize_generic_block(d, chars, offsets, B, P, batch_first, t, out, B, hip_stream);
-}
-
 // The (P, B) token matrix as a COLUMN BLOCK of a wider (P, row_seqs) matrix: `out` points at element (0, b0) of it.  The block form of
 // batch_tokenize's default layout -- pieces of a host batch (staged batches), a rank's shard stored into another GPU's matrix.
 // 1-, 2- and 8-byte types of alphabets with ids < 251 run through k_tokens_pb8_fast at the speed of the whole matrix; the rest
@@ -2828,82 +2395,7 @@ bsq_status bsq_tokenize_block_device(const bsq_desc *d, const uint8_t *chars, co
     if (reinterpret_cast<uintptr_t>(out) % sz) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output is not aligned to its element size");
     if (row_seqs < (int64_t(1) << 31) && bsq_internal::tokens_pb8_applicable(d, B, P, out, row_seqs, t))
         return bsq_internal::launch_tokens_pb8(d, chars, offsets, B, P, out, row_seqs, static_cast<hipStream_t>(hip_stream), false, t);
-    return tokenize_generic_block(d, chars, offsets, B, P, 0, t, out, row_seqs, hip_stream);
-}
-
-static bsq_status tokenize_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
-                                         int32_t batch_first, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream) {
-    if (!d || B < 0 || P <= 0 || (B > 0 && (!offsets || !out)))  // (an EMPTY batch -- a rank without sequences -- has nothing to point at)
-        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
-    if (B == 0) return BSQ_OK;
-    GParams g;
-    fill_generic(g, d, chars, offsets, nullptr, B, P, batch_first != 0, out);
-    g.row_seqs = row_seqs;
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const unsigned grid = generic_grid(P * B);
-#define BSQ_GEN(T) hipLaunchKernelGGL((k_tokenize_generic<T>), dim3(grid), dim3(kThreads), 0, s, g)
-    switch (t) {
-    case BSQ_I8: BSQ_GEN(int8_t); break;
-    case BSQ_I16: BSQ_GEN(int16_t); break;
-    case BSQ_I32: BSQ_GEN(int32_t); break;
-    case BSQ_U64: BSQ_GEN(uint64_t); break;
-    case BSQ_F32: BSQ_GEN(float); break;
-    case BSQ_F64: BSQ_GEN(double); break;
-    default: return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
-    }
-#undef BSQ_GEN
-    return check_launch("k_tokenize_generic");
-}
-
-bsq_status bsq_validate_lengths_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos,
-                                       int32_t eos, int64_t *first_bad, void *hip_stream) {
-    return bsq_validate_packed_device(offsets_dev, B, P, bos, eos, -1, first_bad, hip_stream);
-}
-
-bsq_status bsq_validate_packed_device(const int64_t *offsets_dev, int64_t B, int64_t P, int32_t bos, int32_t eos,
-                                      int64_t nchars, int64_t *first_bad, void *hip_stream) {
-    if (!offsets_dev || B < 0 || P <= 0 || !first_bad) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, B < 0 or padlen <= 0");
-    *first_bad = -1;
-    if (B == 0) return BSQ_OK;
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    // per device, allocated once: three device words (two minima + the count of finished workgroups; "none", "none", 0 between calls)
-    // and two host-mapped words the kernel's last workgroup reports into
-    static unsigned long long *flags[16] = {}, *reports[16] = {};
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);  // the words are shared: one validation at a time per process
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return bsq_internal::set_hip_error("hipGetDevice", e);
-    if (dev < 0 || dev >= 16) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "device ordinal out of range");
-    if (!flags[dev]) {
-        unsigned long long *f = nullptr, *r = nullptr;
-        const unsigned long long init[3] = {~0ull, ~0ull, 0ull};
-        e = hipMalloc(reinterpret_cast<void **>(&f), sizeof(init));
-        if (e == hipSuccess) e = hipMemcpy(f, init, sizeof(init), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&r), 2 * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
-        if (e != hipSuccess) {
-            if (f) (void)hipFree(f);
-            return bsq_internal::set_hip_error("bsq_validate_packed_device: flags", e);
-        }
-        flags[dev] = f;
-        reports[dev] = r;
-    }
-    volatile unsigned long long *host = reports[dev];
-    host[0] = host[1] = ~0ull;
-    hipLaunchKernelGGL(k_first_too_long, dim3(generic_grid(B)), dim3(kThreads), 0, s, offsets_dev, B, P - (bos != 0) - (eos != 0), nchars,
-                       flags[dev], reports[dev]);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return bsq_internal::set_hip_error("bsq_validate_packed_device", e);
-    if (host[1] != ~0ull) {
-        *first_bad = static_cast<int64_t>(host[1]);
-        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "offsets are negative, decreasing or run past the end of chars");
-    }
-    if (host[0] != ~0ull) {
-        *first_bad = static_cast<int64_t>(host[0]);
-        return BSQ_ERR_SEQ_TOO_LONG;
-    }
-    return BSQ_OK;
+    return bsq_internal::tokenize_generic_block(d, chars, offsets, B, P, 0, t, out, row_seqs, hip_stream);
 }
 
 }  // extern "C"

@@ -104,7 +104,7 @@ def _gather(local, batch_axis: int, B: int, group=None):
     return torch.cat(_all_gather_padded(local, batch_axis, B, group), dim=batch_axis)
 
 
-def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, group=None, rows_per_call: int = 0):
+def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, group=None, rows_per_call: int = 0, stage_bytes: int = 0):
     """Whole batch from per-rank shards by grouped point-to-point transfers: ONE message per peer.
 
     local: this rank's shard, contiguous; batch_axis 0 = (B_g, ...) slabs, 1 = (P, B_g, ...) column blocks.
@@ -151,19 +151,34 @@ def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, gr
         for q in reqs:
             q.wait()
     elif rows_per_call <= 0:
-        stage = {}
-        for r in recvs:
-            shape = list(local.shape)
-            shape[1] = bounds[r][1] - bounds[r][0]
-            stage[r] = local.new_empty(shape)
-        ops = [dist.P2POp(dist.irecv, stage[r], peer(r), group) for r in recvs]
-        ops += [dist.P2POp(dist.isend, local, peer(r), group) for r in sends]
-        if ops:
-            reqs += dist.batch_isend_irecv(ops)
-        for q in reqs:
-            q.wait()
-        for r in recvs:  # column block of every position row: one strided copy per peer
-            full.narrow(1, bounds[r][0], bounds[r][1] - bounds[r][0]).copy_(stage[r])
+        # Column blocks: one contiguous message per peer and ROW GROUP into a staging buffer, then one strided copy per peer into the
+        # result.  A row group holds at most `stage_bytes` (default 256 MB) of the largest shard, so the staging beside the result is
+        # (world - 1) x 256 MB however large the shards are -- at cfg3 on 8 ranks 7 x 671 MB were staged per receiving rank until
+        # round 4; one group when the shards are smaller than that (one message per peer, as before).
+        # Every rank cuts the SAME groups (they depend on P and the largest shard only), so sends and receives pair up group by group.
+        P = int(local.shape[0])
+        inner = 1
+        for d in local.shape[2:]:
+            inner *= int(d)
+        widest = max(b[1] - b[0] for b in bounds)
+        row_bytes = max(1, widest * inner * local.element_size())
+        cap = int(stage_bytes) if stage_bytes and stage_bytes > 0 else (256 << 20)
+        rows_per_group = max(1, min(P, cap // row_bytes))
+        for t0 in range(0, P, rows_per_group):
+            t1 = min(P, t0 + rows_per_group)
+            stage = {}
+            for r in recvs:
+                shape = list(local.shape)
+                shape[0], shape[1] = t1 - t0, bounds[r][1] - bounds[r][0]
+                stage[r] = local.new_empty(shape)
+            ops = [dist.P2POp(dist.irecv, stage[r], peer(r), group) for r in recvs]
+            ops += [dist.P2POp(dist.isend, local[t0:t1], peer(r), group) for r in sends]  # (rows t0 .. t1 of a contiguous shard: contiguous)
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            for q in reqs:
+                q.wait()
+            for r in recvs:  # column block of the group's position rows: one strided copy per peer
+                full[t0:t1].narrow(1, bounds[r][0], bounds[r][1] - bounds[r][0]).copy_(stage[r])
+            del stage
     else:
         P = int(local.shape[0])
         for t0 in range(0, P, rows_per_call):

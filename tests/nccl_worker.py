@@ -66,6 +66,41 @@ def main():
             ok = ok and same(sharding.onehot_gathered(raw_tokens, expand, chars, offs), full_oh)
         else:
             ok = ok and same(sharding.onehot_gathered(lambda c, o: raw_tokens(c, o).cpu(), lambda t: expand(t.to(dev)), chars, offs), full_oh)
+    # BASELINE config 4's split at 1/64 scale ("1M reads, 1 vs 8 GPU shard + RCCL gather": 15 625 reads of 150, DNA4 + BOS / EOS / PAD,
+    # padlen 160, f32 -- 28-byte rows, shards that are not a multiple of anything): the point-to-point gather with its staging cut into
+    # row groups (a cap far below the shard: dozens of messages per peer in flight group after group), to a root and to every rank; the
+    # token-matrix gather; the kernels storing straight into the root's buffer -- and then the same store with ONE rank handed a
+    # sequence that does not fit: the MIN-reduced ok flag must raise on EVERY rank, none may be left waiting
+    tok4, ora4 = bioseq_amd.Tokenizer("DNA4", 1, 1, 1), O.OracleTokenizer("DNA4", 1, 1, 1)
+    B4, P4 = 15625, 160
+    chars4, offs4 = synth.synth_packed(404, B4, 150, 150, "ACGT")
+    full4 = ora4.onehot_packed(chars4, offs4, P4, "f")
+    enc4 = lambda c, o: ship(tok4.onehot_packed(torch.as_tensor(np.ascontiguousarray(c)).to(dev), torch.as_tensor(np.ascontiguousarray(o)).to(dev), P4, "f"))
+    keep4 = sharding.encode_sharded(enc4, chars4, offs4).contiguous()
+    for root in (None, 0, world - 1):
+        for cap in (0, 1 << 20, 200000):
+            r = sharding.gather_direct(keep4, 1, B4, root, stage_bytes=cap)
+            want_here = root is None or rank == root
+            ok = ok and ((r is not None and r.cpu().numpy().tobytes() == full4.tobytes()) if want_here else r is None)
+            del r
+    got = sharding.encode_into_root(tok4, chars4, offs4, P4, "f", "tbc", dev, root=0)
+    ok = ok and ((got is not None and got.cpu().numpy().tobytes() == full4.tobytes()) if rank == 0 else got is None)
+    del got
+    dist.barrier()
+    bad_rank = world - 1
+    c_bad, o_bad = sharding.shard_packed(chars4, offs4, world, rank)
+    b0_bad = sharding.shard_bounds(B4, world, rank)[0]
+    if rank == bad_rank:  # this rank's shard gets one sequence longer than padlen - 2: its validation fails before any launch
+        o_bad = o_bad.copy()
+        c_bad = np.concatenate([c_bad, np.full(200, ord("A"), np.uint8)])
+        o_bad[-1] += 200
+    raised = False
+    try:
+        sharding.store_shard_into_root(tok4, c_bad, o_bad, b0_bad, B4, P4, "f", "tbc", dev, 0, None, True)
+    except Exception:
+        raised = True
+    ok = ok and raised            # on EVERY rank: the bad one with its own error, the others with "another rank failed"
+    dist.barrier()
     flag = torch.tensor([1 if ok else 0], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

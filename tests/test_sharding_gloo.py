@@ -64,6 +64,11 @@ def _worker(rank, world, port, B, P, q):
             r_oh = sharding.gather_direct(torch.from_numpy(keep), 1, B, root, rows_per_call=5)     # one message per (peer, row)
             r_oh1 = sharding.gather_direct(torch.from_numpy(keep), 1, B, root)                     # one message per peer (default)
             direct_ok = direct_ok and ((r_oh1 is None) if rank != root else r_oh1.numpy().tobytes() == full_oh.tobytes())
+            # the staging cap: row groups of a few KB here (the 256-MB default never splits a test-sized shard) -- several messages per
+            # peer, every rank cutting the same groups, ragged and empty shards included
+            for cap in (1, 4096, 20000):
+                r_g = sharding.gather_direct(torch.from_numpy(keep), 1, B, root, stage_bytes=cap)
+                direct_ok = direct_ok and ((r_g is None) if rank != root else r_g.numpy().tobytes() == full_oh.tobytes())
             r_bf = sharding.gather_direct(torch.from_numpy(np.ascontiguousarray(full_bf[slice(*sharding.shard_bounds(B, world, rank))])), 0, B, root)
             if rank == root:
                 direct_ok = direct_ok and r_oh.numpy().tobytes() == full_oh.tobytes() and r_bf.numpy().tobytes() == full_bf.tobytes()
