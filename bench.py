@@ -428,7 +428,11 @@ class Batch:
         else:
             name = "k_tokens_pb8_fast" if sz <= 2 and (n * sz) % 16 == 0 else ("k_tokens_raw<value>" if sz == 1 else "k_tokenize_tile")
         if op == "augment+tokenize":
-            return "k_augment_tokens_fused(k_augment_groups -> k_tokens_bp8_fast)" if name == "k_tokens_bp8_fast" else "k_augment_groups+" + name
+            if name != "k_tokens_bp8_fast":
+                return "k_augment_groups+" + name
+            # one launch either way: up to 16 384 chunks nobody waits and a patch launch follows; beyond that the token waves wait for flags
+            return ("k_augment_tokens_nowait(k_augment_groups || k_tokens_bp8_fast)+k_patch_tokens" if n * P <= 16384 * 4096
+                    else "k_augment_tokens_fused(k_augment_groups -> k_tokens_bp8_fast)")
         return name
 
     def describe(self):

@@ -55,16 +55,29 @@ constexpr int kSeqPerWave = 64;
 // other XCDs' loads find them -- because waves of the SAME launch read them next.
 // MAPPED (round 5, the same-XCD form of the fused launch): the lane's sequence is `b_mapped` (>= B: none) instead of the vblock's
 // 256 consecutive ones -- the stream is keyed by (seed, sequence), so WHICH lane mutates a sequence never changes a result.
-template <int K, bool COHERENT = false, bool MAPPED = false>
+// RECORD (round 5, the no-wait form of the fused launch): every mutation is also written down -- rec[b * chain_len + m] = (position in
+// the sequence, new byte) for the m-th mutation of sequence b, (0xFFFFFFFF, 0) where there is none -- so that a patch pass can put the
+// mutated residues' tokens into a token matrix that was encoded WHILE the mutations were being made (bsq_tokens8.hip: k_patch_tokens).
+// (records are stored at agent scope = written through: a line left dirty in L2 costs its write-back at the END of the launch, and the
+//  patch launch behind it reads them from the memory side at once; measured neutral against plain stores, profiles/r05/aug_nowait_patch_ab.txt)
+__device__ __forceinline__ void store_record(uint2 *dst, uint32_t pos, uint32_t byte) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst), (static_cast<unsigned long long>(byte) << 32) | pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int K, bool COHERENT = false, bool MAPPED = false, bool RECORD = false>
 __device__ __forceinline__ void augment_groups_body(uint32_t vblock, uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len,
-                                                    double frac, uint64_t seed, const AugTable *tab, int64_t b_mapped = 0) {
+                                                    double frac, uint64_t seed, const AugTable *tab, int64_t b_mapped = 0, uint2 *rec = nullptr) {
     __shared__ __align__(16) AugTable s_tab;
     __shared__ int64_t s_start[4][kSeqPerWave], s_len[4][kSeqPerWave];
     __shared__ uint64_t s_h0[4][kSeqPerWave];
     __shared__ uint32_t s_ctr[4][kSeqPerWave];
     __shared__ int32_t s_rem[4][kSeqPerWave], s_tries[4][kSeqPerWave];
+    __shared__ int64_t s_b[RECORD ? 4 : 1][RECORD ? kSeqPerWave : 1];  // RECORD: the sequence of every home lane (the winning lane of a group writes its record)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t b = MAPPED ? b_mapped : (static_cast<int64_t>(vblock) * 4 + wave) * kSeqPerWave + lane;
+    if constexpr (RECORD) {
+        if (b < B)
+            for (int32_t m = 0; m < chain_len; ++m) store_record(rec + b * chain_len + m, 0xFFFFFFFFu, 0u);
+    }
     // the spans first: their loads are in flight while the table is staged (round 3: the kernel is latency-bound --
     // 59 % of its wave cycles are waits, profiles/r03/augment_groups_pmc.txt -- and this was one dependent round trip more)
     int64_t start = 0, L = 0;
@@ -124,6 +137,8 @@ __device__ __forceinline__ void augment_groups_body(uint32_t vblock, uint8_t *ch
                 const int last = row == kCols - 1 ? kCols - 2 : kCols - 1;
                 if constexpr (COHERENT) __hip_atomic_store(chars + start + iw, static_cast<uint8_t>(s_tab.letter[below ? __builtin_ctz(below) : last]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else chars[start + iw] = s_tab.letter[below ? __builtin_ctz(below) : last];
+                if constexpr (RECORD)  // the sequence's first mutation (positions of 2^32 and beyond lie in no token row: left as "none")
+                    if (iw < 0xFFFFFFFFll) store_record(rec + b * chain_len, static_cast<uint32_t>(iw), static_cast<uint32_t>(s_tab.letter[below ? __builtin_ctz(below) : last]));
                 ctr = c + 2;
                 rem -= 1;
             } else {
@@ -138,6 +153,7 @@ __device__ __forceinline__ void augment_groups_body(uint32_t vblock, uint8_t *ch
         s_ctr[wave][lane] = ctr;
         s_rem[wave][lane] = rem;
         s_tries[wave][lane] = tries;
+        if constexpr (RECORD) s_b[wave][lane] = b;
     }
     __shared__ int32_t s_sel[4][kSeqPerWave];
     for (;;) {
@@ -220,6 +236,11 @@ __device__ __forceinline__ void augment_groups_body(uint32_t vblock, uint8_t *ch
                     const int pick = below ? __builtin_ctz(below) : last;
                     if constexpr (COHERENT) __hip_atomic_store(chars + start + iw, static_cast<uint8_t>(s_tab.letter[pick]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else chars[start + iw] = s_tab.letter[pick];
+                    if constexpr (RECORD) {  // mutation number chain_len - (mutations still to make) of the home lane's sequence
+                        const int64_t bs = s_b[wave][sidx];
+                        if (bs < B && iw < 0xFFFFFFFFll)
+                            store_record(rec + bs * chain_len + (chain_len - s_rem[wave][sidx]), static_cast<uint32_t>(iw), static_cast<uint32_t>(s_tab.letter[pick]));
+                    }
                     s_ctr[wave][sidx] = c + 2;
                     s_rem[wave][sidx] -= 1;
                     s_tries[wave][sidx] = 0;

@@ -57,7 +57,9 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   tokens_pb8            1: never use k_tokens_pb8_fast for the (P,B) token matrices (k_tokens_raw / k_tokenize_tile instead), 2: also
 //                         for 4-byte elements (automatic: 1-, 2- and 8-byte elements), 3: only when rows and output are 16-byte aligned;
 //                         its lookup follows tokens8_lookup
-//   augment_fused         1: bsq_augment_tokenize_device never fuses its two launches; 2: fuses, but never in the same-XCD form (round 5), 3: the same-XCD form whenever it applies (automatic: <= 6144 chunks)
+//   augment_fused         bsq_augment_tokenize_device: 0 automatic -- up to 16 384 chunks the no-wait form (augmentation + tokens in one launch, nobody
+//                         waits, a patch launch behind it: round 5; 4: at every size), beyond that the flag form --, 1 never fused (the two launches), 2 the flag form of rounds 3-4 (token waves wait for their rows' augmentation;
+//                         written-through stores, any XCD), 3 the flag form with the hand-off inside one XCD where it applies
 //   expand_gate           k_expand_chunks: one pacing load in front of every wave (0 automatic: rows of 24 ... 63 bytes; 1 never; 2 always)
 //   expand_rows1          the LDS-free expansion k_expand_rows1 (one-byte elements, rows of 3 ... 15 bytes): 0 automatic, 1 never, 2 whenever it applies
 //   tokens8_ring          LABS: N > 0: the (B,P) int8 token matrix through k_tokens_bp8_pipe (every wave walks N chunks with its offsets and

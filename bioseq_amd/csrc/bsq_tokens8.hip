@@ -662,6 +662,7 @@ struct FusedAug {
     uint32_t aug_blocks;
     uint32_t *flags;          // aug_blocks * 4 words (one per augmentation wave)
     FusedWait wait;
+    uint2 *rec;               // no-wait form: B * chain_len mutation records (bsq_augment_dev.h, RECORD)
 };
 template <bool NT, int K, bool SAMEXCD = false>
 __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t *__restrict__ offsets, const uint8_t *chars,
@@ -695,6 +696,44 @@ __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t
         return;
     }
     tokens_fast_body<NT, SAMEXCD ? 2 : 1>(blockIdx.x - fa.aug_blocks, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, fa.wait);
+}
+
+// The NO-WAIT form (round 5) -- cfg5's default entry since then.  Nobody waits for anybody inside the launch: the augmentation role mutates the
+// characters in place (plain stores) and writes every mutation down (position, new byte); the token role is k_tokens_bp8_fast as it is, at
+// once, on whatever it finds -- for a mutated position that is the old residue or the new one, depending on who came first.  A second, tiny
+// launch (k_patch_tokens, one thread per sequence, in chain order) then stores the token of every recorded new residue at its place in the
+// matrix: whichever version the token role saw, the matrix ends up as the tokens of the mutated batch, bit for bit (a mutation never
+// changes a length, so BOS / EOS / PAD are where they were).  Against the flag form (above; still there under knob augment_fused = 2):
+// the ~9 us the token stream used to wait for the augmentation are gone, so are the written-through stores, the second fetch of the
+// characters through sc1 loads, the polling, the epoch bookkeeping -- and the failure mode (a wait that could expire).  What it costs is
+// the patch launch: 1 MB of records read, one byte store per mutation.  Round 4 had tried the side list with the wait kept INSIDE the
+// launch (46.5 us: the late waits stalled the stream); profiles/r05/aug_nowait_patch_ab.txt.
+template <bool NT, int K, bool EOSV>
+__global__ __launch_bounds__(kThreads) void k_augment_tokens_nowait(const int64_t *__restrict__ offsets, const uint8_t *chars,
+                                                                    uint8_t *__restrict__ out, uint32_t nchunks, uint32_t B, uint32_t PPR,
+                                                                    uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
+                                                                    T8Tab tab, T8Rules rules, FusedAug fa) {
+    if (blockIdx.x < fa.aug_blocks) {
+        // the augmentation's waves share their SIMDs with seven token waves each: with priority their 64-bit multiplies and FP64 draw are not
+        // an eighth of the issue slots -- 32 768 sequences 16.2 -> 13.0 us; no effect from 131 072 on (profiles/r05/aug_nowait_patch_ab.txt)
+        __builtin_amdgcn_s_setprio(3);
+        bsq_aug::augment_groups_body<K, true, false, true>(blockIdx.x, fa.chars, offsets, fa.B, fa.chain_len, fa.frac, fa.seed, fa.tab, 0, fa.rec);
+        return;
+    }
+    tokens_fast_body<NT, 0, EOSV>(blockIdx.x - fa.aug_blocks, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, FusedWait{});
+}
+
+struct PatchLut {
+    uint8_t v[128];  // token VALUE of every 7-bit byte (unmapped: 0, the memset value of tokenize.h:427)
+};
+__global__ __launch_bounds__(kThreads) void k_patch_tokens(const uint2 *__restrict__ rec, int64_t B, int32_t chain_len, int64_t P, int32_t bos,
+                                                           int32_t room, PatchLut lut, uint8_t *__restrict__ out) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (b >= B) return;
+    for (int32_t m = 0; m < chain_len; ++m) {  // in chain order: a later mutation of the same position wins, as in the characters
+        const uint2 r = rec[b * chain_len + m];
+        if (r.x != 0xFFFFFFFFu && r.x < static_cast<uint32_t>(room)) out[b * P + bos + r.x] = (r.y < 128u) ? lut.v[r.y] : uint8_t(0);
+    }
 }
 
 // k_tokens_pb8_fast: the (P,B) token matrix -- batch_tokenize's DEFAULT layout (batch_first=False, tokenize.cpp:82-98) --
@@ -1186,14 +1225,56 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
                 const void *atab = nullptr;
                 bsq_status st = augment_device_table(&atab);
                 if (st != BSQ_OK) return st;
+                // The no-wait form (round 5, see k_augment_tokens_nowait; knob "augment_fused" 2 / 3: the flag forms instead)
+                // Automatic (knob 0): up to 16 384 chunks (65 536 sequences of cfg5's shape: 15.7 vs 18.6 us; the 1/8 shard 13.7 vs 16.8; a
+                // loader batch of 4096: 12.5 vs 14.1) -- beyond that the mutations' own work no longer hides beside the stream and the patch
+                // launch comes on top (262 144 sequences: 40.5 + 6.4 us against 41 for the flag form, which cfg5 itself therefore keeps).
+                // Knob 4: whatever the size.
+                if ((tuning().augment_fused == 0 && c.nchunks <= 16384) || tuning().augment_fused == 4) {
+                    std::lock_guard<std::mutex> scratch_turn(workspace_mutex());  // (the scratch is shared by the calls of a stream: both launches back to back)
+                    void *ws = nullptr;
+                    const int32_t chain = fuse->chain_len > 0 ? fuse->chain_len : 1;
+                    st = workspace_acquire(size_t(B) * size_t(chain) * sizeof(uint2), s, &ws);
+                    if (st != BSQ_OK) return st;
+                    FusedAug fa;
+                    fa.chars = fuse->chars;
+                    fa.B = B;
+                    fa.tab = static_cast<const bsq_aug::AugTable *>(atab);
+                    fa.frac = fuse->frac;
+                    fa.seed = fuse->seed;
+                    fa.chain_len = fuse->chain_len;
+                    fa.aug_blocks = uint32_t(aug_blocks);
+                    fa.flags = nullptr;
+                    fa.wait = FusedWait{};
+                    fa.rec = static_cast<uint2 *>(ws);
+                    const bool eosv_f = (c.at_len_v & 0xFFu) != (c.fill_v & 0xFFu);
+                    const dim3 fgrid(unsigned(aug_blocks + int64_t(grid.x)));
+#define BSQ_NOWAIT(NTV, EV)                                                                                                              \
+    hipLaunchKernelGGL((k_augment_tokens_nowait<NTV, 4, EV>), fgrid, dim3(kThreads), 0, s, offsets, chars, c.out, uint32_t(c.nchunks),   \
+                       uint32_t(B), c.ppr, magic, shift, c.room, packed, tab, rules, fa)
+                    if (nt) { if (eosv_f) BSQ_NOWAIT(true, true); else BSQ_NOWAIT(true, false); }
+                    else { if (eosv_f) BSQ_NOWAIT(false, true); else BSQ_NOWAIT(false, false); }
+#undef BSQ_NOWAIT
+                    hipError_t en = hipGetLastError();
+                    if (en == hipSuccess && fuse->chain_len > 0) {
+                        PatchLut pl;
+                        for (int i = 0; i < 128; ++i) pl.v[i] = d->lut[i] >= 0 ? uint8_t(d->lut[i]) : uint8_t(c.none_v);
+                        hipLaunchKernelGGL(k_patch_tokens, dim3(unsigned((B + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, static_cast<const uint2 *>(ws), B,
+                                           fuse->chain_len, P, int32_t(c.bos), c.room, pl, c.out);
+                        en = hipGetLastError();
+                    }
+                    workspace_release(ws, s);
+                    if (en != hipSuccess) return set_hip_error("k_augment_tokens_nowait / k_patch_tokens", en);
+                    *fused_taken = true;
+                    return BSQ_OK;
+                }
                 // Same-XCD form (round 5; knob "augment_fused" = 2: never): padlen divides 4096 (a chunk is 4096 / padlen WHOLE rows) and
                 // the dispatcher deals blocks round-robin over the XCDs (probed once per device): every chunk's rows are mutated by an
                 // augmentation wave of the chunk's own class, the hand-off stays inside one L2 (see tokens_fast_body, FLAGS == 2)
                 const uint32_t rows_per_chunk = uint32_t(P) <= 4096u && 4096u % uint32_t(P) == 0 ? 4096u / uint32_t(P) : 0u;
                 // (measured, profiles/r05/aug_same_xcd_lab.txt: 1 us ahead up to 32 768 sequences of cfg5's shape, 2.6 us BEHIND at 262 144 -- the
                 //  augmentation role's rows are then eight runs of eight sequences per wave and its offsets loads gathers; knob 3: whenever it applies)
-                const bool same_xcd = rows_per_chunk >= 1 && rows_per_chunk <= 64 && tuning().augment_fused != 2 &&
-                                      (c.nchunks <= 6144 || tuning().augment_fused == 3) && bsq_xcd_round_robin() == 1;
+                const bool same_xcd = rows_per_chunk >= 1 && rows_per_chunk <= 64 && tuning().augment_fused == 3 && bsq_xcd_round_robin() == 1;
                 uint32_t cw = 0;
                 int64_t aug_blocks_x = aug_blocks;
                 if (same_xcd) {
@@ -1214,6 +1295,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
                 fa.seed = fuse->seed;
                 fa.chain_len = fuse->chain_len;
                 fa.aug_blocks = uint32_t(aug_blocks_x);
+                fa.rec = nullptr;
                 fa.flags = flags;
                 fa.wait.flags = flags;
                 fa.wait.failures = failures;

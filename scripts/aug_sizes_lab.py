@@ -12,18 +12,18 @@ stream = torch.cuda.current_stream()
 c = synth.CONFIGS["cfg5"]
 desc = capi.make_desc(c["key"], c["eos"], c["bos"], c["padchar"])
 P = c["padlen"]
-for n in (1024, 4096, 8192, 16384, 32768, 65536, 131072, 262144):
+for n in [int(x) for x in os.environ.get("SIZES", "1024,4096,8192,16384,32768,65536,131072,262144").split(",")]:
     chars, offs = synth.synth_packed(c["seed"], n, c["lo"], c["hi"], c["letters"])
     dch, dof = torch.from_numpy(chars).to(dev), torch.from_numpy(offs).to(dev)
     pristine = dch.clone()
     out = torch.empty((n, P), dtype=torch.int8, device=dev)
     res = []
-    for knob in (0, 1, 2):
+    for knob in [int(x) for x in os.environ.get("KNOBS", "0,1,2").split(",")]:
         capi.check(lib.bsq_tuning_set(b"augment_fused", knob))
         seed = [0]
         def step():
             seed[0] += 1
-            capi.check(lib.bsq_augment_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), n, P, 1, capi.I8, out.data_ptr(), 1, 0.5, seed[0], stream.cuda_stream))
+            capi.check(lib.bsq_augment_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), n, P, 1, capi.I8, out.data_ptr(), int(os.environ.get("CHAIN", "1")), float(os.environ.get("FRAC", "0.5")), seed[0], stream.cuda_stream))
         ts = []
         for rep in range(5):
             dch.copy_(pristine)

@@ -69,7 +69,7 @@ def run(budget=120.0, seed=1):
             if rng.random() < 0.3:  # augmentation + tokens in one call == the two calls (fused launch or not, any shape / type / layout)
                 from bioseq_amd import blosum
                 cl, fr, sd = int(rng.integers(0, 4)), float(rng.choice([0.3, 0.5, 1.0])), int(rng.integers(1 << 30))
-                capi.check(lib.bsq_tuning_set(b"augment_fused", int(rng.integers(0, 2))))
+                capi.check(lib.bsq_tuning_set(b"augment_fused", int(rng.integers(0, 5))))
                 a1, a2 = dch.clone(), dch.clone()
                 blosum.augment_packed(a1, dof, cl, fr, sd)
                 t1 = tok.tokenize_packed(a1, dof, P, d, bf, validate=False)

@@ -340,8 +340,11 @@ def test_fused_augment_tokenize_equals_the_two_calls(gpu, bsq, oracle, key, flag
     dof = torch.from_numpy(offs).to(gpu)
     tok = bsq.Tokenizer(key, eos, bos, pad)
     ora = oracle.OracleTokenizer(key, eos, bos, pad)
+    # knob augment_fused: 0 automatic (no-wait form + patch launch up to 16 384 chunks, else the flag form), 4 no-wait at any size, 1 two launches,
+    # 2 / 3 the flag forms of rounds 3-4 (any XCD / same XCD)
     for chain_len, frac, dc, bf, knob in ((1, 0.5, "b", True, 0), (3, 1.0, "b", True, 0), (2, 0.7, "b", True, 1), (1, 0.5, "b", False, 0),
-                                          (1, 1.0, "i", True, 0), (0, 1.0, "b", True, 0)):
+                                          (1, 1.0, "i", True, 0), (0, 1.0, "b", True, 0), (1, 0.5, "b", True, 2), (3, 1.0, "b", True, 2),
+                                          (2, 0.7, "b", True, 3), (4, 1.0, "b", True, 4), (1, 0.5, "b", True, 4)):
         if key == "BYTES" and dc == "b":
             continue  # ids up to 255 need a wider type
         capi.check(lib.bsq_tuning_set(b"augment_fused", knob))
@@ -472,13 +475,17 @@ def test_cfg5_full_size_one_launch_vs_oracle(gpu, bsq, oracle, chain_len, frac):
     del ref
     ndiff = int((want_chars != chars).sum())
     assert (0.4 * n < ndiff < 0.6 * n) if frac < 1.0 else (n <= ndiff + n // 8 and ndiff <= chain_len * n)
-    for bf in (True, False):
+    for bf, knob in ((True, 0), (True, 4), (False, 0)):   # knob 0: this size takes the flag form; 4: the no-wait form + patch launch (round 5)
         want = ora.tokenize_packed(want_chars, offs, P, "b", bf)
         buf = torch.from_numpy(chars).to(gpu)
-        got = blosum.augment_tokenize_packed(tok, buf, dof, P, "b", bf, chain_len=chain_len, augment_frac=frac, seed=1)
+        capi.check(lib.bsq_tuning_set(b"augment_fused", knob))
+        try:
+            got = blosum.augment_tokenize_packed(tok, buf, dof, P, "b", bf, chain_len=chain_len, augment_frac=frac, seed=1)
+        finally:
+            capi.check(lib.bsq_tuning_set(b"augment_fused", 0))
         blosum.check_fused(synchronize=True)
-        assert buf.cpu().numpy().tobytes() == want_chars.tobytes(), (chain_len, frac, bf)
-        assert got.cpu().numpy().tobytes() == want.tobytes(), (chain_len, frac, bf)
+        assert buf.cpu().numpy().tobytes() == want_chars.tobytes(), (chain_len, frac, bf, knob)
+        assert got.cpu().numpy().tobytes() == want.tobytes(), (chain_len, frac, bf, knob)
         del buf, got, want
 
 
@@ -537,6 +544,7 @@ def test_fused_wait_expiry_is_loud(gpu, bsq, oracle):
     blosum.augment_packed(ref, dof, chain_len=1, augment_frac=0.5, seed=3)
     want = ora.tokenize_packed(ref.cpu().numpy(), offs, P, "b", True)
     capi.check(lib.bsq_tuning_set(b"fused_spins", 1))
+    capi.check(lib.bsq_tuning_set(b"augment_fused", 2))  # the flag form (since round 5 the default form has no wait that could expire)
     try:
         buf = torch.from_numpy(chars).to(gpu)
         got = blosum.augment_tokenize_packed(tok, buf, dof, P, "b", True, chain_len=1, augment_frac=0.5, seed=3)
@@ -558,6 +566,7 @@ def test_fused_wait_expiry_is_loud(gpu, bsq, oracle):
             blosum.augment_tokenize_packed(tok, torch.from_numpy(chars).to(gpu), dof, P, "b", True, chain_len=1, augment_frac=0.5, seed=3)
     finally:
         capi.check(lib.bsq_tuning_set(b"fused_spins", 0))
+        capi.check(lib.bsq_tuning_set(b"augment_fused", 0))
         blosum.clear_fused_error()
     buf = torch.from_numpy(chars).to(gpu)
     got = blosum.augment_tokenize_packed(tok, buf, dof, P, "b", True, chain_len=1, augment_frac=0.5, seed=3)
