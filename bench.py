@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg2sf|cfg3b|cfg4f|cfg4b|cfg5|cfg5aug]
-                    [--configs all|none|a,b,c] [--scaling weak|strong] [--gather K]
+                    [--configs all|none|a,b,c] [--scaling weak|strong] [--gather K] [--shard-of N [--shard-rank R]] [--cold]
 
 A "step" is ONE pass of the hot path over one batch of synthetic input that is already resident
 in HBM (packed chars + offsets on the device, output preallocated): for the default workload
@@ -28,7 +28,16 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 (>= 0.25 s), traffic, kernel, an untimed `check` of its full-size output against the committed folds of the
                 REFERENCE's output (tests/golden/bench_folds.json -- never a comparison with the product's own kernels), and
                 for the token workloads `cold`: the same step cycling over distinct resident batches whose inputs add up to
-                more than 512 MiB (past the 256-MiB Infinity Cache -- a training loop never encodes one batch twice).
+                more than 512 MiB (past the 256-MiB Infinity Cache -- a training loop never encodes one batch twice).  Since round 5
+                the cold regime's figures ARE the token workloads' `frac` / `ms_per_step` (their working sets fit the Infinity Cache);
+                the loop over one resident batch is beside them as `frac_cache_resident` / `ms_per_step_cache_resident`.
+                `<w>_shard8` (cfg3, cfg4f, cfg4b, cfg5aug): rank 0's sharding.shard_bounds share of the workload's batch split over 8
+                ranks -- the per-GPU term of the 1/2/4/8 strong-scaling curve, measured on this one GPU -- as a tensor of its own
+                (checked against reference-made folds) and written straight into a whole-batch root tensor (`into_root`: a column
+                block at the root's pitch for seq-first layouts; also at the middle rank's offset), with
+                predicted_strong_scaling_efficiency = t(full batch) / (8 * t(shard)).  `--shard-of N` does the same for --workload.
+  build_id      bsq_build_id() of the loaded library; `roofline.traffic_stale` / `configs.*.traffic_stale` are true when the committed
+                counters (profiles/traffic.json) were measured on another build.
 """
 import argparse
 import json

@@ -21,7 +21,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libbsq_hip.so")
 EXT = os.path.join(HERE, "cbioseq" + sysconfig.get_config_var("EXT_SUFFIX"))
 
-LIB_SRCS = ["bsq_kernels.hip", "bsq_generic.hip", "bsq_tokens8.hip", "bsq_decode.hip", "bsq_augment.hip", "bsq_gather.hip", "bsq_diag.hip", "bsq_host.cpp", "bsq_alphabet.cpp", "bsq_fastx.cpp"]
+LIB_SRCS = ["bsq_onehot.hip", "bsq_tokens.hip", "bsq_generic.hip", "bsq_tokens8.hip", "bsq_decode.hip", "bsq_augment.hip", "bsq_gather.hip", "bsq_diag.hip", "bsq_host.cpp", "bsq_alphabet.cpp", "bsq_fastx.cpp"]
 EXT_SRCS = ["cbioseq_module.cpp"]
 
 

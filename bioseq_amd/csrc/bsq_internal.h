@@ -122,6 +122,10 @@ bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
 bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
                              int64_t pitch, hipStream_t stream, bool raw = false, bsq_dtype t = BSQ_I8);
 
+// bsq_tokens.hip: the channels-first (B, C, P) one-hot through the (B,P) chunk kernel's HOT form (the fallback of bsq_onehot_bcl_device for outputs
+// below its two-pass threshold and for masked batches)
+bsq_status launch_onehot_bcl_chunks(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null, int64_t B,
+                                    int64_t P, bsq_dtype t, void *out, hipStream_t s);
 // bsq_generic.hip: the element kernels as blocks of a wider destination (row_seqs sequences per position row; = B: the whole tensor / matrix)
 bsq_status onehot_generic_block(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null, int64_t B,
                                 int64_t P, bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream);

@@ -93,10 +93,6 @@ __device__ __forceinline__ uint32_t nonletter_mask(uint32_t cw) {
     return (f << 8) - f;  // f * 0xFF
 }
 
-__device__ __forceinline__ uint32_t keep_word(const uint4 &k, int q) { return q == 0 ? k.x : (q == 1 ? k.y : (q == 2 ? k.z : k.w)); }
-typedef __attribute__((address_space(3))) void bsq_lds_void;
-typedef __attribute__((address_space(1))) const void bsq_glb_cvoid;
-
 // ABL (diagnostic instantiations only): 0 the kernel; 1 no alphabet lookup (characters stored as they are);
 // 2 no character loads; 3 no offsets loads either (synthetic sequence spans); 4 stores only; 5 character loads at
 // synthetic addresses that do not depend on the offsets.
