@@ -94,7 +94,6 @@ for w in ("cfg3", "cfg3b", "cfg2", "cfg2sf", "cfg5", "cfg5aug", "cfg4f", "cfg4b"
             pass
     traffic[w] = entry
     print(w, json.dumps(entry))
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 # the round's other records: the driver's line, bench lines, GPU suite, harness, SQ / TCC counter summaries
 for name in ("bench_default.json", "bench_lines.txt", "gputest.txt", "fuzz.txt"):
     f = os.path.join(ROOT, "gpurun_out", tag, name)
@@ -105,3 +104,23 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_sq*_*"))):
     kind = "cold_sq_tcc_counters" if "_sqcold_" in os.path.basename(d) else "sq_tcc_counters"
     if os.path.exists(os.path.join(d, "summary.txt")):
         shutil.copy(os.path.join(d, "summary.txt"), os.path.join(dst, "%s_%s.txt" % (w, kind)))
+# The COLD regime is the token workloads' primary `frac` since round 5: its kernel durations from the rocprofv3 kernel trace of
+# `bench.py --workload W --cold` (COLD=1 scripts/gpu_evidence.sh sq; the first lines of W_cold_sq_tcc_counters.txt: tens of thousands of
+# cold dispatches, a few hundred cache-resident ones among them) beside the event-timed figure of the un-profiled line.
+for w, entry in traffic.items():
+    f = os.path.join(dst, "%s_cold_sq_tcc_counters.txt" % w)
+    if not isinstance(entry, dict) or "cold" not in entry or not os.path.exists(f):
+        continue
+    for line in open(f):
+        k = short(line)
+        if k and " calls " in line and " avg " in line:
+            calls = int(line.split(" calls ")[1].split()[0])
+            avg_us = float(line.split(" avg ")[1].split()[0])
+            entry["cold"]["kernel"] = k
+            entry["cold"]["kernel_avg_us_from_trace"] = avg_us
+            entry["cold"]["trace_calls"] = calls
+            entry["cold"]["frac_from_trace"] = entry["algorithmic_bytes_per_launch"] / (avg_us * 1e-6) / 8e12
+            entry["cold"]["source"] = "profiles/%s/%s_cold_sq_tcc_counters.txt" % (tag, w)
+            print(w, "cold:", json.dumps(entry["cold"]))
+            break
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
