@@ -61,6 +61,9 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //                         waits, a patch launch behind it: round 5; 4: at every size), beyond that the flag form --, 1 never fused (the two launches), 2 the flag form of rounds 3-4 (token waves wait for their rows' augmentation;
 //                         written-through stores, any XCD), 3 the flag form with the hand-off inside one XCD where it applies
 //   expand_gate           k_expand_chunks: one pacing load in front of every wave (0 automatic: rows of 24 ... 63 bytes; 1 never; 2 always)
+//   raw_nibbles           the id scratch of the two-pass one-hot as nibbles (alphabets of at most 15 classes, expansion = k_expand_chunks): 0 automatic (rows of 24 ... 31 bytes), 1 never, 2 whenever they apply
+//   two_pass_slice_mb     the two-pass one-hot in SLICES of position rows whose id scratch stays cache-resident: 0 automatic (slices of <= 96 MB once the
+//                         id matrix exceeds 128 MB), > 0 that many MB per slice (whatever the size), < 0 never
 //   expand_rows1          the LDS-free expansion k_expand_rows1 (one-byte elements, rows of 3 ... 15 bytes): 0 automatic, 1 never, 2 whenever it applies
 //   tokens8_ring          LABS: N > 0: the (B,P) int8 token matrix through k_tokens_bp8_pipe (every wave walks N chunks with its offsets and
 //                         characters arriving by LDS-DMA two / four chunks ahead) instead of k_tokens_bp8_fast; lost, profiles/r05/tokens8_pipeline_lost.txt
@@ -79,7 +82,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
     X(nt_stores, 1) X(onehot_tb, 0) X(tile_order, 0) X(fill_mode, 0) X(onehot_path, 0) X(expand_pad, 0) X(tokenize_path, 0)   \
     X(fill_pad, 0) X(chunks_pad, 0) X(host_copy_threads, 0) X(tokenize_pad, 0) X(expand_slots, 0) X(tile_group, 0)             \
     X(bcl_path, 0) X(bcl_pad, 0) X(raw_mode, 0) X(workspace_cache, 0) X(tokens8, 0) X(tokens8_fast, 0) X(tokens8_lookup, 0)    \
-    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0) X(expand_gate, 0) X(host_pieces, 0) X(gather_small, 0) X(expand_rows1, 0)                                               \
+    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0) X(expand_gate, 0) X(host_pieces, 0) X(gather_small, 0) X(expand_rows1, 0) X(raw_nibbles, 0) X(two_pass_slice_mb, 0)                                               \
     L(chunks_cpw, 0) L(tokenize_nch, 0) L(expand_mode, 0) L(xcd_claim, 0) L(chunk_math, 0) L(tokens8_abl, 0) L(augment_mode, 0) L(tokens8_ring, 0)
 struct Tuning {
 #define BSQ_KNOB_FIELD(name, def) int32_t name = def;
@@ -119,8 +122,10 @@ uint32_t fused_failures();                              // bsq_tokens8.hip: toke
 void fused_failures_clear();
 // the (P,B) token matrix of any element type (pitch = elements between two position rows), no mask, 16-byte aligned rows
 bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out, int64_t pitch, bsq_dtype t = BSQ_I8);
+// nib (raw only): ids as nibbles, two sequences per byte (15 = no one), a row = pitch / 2 bytes; at most 15 classes, pitch % 32 == 0
 bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
-                             int64_t pitch, hipStream_t stream, bool raw = false, bsq_dtype t = BSQ_I8);
+                             int64_t pitch, hipStream_t stream, bool raw = false, bsq_dtype t = BSQ_I8, bool nib = false,
+                             int64_t tt0 = 0, int64_t ntt_count = 0);  // tt0, ntt_count: a SLICE of 64-position tiles (0 = all from tt0 on); `out` = its first row
 
 // bsq_tokens.hip: the channels-first (B, C, P) one-hot through the (B,P) chunk kernel's HOT form (the fallback of bsq_onehot_bcl_device for outputs
 // below its two-pass threshold and for masked batches)

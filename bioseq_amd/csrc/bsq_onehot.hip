@@ -160,6 +160,7 @@ struct EParams {
     unsigned int *claim;                   // CLAIM: 8 counters, 128 bytes apart, zeroed before the launch
     int64_t groups_per_class;              // CLAIM: slots-of-4 per class
     Div64 dv_pitch, dv_rb;                 // div64() constants of pitch and rowbytes (scalar chunk arithmetic)
+    int32_t nib;                           // 1: `tok` holds NIBBLES (k_expand_chunks<.., NIB>; never with the other expansion kernels)
     int64_t row_gap;                       // column block of a wider tensor: bytes between the end of one position row of the block and
                                            // the start of the next (0 = the whole tensor).  Non-zero only when pitch % 4096 == 0 and
                                            // head == 0: no chunk then straddles two position rows
@@ -213,10 +214,13 @@ __device__ __forceinline__ ChunkCoord chunk_coord(const EParams &p, int64_t k, i
 // stores in step.  Measured over 24 shapes (profiles/r04/expand_gate_sweep.txt): 28-byte rows (DNA f32: cfg4) +1-2 %, 32-byte rows +5.5 %,
 // 56-byte rows +4.7 %; rows of 64 bytes and more lose 5-7 % (cfg3 0.724 -> 0.774 ms), rows of 20 bytes and less lose 1-4 %: those
 // do not get it.  (Found as a by-product of the one-launch experiment, profiles/r04/onehot_fused_one_launch_lost.txt.)
+// NIB (round 5): the id matrix holds NIBBLES -- the id of (t, b) in bits 4 (b & 1) ... of byte (t * Bp + b) / 2 (Bp is even), 15 = no one:
+// the scratch of alphabets with at most 15 classes at half its bytes (see two_pass_nibbles).  A template flag: as a runtime one its
+// shift / mask arithmetic cost the BYTE form 13 % on cfg4 f32 (670 -> 759 us).
 #ifdef BSQ_LABS
-template <typename ST, bool NT, int MATH, bool GATE = false, int CLAIM = 0>
+template <typename ST, bool NT, int MATH, bool GATE = false, int CLAIM = 0, bool NIB = false>
 #else
-template <typename ST, bool NT, int MATH, bool GATE = false>
+template <typename ST, bool NT, int MATH, bool GATE = false, bool NIB = false>
 #endif
 __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     constexpr int PIECE = kChunk;             // bytes per wave
@@ -246,8 +250,11 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     if (!cc.live) return;
     const int64_t lo = cc.lo, b_lo = cc.b_lo, t_lo = cc.t_lo;
     const int32_t len = cc.len, skip = cc.skip, nr = cc.nr;
-    const uint8_t *tok = p.tok + t_lo * p.Bp + b_lo;
+    // NIB: the byte that holds the chunk's first id, and that id's half (Bp is even: the parity of t_lo * Bp + b_lo is b_lo's)
+    const uint8_t *tok = NIB ? p.tok + ((t_lo * p.Bp + b_lo) >> 1) : p.tok + t_lo * p.Bp + b_lo;
+    const int32_t par0 = NIB ? static_cast<int32_t>(b_lo & 1) : 0;
     if constexpr (GATE) tok += (gate == 0xFEFEFEFDu && p.nchunks < 0) ? 1 : 0;  // never taken: the token loads wait for the gate load
+    constexpr uint32_t nmask = NIB ? 0xFu : kNone;  // "no one"
     const int64_t wrap_at = p.B - b_lo;  // rows i >= wrap_at belong to position t_lo + 1 (or later)
     // scatter: row r_lo + i has its one at image byte i*rowbytes - skip + tok*sizeof(ST).
     // NS (1..4) coalesced token loads in flight per step, straight-line per NS: the number of 64-row slots a
@@ -265,13 +272,18 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
                 const int64_t w = (i - wrap_at) / p.B + 1;
                 a = i + w * (p.Bp - p.B);
             }
-            tk[q] = i < nr_s ? static_cast<uint32_t>(tok[a]) : kNone;
+            if constexpr (NIB) {
+                const int64_t ia = a + par0;
+                tk[q] = i < nr_s ? (static_cast<uint32_t>(tok[ia >> 1]) >> ((static_cast<uint32_t>(ia) & 1u) << 2)) & 0xFu : nmask;
+            } else {
+                tk[q] = i < nr_s ? static_cast<uint32_t>(tok[a]) : kNone;
+            }
         }
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const int32_t i = i0 + 64 * q + lane;
             const int32_t pos = i * rowbytes - skip + static_cast<int32_t>(tk[q]) * static_cast<int32_t>(sizeof(ST));
-            if (tk[q] != kNone && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
+            if (tk[q] != nmask && pos >= 0 && pos < len) *reinterpret_cast<ST *>(img + pos) = one;
         }
     };
     for (int32_t i0 = 0; i0 < nr_s; i0 += 256) {
@@ -715,7 +727,9 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     const dim3 grid(unsigned(groups * 8));
     // Occupancy cap through unused dynamic LDS (3 x (16 KiB image + 36 KiB) = 156 KiB <= 160 KiB; 37 KiB already
     // rounds up to 2 per CU).  Rows >= 64 B (one token load per lane and chunk): 3 workgroups per CU stream
-    // cfg3 at 7.5-7.8 TB/s, 8 at 6.3, 4 at 6.7, 2 at 5.5.  Smaller rows: 5 workgroups per CU (16 KiB + 16 KiB each).
+    // cfg3 at 7.5-7.8 TB/s, 8 at 6.3, 4 at 6.7, 2 at 5.5.  Smaller rows: 16 KiB + the 16-KiB image -- FOUR workgroups per CU, not the five
+    // the arithmetic suggests (round 5, profiles/r05/nibble_ids_lab.txt: the step from four to five lies between pads of 16 384 and 15 360
+    // bytes; byte ids 673 us at four, 690 at five, 703 at six on cfg4 f32).
     // In round 1 a cap HURT the 1M x 160 x 28-byte batch (0.90 ms at 5 per CU vs 0.78 uncapped) -- because the token pass
     // then fetched every character three times and pushed its own scratch out of the Infinity Cache; with the XCD-aware
     // tile order the token loads of the expansion are cache hits and the cap pays: 0.687 ms at 5, 0.689 at 4, 0.725 at
@@ -742,7 +756,9 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
 #endif
     const int padv = bsq_internal::tuning().expand_pad;
     const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;
-    const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : (big_rows ? size_t(36864) : size_t(16384)));
+    // (nibble ids, rows below 64 bytes: 12 KiB = FIVE workgroups per CU -- 16 KiB + the 16-KiB image + the kernel's few bytes of static LDS
+    //  round up to four; cfg4 f32 with nibbles 714 us at four, 648 at five, 662 at six; byte ids 673 / 690 / 703: profiles/r05/nibble_ids_lab.txt)
+    const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : (big_rows ? size_t(36864) : (e.nib ? size_t(12288) : size_t(16384))));
 #ifdef BSQ_LABS
     if (bsq_internal::tuning().xcd_claim == 1) {  // measurement only: placement-independent chunk classes (see the kernel)
         static unsigned int *counters[16] = {};
@@ -800,6 +816,20 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     const int gk = bsq_internal::tuning().expand_gate;
     const int64_t rowb = e.C * int64_t(sizeof(ST));
     const bool gated = (gk == 2 || (gk == 0 && rowb >= 24 && rowb < 64)) && e.Bp >= 256;
+    if constexpr (sizeof(ST) >= 2) {
+        if (e.nib) {  // ids as nibbles (two_pass_nibbles)
+#ifdef BSQ_LABS
+#define BSQ_EXPN(NTV, GV) hipLaunchKernelGGL((k_expand_chunks<ST, NTV, 0, GV, 0, true>), grid, dim3(kThreads), pad, s, e)
+#else
+#define BSQ_EXPN(NTV, GV) hipLaunchKernelGGL((k_expand_chunks<ST, NTV, 0, GV, true>), grid, dim3(kThreads), pad, s, e)
+#endif
+            if (bsq_internal::nontemporal_stores()) { if (gated) BSQ_EXPN(true, true); else BSQ_EXPN(true, false); }
+            else { if (gated) BSQ_EXPN(false, true); else BSQ_EXPN(false, false); }
+#undef BSQ_EXPN
+            return check_launch("k_expand_chunks<nibbles>");
+        }
+    }
+    if (e.nib) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "nibble ids: elements of 2 bytes and more");
     if (bsq_internal::nontemporal_stores()) {
         if (gated) hipLaunchKernelGGL((k_expand_chunks<ST, true, 0, true>), grid, dim3(kThreads), pad, s, e);
         else hipLaunchKernelGGL((k_expand_chunks<ST, true, 0>), grid, dim3(kThreads), pad, s, e);
@@ -812,10 +842,9 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
 
 // Two-pass one-hot: raw (P,B) tokens into `workspace` (P*B bytes), then the chunk expansion.
 int64_t two_pass_pitch(int64_t B) { return (B + kRawTB - 1) / kRawTB * kRawTB; }
-size_t two_pass_workspace_bytes(int64_t B, int64_t P) { return size_t(two_pass_pitch(B)) * size_t(P); }
 
 // Pass 1: raw tokens (kNone = no token) of the batch into a (P, pitch) uint8 matrix.
-bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_t s) {
+bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_t s, bool nib = false, int64_t tt0 = 0, int64_t ntt_count = 0) {
     k.out = tokens;
     k.out_pitch = pitch;
     k.aligned = reinterpret_cast<uintptr_t>(tokens) % 16 == 0 && pitch % 16 == 0;  // every row starts 16-byte aligned
@@ -824,7 +853,8 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
     // no mask, 16-byte aligned rows: the register-transposed tiles of k_tokens_pb8_fast in raw-id mode (round 3; knob
     // tokens_pb8 = 1 or any raw_mode != 0: k_tokens_raw)
     if (!k.mask && k.desc && bsq_internal::tuning().raw_mode == 0 && bsq_internal::tokens_pb8_applicable(k.desc, k.B, k.P, tokens, pitch))
-        return bsq_internal::launch_tokens_pb8(k.desc, k.chars, k.offsets, k.B, k.P, tokens, pitch, s, true);
+        return bsq_internal::launch_tokens_pb8(k.desc, k.chars, k.offsets, k.B, k.P, tokens, pitch, s, true, BSQ_I8, nib, tt0, ntt_count);
+    if (nib || tt0 != 0 || ntt_count != 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "nibble ids / slices need the register-transposed raw pass");
     const dim3 grid(unsigned(tile_grid(k, k.ntt)));
     // knob "raw_mode": 0 / 1 k_tokens_raw; 2 k_tokens_raw2 (register transpose) with the LDS byte table, 3 with the
     // register table.  k_tokens_raw2 is an experiment that LOST (profiles/r02/raw_lab.txt: cfg2 as (P,B) int8 tokens
@@ -853,9 +883,10 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
 
 // Pass 2: the (P, B, C) one-hot as the flat expansion of a (P, pitch) raw token matrix.
 bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int64_t P, int32_t C, size_t sz,
-                            uint64_t one_bits, void *out, hipStream_t s, int64_t row_gap = 0) {
+                            uint64_t one_bits, void *out, hipStream_t s, int64_t row_gap = 0, bool nib = false) {
     EParams e;
     e.row_gap = row_gap;
+    e.nib = nib ? 1 : 0;  // (k_expand_chunks only: see two_pass_nibbles)
     e.tok = tokens;
     e.B = B;
     e.Bp = pitch;
@@ -883,12 +914,77 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
     }
 }
 
-bsq_status onehot_two_pass(KParams &k, size_t sz, void *workspace, hipStream_t s, int64_t row_gap = 0) {
-    void *out = k.out;
-    const int64_t pitch = two_pass_pitch(k.B);  // padded: every scratch row is aligned, full-width vector stores
-    const bsq_status st = launch_tokens_raw(k, workspace, pitch, s);
+// How a two-pass one-hot is run (round 5).
+//  * nib: ids as NIBBLES in the scratch -- alphabets of at most 15 classes (DNA, the reduced amino alphabets; 15 = no one) whose raw pass is
+//    k_tokens_pb8_fast and whose expansion is k_expand_chunks (elements of 2 bytes and more: one-byte rows of <= 15 bytes expand through
+//    k_expand_rows1, which reads byte ids).  The scratch is written and re-read at half its bytes.  Automatic for rows of 24 ... 31 bytes,
+//    where it wins on every shape tried (cfg4 f32 673 -> 648 us; 0.5-4 % elsewhere); other row widths lose 1-3 % to the byte form
+//    (profiles/r05/nibble_ids_lab.txt).  Knob "raw_nibbles": 1 never, 2 whenever they apply.
+//  * tiles_per_slice: the matrix in SLICES of 64-position tiles, raw pass and expansion of one slice after the other through ONE scratch of
+//    a slice's size.  The expansion runs at the write roof only while the ids it reads come out of the Infinity Cache: with 268 MB of ids
+//    (262 144 x 1024 AMINO20) the int8 one-hot fell from 0.85 to 0.68 of the roof and the f32 one from 0.94 to 0.72, 2M x 160 DNA f32 to 0.59.
+//    Slices of <= 96 MB keep every size at the small batches' rate, for two more launches per slice.  Knob "two_pass_slice_mb".
+struct TwoPassPlan {
+    int64_t pitch;            // ids per scratch row
+    bool nib;
+    int64_t ntt, tiles_per_slice;
+    size_t ws_bytes;
+};
+TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
+    const auto &tn = bsq_internal::tuning();
+    TwoPassPlan pl;
+    pl.pitch = two_pass_pitch(k.B);  // padded: every scratch row is aligned, full-width vector stores
+    pl.ntt = (k.P + kTT - 1) / kTT;
+    const int64_t rb = k.C * int64_t(sz);
+    // the register-transposed raw pass (no mask, foldable or LDS table, ids < 251): what nibbles and slices are built on
+    const bool pb8 = !k.mask && k.desc && tn.raw_mode == 0 &&
+                     bsq_internal::tokens_pb8_applicable(k.desc, k.B, k.P, reinterpret_cast<const void *>(uintptr_t(256)), pl.pitch);
+    const bool nib_ok = pb8 && k.C <= 15 && sz >= 2 && tn.expand_mode == 0 && tn.xcd_claim == 0 && tn.chunk_math == 0;
+    // (automatic: rows of 24 ... 31 bytes, and every id matrix beyond 128 MB as bytes -- half the scratch to keep resident, slices of twice the rows)
+    pl.nib = nib_ok && (tn.raw_nibbles == 2 || (tn.raw_nibbles == 0 && ((rb >= 24 && rb < 32) || pl.pitch * k.P > (int64_t(128) << 20))));
+    const int64_t row_bytes = pl.pitch >> (pl.nib ? 1 : 0), all_bytes = row_bytes * k.P;
+    pl.tiles_per_slice = pl.ntt;
+    const int64_t mb = tn.two_pass_slice_mb;
+    // (a column block -- row_gap != 0 -- needs every slice to start on a chunk boundary like the block itself: no chunk may straddle two rows)
+    const bool gap_ok = row_gap == 0 || (kTT * (k.B * rb + row_gap)) % kChunk == 0;
+    if (pb8 && mb >= 0 && tn.expand_mode == 0 && gap_ok) {
+        const int64_t slice_bytes = (mb > 0 ? mb : 96) << 20;
+        if (mb > 0 || all_bytes > (int64_t(128) << 20)) {
+            const int64_t tile_bytes = row_bytes * kTT;
+            const int64_t max_tiles = slice_bytes / tile_bytes > 1 ? slice_bytes / tile_bytes : 1;  // (a single tile may exceed the target: B beyond 1.5 M)
+            const int64_t nslices = (pl.ntt + max_tiles - 1) / max_tiles;
+            pl.tiles_per_slice = (pl.ntt + nslices - 1) / nslices;  // balanced, none above max_tiles
+        }
+    }
+    const int64_t rows = pl.tiles_per_slice * kTT < k.P ? pl.tiles_per_slice * kTT : k.P;
+    pl.ws_bytes = size_t(pl.tiles_per_slice == pl.ntt ? pl.pitch * k.P : row_bytes * rows);  // (one slice: the byte-sized scratch as before)
+    return pl;
+}
+
+// The caller holds nothing: the scratch is acquired here (shared by the calls of one stream -- workspace cache --, so the launches of a
+// call are enqueued back to back under the workspace mutex).
+bsq_status onehot_two_pass(KParams &k, size_t sz, hipStream_t s, int64_t row_gap = 0) {
+    const TwoPassPlan pl = two_pass_plan(k, sz, row_gap);
+    std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());
+    void *ws = nullptr;
+    bsq_status st = bsq_internal::workspace_acquire(pl.ws_bytes, s, &ws);
     if (st != BSQ_OK) return st;
-    return launch_expansion(static_cast<const uint8_t *>(workspace), pitch, k.B, k.P, k.C, sz, k.one_bits, out, s, row_gap);
+    uint8_t *out = static_cast<uint8_t *>(k.out);
+    const int64_t out_row = k.B * k.C * int64_t(sz) + row_gap;  // bytes from one position row of the result to the next
+    if (pl.tiles_per_slice >= pl.ntt) {
+        st = launch_tokens_raw(k, ws, pl.pitch, s, pl.nib);
+        if (st == BSQ_OK) st = launch_expansion(static_cast<const uint8_t *>(ws), pl.pitch, k.B, k.P, k.C, sz, k.one_bits, out, s, row_gap, pl.nib);
+    } else {
+        for (int64_t tt0 = 0; tt0 < pl.ntt && st == BSQ_OK; tt0 += pl.tiles_per_slice) {
+            const int64_t cnt = pl.ntt - tt0 < pl.tiles_per_slice ? pl.ntt - tt0 : pl.tiles_per_slice;
+            const int64_t p0 = tt0 * kTT, p1 = (tt0 + cnt) * kTT < k.P ? (tt0 + cnt) * kTT : k.P;
+            st = launch_tokens_raw(k, ws, pl.pitch, s, pl.nib, tt0, cnt);  // rows p0 .. p1 - 1 of the id matrix into the scratch
+            if (st == BSQ_OK)
+                st = launch_expansion(static_cast<const uint8_t *>(ws), pl.pitch, k.B, p1 - p0, k.C, sz, k.one_bits, out + p0 * out_row, s, row_gap, pl.nib);
+        }
+    }
+    bsq_internal::workspace_release(ws, s);
+    return st;
 }
 
 template <typename T>
@@ -1006,15 +1102,9 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     // multiple of 32 KiB (each XCD then keeps to its own chunk columns) and B is moderate, or B is small.
     if (path == 3) return onehot_chunk_owner(k, sz, s);
     if (path == 2) {
-        // The scratch is shared by the calls of one stream (workspace cache): the two launches of a call must be enqueued
-        // back to back, so concurrent host threads take turns here (enqueueing takes microseconds; the GPU work overlaps).
-        std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());
-        void *ws = nullptr;
-        bsq_status wst = bsq_internal::workspace_acquire(two_pass_workspace_bytes(B, P), s, &ws);
-        if (wst != BSQ_OK) return wst;
-        wst = onehot_two_pass(k, sz, ws, s);
-        bsq_internal::workspace_release(ws, s);
-        return wst;
+        // (the scratch is shared by the calls of one stream -- workspace cache --: onehot_two_pass enqueues its launches back to back
+        //  under the workspace mutex; concurrent host threads take turns there: enqueueing takes microseconds, the GPU work overlaps)
+        return onehot_two_pass(k, sz, s);
     }
     switch (sz) {
     case 1: return dispatch_onehot_tile<uint8_t>(k, s);
@@ -1080,13 +1170,7 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
         }
     }
     if (block_path != 1 && rb >= 16 && block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0) {
-        std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());
-        void *ws = nullptr;
-        bsq_status wst = bsq_internal::workspace_acquire(two_pass_workspace_bytes(B, P), s, &ws);
-        if (wst != BSQ_OK) return wst;
-        wst = onehot_two_pass(k, sz, ws, s, (row_seqs - B) * k.C * int64_t(sz));
-        bsq_internal::workspace_release(ws, s);
-        return wst;
+        return onehot_two_pass(k, sz, s, (row_seqs - B) * k.C * int64_t(sz));
     }
     // otherwise the tiled kernel: a workgroup owns (sequence tile x 64 positions) and writes one row SEGMENT per position, so a row
     // pitch other than B * C is just another stride

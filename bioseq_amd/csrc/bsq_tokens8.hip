@@ -789,11 +789,16 @@ __device__ __forceinline__ uint4 widen_tokens(const uint8_t *src) {
 // UA: rows (pitch * SZ bytes) or the output are only element-aligned -- any batch size.  The 16-byte stores go out unaligned
 // (gfx950 splits them in hardware), the pieces that cross the end of a row as single elements, and every XCD walks its own
 // CONTIGUOUS range of sequence tiles: the memory sectors that two neighbouring tiles share are then written through ONE L2.
-template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false, bool UA = false>
+// NIB (round 5, raw ids of alphabets with at most 15 classes -- DNA and the reduced amino alphabets): the id matrix leaves as NIBBLES, two
+// sequences per byte (sequence 2 m in the low half of byte m of a position row, 255 -> 15 = no one), a row of the tile as TB / 2 bytes: the
+// scratch of the two-pass one-hot is written and re-read at half its bytes (cfg4 f32: 160 -> 80 MB of 318 in the raw pass).
+template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false, bool UA = false, bool NIB = false>
 __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
                                                               uint8_t *__restrict__ out, int64_t pitch, uint32_t B, uint32_t P,
                                                               uint32_t ntb, uint32_t ntt, uint32_t magic, uint32_t shift, int32_t room,
-                                                              uint32_t packed, T8Tab tab, T8Rules rules, T8Lut lut) {
+                                                              uint32_t packed, uint32_t tt0, T8Tab tab, T8Rules rules, T8Lut lut) {
+    // (tt0: the launch covers the position tiles tt0 .. tt0 + ntt - 1 -- a SLICE of the matrix; `out` is then the address row 0 would
+    //  have, so that row t of the slice lands at out + t * pitch as everywhere below)
     constexpr int TT = 64, STRIDE = TB + 8, PASSES = TB / 64;
     static_assert(TB % 64 == 0 && (STRIDE / 4) % 32 == 2, "tile shape");
     __shared__ __align__(16) uint4 s_rule[2][18];
@@ -816,7 +821,7 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     if (tb >= ntb) return;
     const uint32_t bos = packed & 1u, none_v = (packed & 2u) ? 0xFFu : 0u;
     const uint32_t bos_id = (packed >> 8) & 0xFFu;
-    const int32_t t0 = static_cast<int32_t>(tt) * TT;
+    const int32_t t0 = static_cast<int32_t>(tt + tt0) * TT;
     const int la = (lane >> 2) & 3, lb = lane & 3;
 
     // ---- the spans first (the four lanes of a sequence read the same two words) ----
@@ -933,7 +938,30 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     constexpr int N = 16 / SZ;     // tokens per 16-byte store
     constexpr int PPR = TB / N;    // stores per tile row
     static_assert((TT * PPR) % kThreads == 0 && (PPR & (PPR - 1)) == 0, "row walk");
-    if constexpr (!UA) {
+    if constexpr (NIB) {
+        static_assert(!NIB || (SZ == 1 && !UA && !FLT), "nibble ids: the raw byte matrix");
+        constexpr int PPRN = TB / 32;  // 16-byte stores per tile row: 32 ids each
+        static_assert((TT * PPRN) % kThreads == 0 && (PPRN & (PPRN - 1)) == 0, "row walk");
+#pragma unroll
+        for (int f0 = 0; f0 < TT * PPRN; f0 += kThreads) {
+            const int f = f0 + tid;
+            const int rr = f / PPRN, piece = f % PPRN;
+            const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
+            const int64_t col = static_cast<int64_t>(tb) * TB + piece * 32;
+            const uint2 *src = reinterpret_cast<const uint2 *>(s_t + rr * STRIDE + piece * 32);
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 d = src[q];
+                uint32_t lo = d.x & 0x0F0F0F0Fu, hi = d.y & 0x0F0F0F0Fu;
+                lo |= lo >> 4;  // byte 0: id 0 | id 1 << 4, byte 2: id 2 | id 3 << 4
+                hi |= hi >> 4;
+                o[q] = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
+            }
+            if (t < static_cast<int32_t>(P) && col < ncols)
+                store16<NT>(out + ((static_cast<int64_t>(t) * pitch + col) >> 1), uint4{o[0], o[1], o[2], o[3]});
+        }
+    } else if constexpr (!UA) {
 #pragma unroll
         for (int f0 = 0; f0 < TT * PPR; f0 += kThreads) {
             const int f = f0 + tid;
@@ -1376,9 +1404,11 @@ bool tokens_pb8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *
 }
 
 bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P, void *out,
-                             int64_t pitch, hipStream_t s, bool raw, bsq_dtype t) {
+                             int64_t pitch, hipStream_t s, bool raw, bsq_dtype t, bool nib, int64_t tt0, int64_t ntt_count) {
     const uint32_t none_v = raw ? 0xFFu : 0u;
     if (raw && t != BSQ_I8) return set_error(BSQ_ERR_INVALID_ARG, "raw ids are bytes");
+    if (nib && (!raw || pitch % 32 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0 || bsq_alphabet_size(d) > 15))
+        return set_error(BSQ_ERR_INVALID_ARG, "nibble ids: raw mode, at most 15 classes, rows of a multiple of 32 ids");
     T8Tab tab;
     const bool foldable = fold_table(d->lut, tab.t, none_v);
     // knob "tokens8_lookup": 0 automatic (registers when the table folds), 1 LDS byte table, 2 registers
@@ -1411,7 +1441,11 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     // one tile shape: 256 sequences x 64 positions (512 x 64 and 512 x 32 were built and measured slower:
     // profiles/r03/pb8_coalesced_ab.txt, pb8_512x32_tile_lost.txt)
     const int TB = 256, TT = 64;
-    const int64_t ntb = (B + TB - 1) / TB, ntt = (P + TT - 1) / TT;
+    const int64_t ntb = (B + TB - 1) / TB, ntt_all = (P + TT - 1) / TT;
+    if (tt0 < 0 || tt0 >= ntt_all || ntt_count < 0 || tt0 + ntt_count > ntt_all) return set_error(BSQ_ERR_INVALID_ARG, "position tiles of the slice");
+    const int64_t ntt = ntt_count > 0 ? ntt_count : ntt_all - tt0;  // the launch's position tiles: tt0 .. tt0 + ntt - 1 (`out` = the slice's first row)
+    // the address row 0 of the matrix would have (the kernel indexes rows by their absolute position)
+    out = static_cast<uint8_t *>(out) - ((tt0 * TT * pitch * int64_t(bsq_dtype_size(t))) >> (nib ? 1 : 0));
     const int64_t blocks = (ntb + 7) / 8 * 8 * ntt;
     if (blocks >= (int64_t(1) << 31)) return set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const bool ua = !((pitch * int64_t(bsq_dtype_size(t))) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
@@ -1422,7 +1456,7 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
 #define BSQ_PB8U(NTV, LKV, SZV, FLTV, UAV)                                                                                             \
     hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, 256, LKV, SZV, FLTV, UAV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,  \
                        static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift,    \
-                       room, packed, tab, rules, lut)
+                       room, packed, uint32_t(tt0), tab, rules, lut)
 #define BSQ_PB8(NTV, LKV, SZV, FLTV)                                       \
     do {                                                                   \
         if constexpr (SZV <= 2 && !FLTV) {                                 \
@@ -1437,6 +1471,17 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
         if (lk == 2) { if (nt) BSQ_PB8(true, 1, SZV, FLTV); else BSQ_PB8(false, 1, SZV, FLTV); } \
         else { if (nt) BSQ_PB8(true, 0, SZV, FLTV); else BSQ_PB8(false, 0, SZV, FLTV); }         \
     } while (0)
+    if (nib) {  // (raw: plain stores, aligned rows)
+#define BSQ_PB8N(LKV)                                                                                                                     \
+    hipLaunchKernelGGL((k_tokens_pb8_fast<false, 256, LKV, 1, false, false, true>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, \
+                       chars, static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift,   \
+                       room, packed, uint32_t(tt0), tab, rules, lut)
+        if (lk == 2) BSQ_PB8N(1); else BSQ_PB8N(0);
+#undef BSQ_PB8N
+        const hipError_t en = hipGetLastError();
+        if (en != hipSuccess) return set_hip_error("k_tokens_pb8_fast<nibbles>", en);
+        return BSQ_OK;
+    }
     switch (t) {
     case BSQ_I8: BSQ_PB8_T(1, false); break;
     case BSQ_I16: BSQ_PB8_T(2, false); break;
