@@ -96,7 +96,9 @@ def test_nibble_scratch_column_blocks(gpu, bsq, oracle, knobs):
 
 
 @pytest.mark.parametrize("key,flags,letters,dc", [("DNA4", (1, 1, 1), "ACGT", "f"), ("DNA5", (0, 0, 0), "ACGTN", "h"), ("AMINO20", (0, 0, 0), "ACDEFGHIKLMNPQRSTVWY", "B"),
-                                                  ("AMINO20", (1, 1, 1), "ACDEFGHIKLMNPQRSTVWY", "f"), ("SEB8", (1, 0, 1), "ACDEFGHIKLMNPQRSTVWY", "d")])
+                                                  ("AMINO20", (1, 1, 1), "ACDEFGHIKLMNPQRSTVWY", "f"), ("SEB8", (1, 0, 1), "ACDEFGHIKLMNPQRSTVWY", "d"),
+                                                  # one-byte rows of 14 / 7 bytes: the sliced expansion is k_expand_rows1 (byte ids)
+                                                  ("SEB14", (0, 0, 0), "ACDEFGHIKLMNPQRSTVWY", "B"), ("DNA4", (1, 1, 1), "ACGT", "B")])
 def test_two_pass_slices_equal_the_oracle(gpu, bsq, oracle, knobs, key, flags, letters, dc):
     """two_pass_slice_mb = 1: every shape below is cut into 2 ... 16 slices of whole 64-position tiles (the last one ragged: padlen % 64 != 0),
     results on and off a 4-KiB boundary (a slice then starts inside a chunk: both neighbours write their part of it)."""
