@@ -1069,8 +1069,16 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
 #endif
         // (unmasked: the raw-id pass runs in k_tokens_pb8_fast unless a knob keeps it in k_tokens_raw -- see launch_tokens_raw)
         const bool rows1 = bsq_dtype_size(t) == 1 && rb >= 3 && rb <= 15 && bsq_internal::tuning().expand_rows1 != 1;
-        if (bsq_internal::tuning().raw_mode == 0 && bsq_internal::tuning().tokens_pb8 != 1)
+        if (bsq_internal::tuning().raw_mode == 0 && bsq_internal::tuning().tokens_pb8 != 1) {
+            KParams kp;  // (what two_pass_plan looks at)
+            kp.desc = d;
+            kp.mask = nullptr;
+            kp.B = B;
+            kp.P = P;
+            kp.C = bsq_alphabet_size(d);
+            if (!rows1 && two_pass_plan(kp, bsq_dtype_size(t), 0).nib) return "k_tokens_pb8_fast<raw, nibbles>+k_expand_chunks<nibbles>";
             return rows1 ? "k_tokens_pb8_fast<raw>+k_expand_rows1" : "k_tokens_pb8_fast<raw>+k_expand_chunks";
+        }
         return rows1 ? "k_tokens_raw+k_expand_rows1" : "k_tokens_raw+k_expand_chunks";
     }
     case 3: return "k_onehot_chunks";
@@ -1231,18 +1239,32 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
     if (bcl_path != 1 && (bcl_path == 2 || total_bytes >= (int64_t(256) << 20)) && k.C <= 250 &&
         reinterpret_cast<uintptr_t>(out) % 16 == 0 && P % 16 == 0 && B * int64_t(k.C) * P < (int64_t(1) << 51) &&
         bsq_internal::tokens_bp8_applicable(d, B, P, out)) {
-        std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());  // see bsq_onehot_device
+        // In SLICES of sequences once the (B,P) id matrix exceeds 128 MB (round 5: like the seq-first two-pass form, the expansion holds the
+        // roof only while its ids come out of the Infinity Cache -- 262 144 x 1024 f32: 0.60 of the roof in one piece).  A sequence's rows
+        // are contiguous in the (B,C,P) result, so a slice is simply a smaller batch: sequences [b0, b0 + nb) with offsets + b0 (the
+        // offsets are absolute), nb a multiple of 256 (every slice then starts on a 4-KiB boundary of the result when the result does).
+        // Knob "two_pass_slice_mb" as in onehot_two_pass.
+        const int64_t mb = bsq_internal::tuning().two_pass_slice_mb;
+        int64_t per_slice = B;
+        if (mb >= 0 && (mb > 0 || B * P > (int64_t(128) << 20))) {
+            per_slice = (((mb > 0 ? mb : 96) << 20) / P) / 256 * 256;
+            if (per_slice < 256) per_slice = 256;
+        }
+        std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());  // see onehot_two_pass
         void *ws = nullptr;
-        bsq_status wst = bsq_internal::workspace_acquire(size_t(B) * size_t(P), s, &ws);
+        bsq_status wst = bsq_internal::workspace_acquire(size_t(per_slice < B ? per_slice : B) * size_t(P), s, &ws);
         if (wst != BSQ_OK) return wst;
-        wst = bsq_internal::launch_tokens_bp8(d, chars, offsets, B, P, ws, s, true, mask_or_null);
-        if (wst == BSQ_OK) {
-            const uint8_t *tk = static_cast<const uint8_t *>(ws);
+        const uint8_t *tk = static_cast<const uint8_t *>(ws);
+        for (int64_t b0 = 0; b0 < B && wst == BSQ_OK; b0 += per_slice) {
+            const int64_t nb = B - b0 < per_slice ? B - b0 : per_slice;
+            uint8_t *dst = static_cast<uint8_t *>(out) + b0 * int64_t(k.C) * P * int64_t(sz);
+            wst = bsq_internal::launch_tokens_bp8(d, chars, offsets + b0, nb, P, ws, s, true, mask_or_null);
+            if (wst != BSQ_OK) break;
             switch (sz) {
-            case 1: wst = launch_expand_bcl<uint8_t>(tk, B, P, k.C, k.one_bits, out, s); break;
-            case 2: wst = launch_expand_bcl<uint16_t>(tk, B, P, k.C, k.one_bits, out, s); break;
-            case 4: wst = launch_expand_bcl<uint32_t>(tk, B, P, k.C, k.one_bits, out, s); break;
-            default: wst = launch_expand_bcl<uint64_t>(tk, B, P, k.C, k.one_bits, out, s); break;
+            case 1: wst = launch_expand_bcl<uint8_t>(tk, nb, P, k.C, k.one_bits, dst, s); break;
+            case 2: wst = launch_expand_bcl<uint16_t>(tk, nb, P, k.C, k.one_bits, dst, s); break;
+            case 4: wst = launch_expand_bcl<uint32_t>(tk, nb, P, k.C, k.one_bits, dst, s); break;
+            default: wst = launch_expand_bcl<uint64_t>(tk, nb, P, k.C, k.one_bits, dst, s); break;
             }
         }
         bsq_internal::workspace_release(ws, s);

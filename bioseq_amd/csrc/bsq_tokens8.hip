@@ -735,7 +735,7 @@ __global__ __launch_bounds__(kThreads) void k_patch_tokens(const uint2 *__restri
 // k_tokens_pb8_fast: the (P,B) token matrix -- batch_tokenize's DEFAULT layout (batch_first=False, tokenize.cpp:82-98) --
 // of 1-, 2- and 8-byte elements without a mask (SZ / FLT below; UA: rows that are only element-aligned), and the raw-id pass of
 // the two-pass one-hot.  Round 3.
-// k_tokens_raw (bsq_kernels.hip) spends ~40 vector and ~10.6 LDS instructions per word of four tokens (byte lookups
+// k_tokens_raw (bsq_tiles.h) spends ~40 vector and ~10.6 LDS instructions per word of four tokens (byte lookups
 // in an LDS table, four transposed ds_write_b8 per word, spans staged through LDS) and sits at 0.59 of the HBM roof on
 // cfg2's shape, bound by instruction issue in BOTH pipes (profiles/r02/cfg2sf_sq_tcc_counters.txt).  Here, on a tile of
 // TB sequences x 64 positions:

@@ -113,3 +113,31 @@ def test_bcl_two_pass_form_equals_single_pass_and_oracle(gpu, bsq, oracle, key, 
                         capi.check(lib.bsq_tuning_set(b"bcl_path", 0))
                 assert got[2].tobytes() == exp.tobytes(), (B, P, d, m is not None)
                 assert got[1].tobytes() == exp.tobytes(), (B, P, d, m is not None)
+
+
+@pytest.mark.parametrize("key,flags", [("AMINO20", (0, 0, 0)), ("DNA", (1, 1, 1))])
+def test_bcl_two_pass_in_slices_of_sequences(gpu, bsq, oracle, key, flags):
+    """Round 5: the two-pass channels-first path in SLICES of sequences (one id scratch of a slice's size; automatic beyond 128 MB of ids,
+    forced here with two_pass_slice_mb = 1: slices of 2048 / 1792 / 512 sequences, the last one ragged) against the transposed oracle,
+    with and without a mask, int8 and float32."""
+    import torch
+    from bioseq_amd import capi, synth
+    lib = capi.load()
+    tok, ora = bsq.Tokenizer(key, *flags), oracle.OracleTokenizer(key, *flags)
+    try:
+        capi.check(lib.bsq_tuning_set(b"bcl_path", 2))
+        for B, P in ((5000, 512), (4000, 576), (1300, 2048)):
+            chars, offs = synth.synth_packed(B + P, B, 0, P - 2, synth.DIRTY)
+            dch, dof = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
+            mask = (np.random.default_rng(B + P).random(chars.size) < 0.7).astype(np.uint8)
+            dm = torch.from_numpy(mask).to(gpu)
+            for d in "bf":
+                for m, mdev in ((None, None), (mask, dm)):
+                    exp = np.ascontiguousarray(ora.onehot_packed(chars, offs, P, d, mask=m).transpose(1, 2, 0))
+                    for mb in (1, -1):
+                        capi.check(lib.bsq_tuning_set(b"two_pass_slice_mb", mb))
+                        got = tok.onehot_packed(dch, dof, P, d, mask=mdev, layout="bcl").cpu().numpy()
+                        assert got.tobytes() == exp.tobytes(), (key, B, P, d, m is not None, mb)
+    finally:
+        capi.check(lib.bsq_tuning_set(b"bcl_path", 0))
+        capi.check(lib.bsq_tuning_set(b"two_pass_slice_mb", 0))
