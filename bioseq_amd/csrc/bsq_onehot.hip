@@ -926,7 +926,7 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
 //    Slices of <= 96 MB keep every size at the small batches' rate, for two more launches per slice.  Knob "two_pass_slice_mb".
 struct TwoPassPlan {
     int64_t pitch;            // ids per scratch row
-    bool nib;
+    bool nib, nib_ok;         // ids as nibbles; whether they could be
     int64_t ntt, tiles_per_slice;
     size_t ws_bytes;
 };
@@ -941,6 +941,7 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
                      bsq_internal::tokens_pb8_applicable(k.desc, k.B, k.P, reinterpret_cast<const void *>(uintptr_t(256)), pl.pitch);
     const bool nib_ok = pb8 && k.C <= 15 && sz >= 2 && tn.expand_mode == 0 && tn.xcd_claim == 0 && tn.chunk_math == 0;
     // (automatic: rows of 24 ... 31 bytes, and every id matrix beyond 128 MB as bytes -- half the scratch to keep resident, slices of twice the rows)
+    pl.nib_ok = nib_ok && tn.raw_nibbles != 1;
     pl.nib = nib_ok && (tn.raw_nibbles == 2 || (tn.raw_nibbles == 0 && ((rb >= 24 && rb < 32) || pl.pitch * k.P > (int64_t(128) << 20))));
     const int64_t row_bytes = pl.pitch >> (pl.nib ? 1 : 0), all_bytes = row_bytes * k.P;
     pl.tiles_per_slice = pl.ntt;
@@ -959,6 +960,30 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
     const int64_t rows = pl.tiles_per_slice * kTT < k.P ? pl.tiles_per_slice * kTT : k.P;
     pl.ws_bytes = size_t(pl.tiles_per_slice == pl.ntt ? pl.pitch * k.P : row_bytes * rows);  // (one slice: the byte-sized scratch as before)
     return pl;
+}
+
+// Position slices thinner than four tiles are a poor cut: every 64-position tile's raw pass fetches the 128-byte lines its neighbour
+// fetched (short reads: 150 characters = three tiles, each touching ~1.5 lines per sequence), and with B beyond 1.5 M a single tile is
+// too much id matrix already -- cfg4 f32 at 2 M / 4 M reads ran at 0.80 / 0.63 of the roof that way.  Such batches are cut by SEQUENCES
+// instead: column blocks of nb sequences (a multiple of 4096 / gcd(row bytes, 4096), so that every block's rows are whole chunks), each a
+// two-pass stream of its own with a gap after every position row (bsq_onehot_block_device) whose ids fit the slice target in one piece.
+// Returns nb, or 0 when the batch is not to be cut this way.
+int64_t two_pass_sequence_block(const KParams &k, size_t sz, const void *out) {
+    const TwoPassPlan pl = two_pass_plan(k, sz, 0);
+    if (pl.tiles_per_slice >= pl.ntt || pl.tiles_per_slice >= 4 || reinterpret_cast<uintptr_t>(out) % kChunk != 0) return 0;
+    const int64_t mb = bsq_internal::tuning().two_pass_slice_mb;
+    const int64_t rb = k.C * int64_t(sz);
+    int64_t g = rb, h = kChunk;
+    while (h) {
+        const int64_t r = g % h;
+        g = h;
+        h = r;
+    }
+    const int64_t m = kChunk / g;  // sequences per period of (b * rb) mod 4096
+    const int64_t ids = (((mb > 0 ? mb : 96) << 20)) << (pl.nib_ok ? 1 : 0);  // a block's ids in one slice: 96 MB as bytes or as nibbles
+    int64_t nb = ids / k.P / m * m;
+    if (nb < m) nb = m;
+    return nb < k.B ? nb : 0;
 }
 
 // The caller holds nothing: the scratch is acquired here (shared by the calls of one stream -- workspace cache --, so the launches of a
@@ -1112,6 +1137,15 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     if (path == 2) {
         // (the scratch is shared by the calls of one stream -- workspace cache --: onehot_two_pass enqueues its launches back to back
         //  under the workspace mutex; concurrent host threads take turns there: enqueueing takes microseconds, the GPU work overlaps)
+        if (const int64_t nb = two_pass_sequence_block(k, sz, out)) {  // short reads, very many of them: column blocks of nb sequences
+            const int64_t rb = k.C * int64_t(sz);
+            for (int64_t b0 = 0; b0 < B; b0 += nb) {
+                const int64_t n = B - b0 < nb ? B - b0 : nb;
+                st = bsq_onehot_block_device(d, chars, offsets + b0, mask_or_null, n, P, t, static_cast<uint8_t *>(out) + b0 * rb, B, hip_stream);
+                if (st != BSQ_OK) return st;
+            }
+            return BSQ_OK;
+        }
         return onehot_two_pass(k, sz, s);
     }
     switch (sz) {
@@ -1178,6 +1212,14 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
         }
     }
     if (block_path != 1 && rb >= 16 && block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0) {
+        if (const int64_t nb = two_pass_sequence_block(k, sz, out)) {  // (a block of very many short reads: sub-blocks, see bsq_onehot_device)
+            for (int64_t b0 = 0; b0 < B; b0 += nb) {
+                const int64_t n = B - b0 < nb ? B - b0 : nb;
+                st = bsq_onehot_block_device(d, chars, offsets + b0, mask_or_null, n, P, t, static_cast<uint8_t *>(out) + b0 * rb, row_seqs, hip_stream);
+                if (st != BSQ_OK) return st;
+            }
+            return BSQ_OK;
+        }
         return onehot_two_pass(k, sz, s, (row_seqs - B) * k.C * int64_t(sz));
     }
     // otherwise the tiled kernel: a workgroup owns (sequence tile x 64 positions) and writes one row SEGMENT per position, so a row
