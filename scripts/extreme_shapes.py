@@ -10,6 +10,7 @@ from bioseq_amd import capi, synth
 from oracle import oracle as O
 lib = capi.load()
 dev = torch.device("cuda:0")
+VALIDATE = os.environ.get("VALIDATE", "0") == "1"   # (the default of the packed calls is to validate the lengths on the device first: a launch + a host read)
 SHAPES = [("onehot", "AMINO20", (0, 0, 0), 16384, 100, 4096, 4096, "f", None), ("onehot", "AMINO20", (1, 1, 1), 4096, 1000, 16382, 16384, "f", None),
           ("onehot", "DNA4", (1, 1, 1), 4000000, 20, 30, 32, "f", None), ("onehot", "DNA4", (1, 1, 1), 4000000, 20, 30, 32, "B", None),
           ("tokens", "AMINO20", (0, 0, 0), 16384, 1000, 16384, 16384, "b", True), ("tokens", "AMINO20", (0, 0, 0), 16384, 1000, 16384, 16384, "b", False),
@@ -23,9 +24,9 @@ for si, (op, key, flags, B, lo, hi, P, dc, bf) in enumerate(SHAPES):
     ora = O.OracleTokenizer(key, *flags)
     dch, dof = torch.from_numpy(chars).to(dev), torch.from_numpy(offs).to(dev)
     if op == "onehot":
-        f = lambda: tok.onehot_packed(dch, dof, P, dc)
+        f = lambda: tok.onehot_packed(dch, dof, P, dc, validate=VALIDATE)
     else:
-        f = lambda: tok.tokenize_packed(dch, dof, P, dc, bf)
+        f = lambda: tok.tokenize_packed(dch, dof, P, dc, bf, validate=VALIDATE)
     out = f(); torch.cuda.synchronize()
     # oracle on the first and the last 64 sequences
     ok = True
@@ -46,7 +47,7 @@ for si, (op, key, flags, B, lo, hi, P, dc, bf) in enumerate(SHAPES):
             r = f(); del r
         b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) / 5)
     t = float(np.median(ts))
-    print("%-6s %-8s %s B=%8d P=%6d %s%s out=%6.2f GB | %9.1f us incl. allocation  %6.0f GB/s  frac %.3f  %s" % (
-        op, key, flags, B, P, dc, "" if bf is None else (" (B,P)" if bf else " (P,B)"), ob / 1e9, t * 1e3, algo / t / 1e6, algo / t / 8e9, "ok" if ok else "MISMATCH"), flush=True)
+    print("%-6s %-8s %s B=%8d P=%6d %s%s out=%6.2f GB | %9.1f us incl. result allocation%s  %6.0f GB/s  frac %.3f  %s" % (
+        op, key, flags, B, P, dc, "" if bf is None else (" (B,P)" if bf else " (P,B)"), ob / 1e9, t * 1e3, " + validation" if VALIDATE else "", algo / t / 1e6, algo / t / 8e9, "ok" if ok else "MISMATCH"), flush=True)
     del dch, dof
     torch.cuda.empty_cache()
