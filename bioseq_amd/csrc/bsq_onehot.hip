@@ -927,6 +927,7 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
 struct TwoPassPlan {
     int64_t pitch;            // ids per scratch row
     bool nib, nib_ok;         // ids as nibbles; whether they could be
+    bool wants_slices;        // the id matrix is too large for one piece (it may still BE one piece: a single position tile cannot be cut)
     int64_t ntt, tiles_per_slice;
     size_t ws_bytes;
 };
@@ -945,12 +946,14 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
     pl.nib = nib_ok && (tn.raw_nibbles == 2 || (tn.raw_nibbles == 0 && ((rb >= 24 && rb < 32) || pl.pitch * k.P > (int64_t(128) << 20))));
     const int64_t row_bytes = pl.pitch >> (pl.nib ? 1 : 0), all_bytes = row_bytes * k.P;
     pl.tiles_per_slice = pl.ntt;
+    pl.wants_slices = false;
     const int64_t mb = tn.two_pass_slice_mb;
     // (a column block -- row_gap != 0 -- needs every slice to start on a chunk boundary like the block itself: no chunk may straddle two rows)
     const bool gap_ok = row_gap == 0 || (kTT * (k.B * rb + row_gap)) % kChunk == 0;
     if (pb8 && mb >= 0 && tn.expand_mode == 0 && gap_ok) {
         const int64_t slice_bytes = (mb > 0 ? mb : 96) << 20;
-        if (mb > 0 || all_bytes > (int64_t(128) << 20)) {
+        if ((mb > 0 && all_bytes > slice_bytes) || all_bytes > (int64_t(128) << 20)) {
+            pl.wants_slices = true;
             const int64_t tile_bytes = row_bytes * kTT;
             const int64_t max_tiles = slice_bytes / tile_bytes > 1 ? slice_bytes / tile_bytes : 1;  // (a single tile may exceed the target: B beyond 1.5 M)
             const int64_t nslices = (pl.ntt + max_tiles - 1) / max_tiles;
@@ -970,7 +973,8 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
 // Returns nb, or 0 when the batch is not to be cut this way.
 int64_t two_pass_sequence_block(const KParams &k, size_t sz, const void *out) {
     const TwoPassPlan pl = two_pass_plan(k, sz, 0);
-    if (pl.tiles_per_slice >= pl.ntt || pl.tiles_per_slice >= 4 || reinterpret_cast<uintptr_t>(out) % kChunk != 0) return 0;
+    // (fat position slices are fine; thin ones, and a matrix of a single tile -- padlen <= 64 -- that is too large all the same, are cut here)
+    if (!pl.wants_slices || pl.tiles_per_slice >= 4 || reinterpret_cast<uintptr_t>(out) % kChunk != 0) return 0;
     const int64_t mb = bsq_internal::tuning().two_pass_slice_mb;
     const int64_t rb = k.C * int64_t(sz);
     int64_t g = rb, h = kChunk;
