@@ -318,7 +318,9 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
 // multiply: ((n * 0x204081) & 0x01010101).  ~35 vector instructions per 16 bytes, no LDS, no barrier; one wave = one aligned 4-KiB
 // chunk, class = blockIdx % 8, exactly as above.  Chunks that are clipped (first / last of the tensor), misaligned, or that run
 // over the end of a position row of a padded id matrix (Bp != B) take the byte loop at the end -- a few hundred chunks of a million.
-template <bool NT, int NR>
+// NIB (end of round 5): the id matrix holds nibbles as in k_expand_chunks<..., NIB> -- a lane's <= 6 ids and the parity of its first one
+// are one unaligned 4-byte window.
+template <bool NT, int NR, bool NIB = false>
 __global__ __launch_bounds__(kThreads) void k_expand_rows1(const EParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
@@ -330,21 +332,46 @@ __global__ __launch_bounds__(kThreads) void k_expand_rows1(const EParams p) {
     if (!cc.live) return;
     const int32_t len = cc.len, skip = cc.skip;
     const int32_t nr_s = __builtin_amdgcn_readfirstlane(cc.nr);
-    const uint8_t *tok = p.tok + cc.t_lo * p.Bp + cc.b_lo;
+    // NIB: the byte that holds the chunk's first id, and that id's half (Bp is even: the parity of t_lo * Bp + b_lo is b_lo's)
+    const uint8_t *tok = NIB ? p.tok + ((cc.t_lo * p.Bp + cc.b_lo) >> 1) : p.tok + cc.t_lo * p.Bp + cc.b_lo;
+    const uint32_t par0 = NIB ? static_cast<uint32_t>(cc.b_lo & 1) : 0u;
+    constexpr uint32_t kNo = NIB ? 0xFu : kNone;  // "no one"
     const int64_t wrap_at = p.B - cc.b_lo;  // rows i >= wrap_at belong to position t_lo + 1 (or later)
     const bool wraps = p.Bp != p.B && wrap_at < nr_s;  // (wave-uniform) the chunk runs over the end of a position row of a PADDED id matrix
     uint8_t *g = p.out + cc.lo + cc.t_lo * p.row_gap;
     const uint32_t one = static_cast<uint32_t>(p.one_bits) & 0xFFu;
-    // address of the id of row i of the chunk (rows behind wrap_at lie in later position rows of the matrix, Bp - B bytes further each)
-    auto id_at = [&](uint32_t i) -> int64_t {
+    // the id of row i of the chunk (rows behind wrap_at lie in later position rows of the matrix, Bp - B ids further each)
+    auto id_of = [&](uint32_t i) -> uint32_t {
         int64_t at = i;
         if (static_cast<int64_t>(i) >= wrap_at) at += ((static_cast<int64_t>(i) - wrap_at) / p.B + 1) * (p.Bp - p.B);
-        return at;
+        if constexpr (NIB) {
+            at += par0;
+            return (static_cast<uint32_t>(tok[at >> 1]) >> ((static_cast<uint32_t>(at) & 1u) << 2)) & 0xFu;
+        } else {
+            return static_cast<uint32_t>(tok[at]);
+        }
     };
+    constexpr int IDB = NIB ? 4 : 8;  // bits per id in a lane's window
     if (len == kChunk && (reinterpret_cast<uintptr_t>(g) & 15) == 0 && nr_s >= 8) {
         uint64_t ids[4];
         uint32_t ph[4];
-        if (!wraps) {
+        if (!wraps && NIB) {
+            typedef uint32_t u32u __attribute__((aligned(1)));
+            uint32_t w[4], sh[4];
+            const uint32_t lb = (par0 + static_cast<uint32_t>(nr_s) - 1u) >> 1;  // the last byte of ids this chunk owns (>= 3: nr_s >= 8)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // the four id windows of the lane in flight together: NR <= 6 nibbles + a parity fit four bytes
+                const uint32_t o = static_cast<uint32_t>(skip) + static_cast<uint32_t>(u * 1024 + lane * 16);
+                const uint32_t q = fast_div(o, p.rb_magic, p.rb_shift, p.rb_pow2);
+                ph[u] = o - q * static_cast<uint32_t>(rb);
+                const uint32_t n0 = q + par0, bo = n0 >> 1;
+                const uint32_t off = bo + 3u <= lb ? bo : lb - 3u;  // pulled back to END at the chunk's last id byte (rows < nr_s lie in bo ... lb)
+                sh[u] = (bo - off) * 8u + ((n0 & 1u) << 2);
+                w[u] = *reinterpret_cast<const u32u *>(tok + off);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ids[u] = w[u] >> sh[u];
+        } else if (!wraps) {
             typedef uint32_t u32x2u __attribute__((ext_vector_type(2), aligned(1)));
             u32x2u w[4];
             uint32_t sh[4];
@@ -368,13 +395,13 @@ __global__ __launch_bounds__(kThreads) void k_expand_rows1(const EParams p) {
                 const uint32_t q = fast_div(o, p.rb_magic, p.rb_shift, p.rb_pow2);
                 ph[u] = o - q * static_cast<uint32_t>(rb);
 #pragma unroll
-                for (int j = 0; j < NR; ++j) b[u][j] = q + j < static_cast<uint32_t>(nr_s) ? static_cast<uint32_t>(tok[id_at(q + j)]) : kNone;
+                for (int j = 0; j < NR; ++j) b[u][j] = q + j < static_cast<uint32_t>(nr_s) ? id_of(q + j) : kNo;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 ids[u] = 0;
 #pragma unroll
-                for (int j = 0; j < NR; ++j) ids[u] |= static_cast<uint64_t>(b[u][j]) << (8 * j);
+                for (int j = 0; j < NR; ++j) ids[u] |= static_cast<uint64_t>(b[u][j]) << (IDB * j);
             }
         }
         const uint32_t cmask = (1u << rb) - 1u;
@@ -383,8 +410,8 @@ __global__ __launch_bounds__(kThreads) void k_expand_rows1(const EParams p) {
             uint32_t bits = 0;
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-                const uint32_t id = static_cast<uint32_t>(ids[u] >> (8 * j)) & 0xFFu;
-                const uint32_t m = (1u << (id & 31u)) & cmask;  // id 255 (no one) -> bit 31 -> 0
+                const uint32_t id = static_cast<uint32_t>(ids[u] >> (IDB * j)) & (NIB ? 0xFu : 0xFFu);
+                const uint32_t m = (1u << (id & 31u)) & cmask;  // id 255 (no one) -> bit 31 -> 0; nibble 15 -> bit 15 -> 0 (rows of <= 15 bytes)
                 const int32_t at = j * rb;                      // wave-uniform; strings that start at bit >= 32 lie beyond the lane's bits
                 if (at < 32) bits |= m << at;
             }
@@ -413,7 +440,7 @@ __global__ __launch_bounds__(kThreads) void k_expand_rows1(const EParams p) {
             const uint32_t a = static_cast<uint32_t>(o + skip);
             const uint32_t i = fast_div(a, p.rb_magic, p.rb_shift, p.rb_pow2);
             cv[m] = a - i * static_cast<uint32_t>(rb);
-            idv[m] = o < len ? static_cast<uint32_t>(tok[id_at(i)]) : kNone;
+            idv[m] = o < len ? id_of(i) : kNo;
         }
 #pragma unroll
         for (int m = 0; m < 8; ++m)
@@ -801,15 +828,20 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
             const bool nt = bsq_internal::nontemporal_stores();
 #define BSQ_ROWS1(NRV)                                                                                       \
     case NRV:                                                                                                \
-        if (nt) hipLaunchKernelGGL((k_expand_rows1<true, NRV>), grid, dim3(kThreads), rpad, s, e);           \
-        else hipLaunchKernelGGL((k_expand_rows1<false, NRV>), grid, dim3(kThreads), rpad, s, e);             \
+        if (e.nib) {                                                                                         \
+            if (nt) hipLaunchKernelGGL((k_expand_rows1<true, NRV, true>), grid, dim3(kThreads), rpad, s, e); \
+            else hipLaunchKernelGGL((k_expand_rows1<false, NRV, true>), grid, dim3(kThreads), rpad, s, e);   \
+        } else {                                                                                             \
+            if (nt) hipLaunchKernelGGL((k_expand_rows1<true, NRV>), grid, dim3(kThreads), rpad, s, e);       \
+            else hipLaunchKernelGGL((k_expand_rows1<false, NRV>), grid, dim3(kThreads), rpad, s, e);         \
+        }                                                                                                    \
         break;
             switch (nrows) {
                 BSQ_ROWS1(2) BSQ_ROWS1(3) BSQ_ROWS1(4) BSQ_ROWS1(5) BSQ_ROWS1(6)
             default: return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "k_expand_rows1: rows per lane");
             }
 #undef BSQ_ROWS1
-            return check_launch("k_expand_rows1");
+            return check_launch(e.nib ? "k_expand_rows1<nibbles>" : "k_expand_rows1");
         }
     }
     // knob "expand_gate": 0 automatic (rows of 24 ... 63 bytes), 1 never, 2 always (the scratch holds at least 256 bytes: Bp >= 256)
@@ -829,7 +861,7 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
             return check_launch("k_expand_chunks<nibbles>");
         }
     }
-    if (e.nib) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "nibble ids: elements of 2 bytes and more");
+    if (e.nib) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "nibble ids: elements of 2 bytes and more, or one-byte rows of 3 ... 15 bytes");
     if (bsq_internal::nontemporal_stores()) {
         if (gated) hipLaunchKernelGGL((k_expand_chunks<ST, true, 0, true>), grid, dim3(kThreads), pad, s, e);
         else hipLaunchKernelGGL((k_expand_chunks<ST, true, 0>), grid, dim3(kThreads), pad, s, e);
@@ -940,10 +972,12 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
     // the register-transposed raw pass (no mask, foldable or LDS table, ids < 251): what nibbles and slices are built on
     const bool pb8 = !k.mask && k.desc && tn.raw_mode == 0 &&
                      bsq_internal::tokens_pb8_applicable(k.desc, k.B, k.P, reinterpret_cast<const void *>(uintptr_t(256)), pl.pitch);
-    const bool nib_ok = pb8 && k.C <= 15 && sz >= 2 && tn.expand_mode == 0 && tn.xcd_claim == 0 && tn.chunk_math == 0;
+    const bool rows1 = sz == 1 && rb >= 3 && rb <= 15 && tn.expand_rows1 != 1;  // (launch_expand: one-byte rows expand through k_expand_rows1)
+    const bool nib_ok = pb8 && k.C <= 15 && (sz >= 2 || rows1) && tn.expand_mode == 0 && tn.xcd_claim == 0 && tn.chunk_math == 0;
     // (automatic: rows of 24 ... 31 bytes, and every id matrix beyond 128 MB as bytes -- half the scratch to keep resident, slices of twice the rows)
     pl.nib_ok = nib_ok && tn.raw_nibbles != 1;
-    pl.nib = nib_ok && (tn.raw_nibbles == 2 || (tn.raw_nibbles == 0 && ((rb >= 24 && rb < 32) || pl.pitch * k.P > (int64_t(128) << 20))));
+    // (one-byte rows through k_expand_rows1<nibbles>: ahead of byte ids on every shape tried, 2-9 % -- profiles/r05/rows1_nib_sweep.txt)
+    pl.nib = nib_ok && (tn.raw_nibbles == 2 || (tn.raw_nibbles == 0 && (rows1 || (rb >= 24 && rb < 32) || pl.pitch * k.P > (int64_t(128) << 20))));
     const int64_t row_bytes = pl.pitch >> (pl.nib ? 1 : 0), all_bytes = row_bytes * k.P;
     pl.tiles_per_slice = pl.ntt;
     pl.wants_slices = false;
@@ -987,7 +1021,11 @@ int64_t two_pass_sequence_block(const KParams &k, size_t sz, const void *out) {
     const int64_t ids = (((mb > 0 ? mb : 96) << 20)) << (pl.nib_ok ? 1 : 0);  // a block's ids in one slice: 96 MB as bytes or as nibbles
     int64_t nb = ids / k.P / m * m;
     if (nb < m) nb = m;
-    return nb < k.B ? nb : 0;
+    if (nb >= k.B) return 0;
+    // blocks of equal size (2M reads as 1M + 1M, not 1.26M + 0.74M: the last, short block's launches are no cheaper per sequence)
+    const int64_t nblocks = (k.B + nb - 1) / nb;
+    const int64_t even = ((k.B + nblocks - 1) / nblocks + m - 1) / m * m;
+    return even < nb ? even : nb;
 }
 
 // The caller holds nothing: the scratch is acquired here (shared by the calls of one stream -- workspace cache --, so the launches of a
@@ -1046,7 +1084,7 @@ bsq_status launch_expand_bcl(const uint8_t *tokens, int64_t B, int64_t P, int32_
 extern "C" {
 
 // 0 generic, 1 tiled, 2 two-pass, 3 chunk-owner
-static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool misaligned_out = false) {
+static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool misaligned_out = false, bool masked = false) {
     const int64_t ntiles = ((B + 63) / 64) * ((P + kTT - 1) / kTT);
     const bool tiled_ok = C <= 250 && 4 * (64 * C * int64_t(sz) + 16) + tile_fixed_bytes<64>() <= 60 * 1024 &&
                           ntiles < (int64_t(1) << 31) && B < (int64_t(1) << 31) - 256 && P <= kMaxTiledP;
@@ -1080,6 +1118,14 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool m
                        // Round 5: one-byte rows of 8 ... 15 bytes too -- their expansion is k_expand_rows1: SEB14 131072 x 512 int8
                        // 187 -> 156 us, SEB8 + BOS / EOS / PAD (11-byte rows) 281 -> 248 us; rows of 3 ... 7 bytes stay tiled unless
                        // misaligned: cfg4 int8 225 us tiled, 240 two-pass -- profiles/r05/rows1_lab.txt)
+        else if (sz == 1 && rowbytes >= 3 && rowbytes < 8 && P <= 4 * kTT && total >= (int64_t(192) << 20) && !masked &&
+                 bsq_internal::tuning().expand_rows1 != 1 && bsq_internal::tuning().raw_nibbles != 1 && bsq_internal::tuning().raw_mode == 0 &&
+                 bsq_internal::tuning().tokens_pb8 != 1)
+            path = 2;  // (end of round 5) SHORT READS with rows of 3 ... 7 bytes -- BASELINE config 4's default dtype: 1M x 160 DNA int8 -- once the
+                       // ids are NIBBLES and expand through k_expand_rows1<nibbles>: 227 -> 207 us on a resident batch, 257-268 -> 222 us on fresh
+                       // batches (0.60 -> 0.72 of the roof); 4-, 5-, 6-byte rows 188 -> 153, 204 -> 174, 214 -> 198 us cold.  Reads of up to four
+                       // position tiles only: every tile of the tiled kernel fetches the character lines its neighbours fetch, which fresh inputs
+                       // pay at HBM; long reads (262144 x 512, 65536 x 2048) stay tiled, 158 vs 166 us (profiles/r05/rows1_nib_sweep.txt)
         else
             path = 1;
     }
@@ -1105,7 +1151,8 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
             kp.B = B;
             kp.P = P;
             kp.C = bsq_alphabet_size(d);
-            if (!rows1 && two_pass_plan(kp, bsq_dtype_size(t), 0).nib) return "k_tokens_pb8_fast<raw, nibbles>+k_expand_chunks<nibbles>";
+            if (two_pass_plan(kp, bsq_dtype_size(t), 0).nib)
+                return rows1 ? "k_tokens_pb8_fast<raw, nibbles>+k_expand_rows1<nibbles>" : "k_tokens_pb8_fast<raw, nibbles>+k_expand_chunks<nibbles>";
             return rows1 ? "k_tokens_pb8_fast<raw>+k_expand_rows1" : "k_tokens_pb8_fast<raw>+k_expand_chunks";
         }
         return rows1 ? "k_tokens_raw+k_expand_rows1" : "k_tokens_raw+k_expand_chunks";
@@ -1127,7 +1174,7 @@ bsq_status bsq_onehot_device(const bsq_desc *d, const uint8_t *chars, const int6
     // Limits of the LDS kernels: 8-bit token ids, 32-bit tile arithmetic, row images must fit in LDS.
     // (a result that does not start on a 64-byte boundary -- a view into a larger tensor -- counts as misaligned: the tiled kernel's
     //  row segments then straddle memory sectors, cfg4 int8 16 bytes off: 225 -> 330 us tiled, 242 us two-pass)
-    const int path = choose_onehot_path(k.C, sz, B, P, reinterpret_cast<uintptr_t>(out) % 64 != 0);
+    const int path = choose_onehot_path(k.C, sz, B, P, reinterpret_cast<uintptr_t>(out) % 64 != 0, k.mask != nullptr);
     if (path == 0) return bsq_onehot_device_generic(d, chars, offsets, mask_or_null, B, P, t, out, hip_stream);
     k.one_bits = one_bits_of(t);
     const int64_t pitch = B * k.C * int64_t(sz);
@@ -1180,6 +1227,10 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
     // any multiple of 4096 sequences at a 4096-sequence boundary of an aligned tensor) is the two-pass stream with a gap after every
     // row: no chunk straddles two rows.  16 384-sequence blocks of cfg3: 4 x 0.19 ms against 4 x 0.25 ms for the tiles.
     const int64_t block_pitch = B * k.C * int64_t(sz), rb = k.C * int64_t(sz);
+    // (rows that the chunk stream expands well: 16 bytes and more, and -- end of round 5 -- one-byte rows of 3 ... 15 bytes through k_expand_rows1)
+    const bool stream_rows = rb >= 16 || (sz == 1 && rb >= 3 && bsq_internal::tuning().expand_rows1 != 1);
+    // (the three-piece cut below stays with rows of 16 bytes and more: the 1/8 shard of cfg4 int8 stored into a root -- 122 880 sequences of
+    //  stream + 2 120 through a tile launch with its ~15-us floor -- took 50-57 us that way against 44 for one tiled launch)
     if (block_path != 1 && rb >= 16 && !(block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0)) {
         // Any other large block: the sequences up to the first one that starts a chunk of the result, the run of whole chunks behind
         // it (a multiple of 4096 / gcd(row bytes, 4096) sequences), the rest -- three calls, the middle one the fast stream; worth it
@@ -1215,7 +1266,7 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
             return side(offsets + lead + main, B - lead - main, o + (lead + main) * rb);
         }
     }
-    if (block_path != 1 && rb >= 16 && block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0) {
+    if (block_path != 1 && stream_rows && block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0) {
         if (const int64_t nb = two_pass_sequence_block(k, sz, out)) {  // (a block of very many short reads: sub-blocks, see bsq_onehot_device)
             for (int64_t b0 = 0; b0 < B; b0 += nb) {
                 const int64_t n = B - b0 < nb ? B - b0 : nb;

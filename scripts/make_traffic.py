@@ -25,7 +25,7 @@ try:
     old = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
 except Exception:
     pass
-STEP_KERNELS = ("k_augment_tokens_fused", "k_tokens_pb8", "k_tokens_raw", "k_expand_chunks", "k_expand_small", "k_expand_bcl", "k_onehot_tile",
+STEP_KERNELS = ("k_augment_tokens_fused", "k_tokens_pb8", "k_tokens_raw", "k_expand_chunks", "k_expand_rows1", "k_expand_small", "k_expand_bcl", "k_onehot_tile",
                 "k_onehot_chunks", "k_tokenize_chunks", "k_tokens_bp8", "k_augment", "k_tokenize_rows", "k_tokenize_tile", "k_onehot_rows")
 
 

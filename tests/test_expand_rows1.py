@@ -19,7 +19,7 @@ def two_pass(bsq):
     lib = capi.load()
     capi.check(lib.bsq_tuning_set(b"onehot_path", 2))
     yield lib
-    for k in (b"onehot_path", b"expand_rows1"):
+    for k in (b"onehot_path", b"expand_rows1", b"raw_nibbles"):
         capi.check(lib.bsq_tuning_set(k, 0))
 
 
@@ -40,21 +40,25 @@ def test_every_small_row_width_vs_oracle(gpu, bsq, oracle, two_pass):
                 seqs = synth.unpack(chars, offs)
                 exp = ora.batch_onehot_encode(seqs, padlen=P, destchar="B")
                 dch, dof = torch.from_numpy(chars).to(gpu), torch.from_numpy(offs).to(gpu)
-                for rows1 in (0, 1):                                  # the new kernel, then k_expand_chunks on the same ids
+                # the new kernel on byte ids, on NIBBLE ids (k_expand_rows1<nibbles>), then k_expand_chunks on the same byte ids
+                for rows1, nib in ((0, 1), (0, 2), (1, 1)):
                     capi.check(lib.bsq_tuning_set(b"expand_rows1", rows1))
+                    capi.check(lib.bsq_tuning_set(b"raw_nibbles", nib))
                     got = tok.onehot_packed(dch, dof, P, "B")
-                    assert got.cpu().numpy().tobytes() == exp.tobytes(), (key, flags, B, P, rows1)
+                    assert got.cpu().numpy().tobytes() == exp.tobytes(), (key, flags, B, P, rows1, nib)
                 capi.check(lib.bsq_tuning_set(b"expand_rows1", 0))
-                # a result 16 / 1 / 4090 bytes off a 4-KiB boundary, guard bytes around it (C ABI on raw pointers)
+                # a result 16 / 1 / 4090 bytes off a 4-KiB boundary, guard bytes around it (C ABI on raw pointers), byte and nibble ids
                 desc = capi.make_desc(key, *flags)
-                for shift in (16, 1, 4090):
+                for shift, nib in ((16, 1), (1, 1), (4090, 1), (16, 2), (1, 2), (4090, 2)):
+                    capi.check(lib.bsq_tuning_set(b"raw_nibbles", nib))
                     buf = torch.full((exp.size + 8192,), 0x5A, dtype=torch.uint8, device=gpu)
                     base = (-buf.data_ptr()) % 4096 + shift
                     capi.check(lib.bsq_onehot_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), None, B, P, capi.I8,
                                                      buf.data_ptr() + base, None))
                     h = buf.cpu().numpy()
-                    assert h[base:base + exp.size].tobytes() == exp.tobytes(), (key, flags, B, P, shift)
-                    assert (h[:base] == 0x5A).all() and (h[base + exp.size:] == 0x5A).all(), (key, flags, shift)
+                    assert h[base:base + exp.size].tobytes() == exp.tobytes(), (key, flags, B, P, shift, nib)
+                    assert (h[:base] == 0x5A).all() and (h[base + exp.size:] == 0x5A).all(), (key, flags, shift, nib)
+                capi.check(lib.bsq_tuning_set(b"raw_nibbles", 0))
     assert seen >= {4, 5, 6, 7, 8, 9, 10, 11, 13, 14}, seen
 
 

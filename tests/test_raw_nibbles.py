@@ -63,19 +63,23 @@ def test_nibble_scratch_equals_the_oracle(gpu, bsq, oracle, knobs, key, letters,
         assert got[1] == want.tobytes(), (key, flags, B, P, dc, "byte scratch differs from the oracle")
 
 
-def test_nibble_scratch_column_blocks(gpu, bsq, oracle, knobs):
+@pytest.mark.parametrize("dc,cuts", [("f", ((0, 3072), (3072, 4096), (4096, 8192))),
+                                     # int8: 7-byte rows, blocks on 4096-sequence boundaries are whole chunks -> the gap stream + k_expand_rows1
+                                     ("B", ((4096, 8192), (0, 4096))), ("B", ((0, 3072), (3072, 4096), (4096, 8192)))])
+def test_nibble_scratch_column_blocks(gpu, bsq, oracle, knobs, dc, cuts):
     """A column block of a wider (P, row_seqs, C) tensor (a rank's shard stored into the root's buffer; a piece of a host batch) through the
     two-pass stream with a row gap: the nibble scratch against the oracle's whole-batch encode."""
     import torch
     from bioseq_amd import capi, synth
     lib = knobs
-    key, flags, P, dc = "DNA4", (1, 1, 1), 640, "f"   # ten position tiles: 1-MB slices cut the 3072- and 4096-sequence blocks in two / three
+    key, flags, P = "DNA4", (1, 1, 1), 640   # ten position tiles: 1-MB slices cut the 3072- and 4096-sequence blocks in two / three
     ora = oracle.OracleTokenizer(key, *flags)
     dev = torch.device("cuda:0")
     Bfull = 8192  # pitch = 8192 * 7 * 4 bytes = 56 chunks: blocks on chunk boundaries every 1024 sequences
     chars, offs = synth.synth_packed(91, Bfull, 100, 638, "ACGT")
     want = ora.onehot_packed(chars, offs, P, dc)
-    root = torch.zeros(want.shape, dtype=torch.float32, device=dev)
+    root = torch.zeros(want.shape, dtype=torch.float32 if dc == "f" else torch.int8, device=dev)
+    sz = want.dtype.itemsize
     desc = capi.make_desc(key, *flags)
     dt = ctypes.c_int(0)
     capi.check(lib.bsq_dtype_from_destchar(dc.encode(), ctypes.byref(dt)))
@@ -86,13 +90,13 @@ def test_nibble_scratch_column_blocks(gpu, bsq, oracle, knobs):
         capi.check(lib.bsq_tuning_set(b"raw_nibbles", nib))
         capi.check(lib.bsq_tuning_set(b"two_pass_slice_mb", mb))
         root.zero_()
-        for b0, b1 in ((0, 3072), (3072, 4096), (4096, 8192)):
+        for b0, b1 in cuts:
             o = offs[b0:b1 + 1]
             sub_off = torch.from_numpy((o - o[0]).copy()).to(dev)
             capi.check(lib.bsq_onehot_block_device(ctypes.byref(desc), dch.data_ptr() + int(o[0]), sub_off.data_ptr(), None, b1 - b0, P, dt,
-                                                   root.data_ptr() + b0 * C * 4, Bfull, None))
+                                                   root.data_ptr() + b0 * C * sz, Bfull, None))
         torch.cuda.synchronize()
-        assert root.cpu().numpy().tobytes() == want.tobytes(), ("column blocks", nib, mb)
+        assert root.cpu().numpy().tobytes() == want.tobytes(), ("column blocks", dc, nib, mb)
 
 
 @pytest.mark.parametrize("key,flags,letters,dc", [("DNA4", (1, 1, 1), "ACGT", "f"), ("DNA5", (0, 0, 0), "ACGTN", "h"), ("AMINO20", (0, 0, 0), "ACDEFGHIKLMNPQRSTVWY", "B"),
