@@ -1228,7 +1228,8 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
     // row: no chunk straddles two rows.  16 384-sequence blocks of cfg3: 4 x 0.19 ms against 4 x 0.25 ms for the tiles.
     const int64_t block_pitch = B * k.C * int64_t(sz), rb = k.C * int64_t(sz);
     // (rows that the chunk stream expands well: 16 bytes and more, and -- end of round 5 -- one-byte rows of 3 ... 15 bytes through k_expand_rows1)
-    const bool stream_rows = rb >= 16 || (sz == 1 && rb >= 3 && bsq_internal::tuning().expand_rows1 != 1);
+    // (unmasked only: a masked raw pass is k_tokens_raw with byte ids -- such blocks stay with the tiled kernel as before)
+    const bool stream_rows = rb >= 16 || (sz == 1 && rb >= 3 && !k.mask && bsq_internal::tuning().expand_rows1 != 1);
     // (the three-piece cut below stays with rows of 16 bytes and more: the 1/8 shard of cfg4 int8 stored into a root -- 122 880 sequences of
     //  stream + 2 120 through a tile launch with its ~15-us floor -- took 50-57 us that way against 44 for one tiled launch)
     if (block_path != 1 && rb >= 16 && !(block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0)) {
