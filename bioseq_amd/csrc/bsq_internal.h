@@ -61,7 +61,8 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //                         waits, a patch launch behind it: round 5; 4: at every size), beyond that the flag form --, 1 never fused (the two launches), 2 the flag form of rounds 3-4 (token waves wait for their rows' augmentation;
 //                         written-through stores, any XCD), 3 the flag form with the hand-off inside one XCD where it applies
 //   expand_gate           k_expand_chunks: one pacing load in front of every wave (0 automatic: rows of 24 ... 63 bytes; 1 never; 2 always)
-//   raw_nibbles           the id scratch of the two-pass one-hot as nibbles (alphabets of at most 15 classes, expansion = k_expand_chunks): 0 automatic (rows of 24 ... 31 bytes), 1 never, 2 whenever they apply
+//   raw_nibbles           the id scratch of the two-pass one-hot as nibbles (alphabets of at most 15 classes; expansion = k_expand_chunks<nibbles>, or
+//                         k_expand_rows1<nibbles> for one-byte rows): 0 automatic (rows of 24 ... 31 bytes, id matrices beyond 128 MB, every one-byte row), 1 never, 2 whenever they apply
 //   two_pass_slice_mb     the two-pass one-hot in SLICES of position rows whose id scratch stays cache-resident: 0 automatic (slices of <= 96 MB once the
 //                         id matrix exceeds 128 MB), > 0 that many MB per slice (whatever the size), < 0 never
 //   expand_rows1          the LDS-free expansion k_expand_rows1 (one-byte elements, rows of 3 ... 15 bytes): 0 automatic, 1 never, 2 whenever it applies

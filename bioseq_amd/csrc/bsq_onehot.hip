@@ -948,10 +948,10 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
 
 // How a two-pass one-hot is run (round 5).
 //  * nib: ids as NIBBLES in the scratch -- alphabets of at most 15 classes (DNA, the reduced amino alphabets; 15 = no one) whose raw pass is
-//    k_tokens_pb8_fast and whose expansion is k_expand_chunks (elements of 2 bytes and more: one-byte rows of <= 15 bytes expand through
-//    k_expand_rows1, which reads byte ids).  The scratch is written and re-read at half its bytes.  Automatic for rows of 24 ... 31 bytes,
-//    where it wins on every shape tried (cfg4 f32 673 -> 648 us; 0.5-4 % elsewhere); other row widths lose 1-3 % to the byte form
-//    (profiles/r05/nibble_ids_lab.txt).  Knob "raw_nibbles": 1 never, 2 whenever they apply.
+//    k_tokens_pb8_fast and whose expansion is k_expand_chunks (elements of 2 bytes and more) or k_expand_rows1 (one-byte rows of 3 ... 15
+//    bytes).  The scratch is written and re-read at half its bytes.  Automatic for rows of 24 ... 31 bytes, where it wins on every shape
+//    tried (cfg4 f32 673 -> 648 us; 0.5-4 % elsewhere; other widths of k_expand_chunks lose 1-3 % to the byte form:
+//    profiles/r05/nibble_ids_lab.txt), and for every one-byte row (2-9 %: rows1_nib_sweep.txt).  Knob "raw_nibbles": 1 never, 2 whenever they apply.
 //  * tiles_per_slice: the matrix in SLICES of 64-position tiles, raw pass and expansion of one slice after the other through ONE scratch of
 //    a slice's size.  The expansion runs at the write roof only while the ids it reads come out of the Infinity Cache: with 268 MB of ids
 //    (262 144 x 1024 AMINO20) the int8 one-hot fell from 0.85 to 0.68 of the roof and the f32 one from 0.94 to 0.72, 2M x 160 DNA f32 to 0.59.
@@ -1116,16 +1116,18 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool m
             path = 2;  // (second case: position rows that are not 64-byte aligned -- the tiles would share memory sectors or
                        // fall to element stores: 250001 x 256 int8 DNA 187 -> 120 us, profiles/r02/path_unaligned.txt; round 5: -> 94 us.
                        // Round 5: one-byte rows of 8 ... 15 bytes too -- their expansion is k_expand_rows1: SEB14 131072 x 512 int8
-                       // 187 -> 156 us, SEB8 + BOS / EOS / PAD (11-byte rows) 281 -> 248 us; rows of 3 ... 7 bytes stay tiled unless
-                       // misaligned: cfg4 int8 225 us tiled, 240 two-pass -- profiles/r05/rows1_lab.txt)
-        else if (sz == 1 && rowbytes >= 3 && rowbytes < 8 && P <= 4 * kTT && total >= (int64_t(192) << 20) && !masked &&
-                 bsq_internal::tuning().expand_rows1 != 1 && bsq_internal::tuning().raw_nibbles != 1 && bsq_internal::tuning().raw_mode == 0 &&
+                       // 187 -> 156 us, SEB8 + BOS / EOS / PAD (11-byte rows) 281 -> 248 us; rows of 3 ... 7 bytes on BYTE ids: cfg4 int8
+                       // 225 us tiled, 240 two-pass -- profiles/r05/rows1_lab.txt; on nibble ids: the next rule)
+        else if (sz == 1 && rowbytes >= 3 && rowbytes < 8 && (rowbytes == 7 || P < 8 * kTT || pitch % kChunk != 0) && total >= (int64_t(192) << 20) &&
+                 !masked && bsq_internal::tuning().expand_rows1 != 1 && bsq_internal::tuning().raw_nibbles != 1 && bsq_internal::tuning().raw_mode == 0 &&
                  bsq_internal::tuning().tokens_pb8 != 1)
-            path = 2;  // (end of round 5) SHORT READS with rows of 3 ... 7 bytes -- BASELINE config 4's default dtype: 1M x 160 DNA int8 -- once the
-                       // ids are NIBBLES and expand through k_expand_rows1<nibbles>: 227 -> 207 us on a resident batch, 257-268 -> 222 us on fresh
-                       // batches (0.60 -> 0.72 of the roof); 4-, 5-, 6-byte rows 188 -> 153, 204 -> 174, 214 -> 198 us cold.  Reads of up to four
-                       // position tiles only: every tile of the tiled kernel fetches the character lines its neighbours fetch, which fresh inputs
-                       // pay at HBM; long reads (262144 x 512, 65536 x 2048) stay tiled, 158 vs 166 us (profiles/r05/rows1_nib_sweep.txt)
+            path = 2;  // (end of round 5) rows of 3 ... 7 bytes -- BASELINE config 4's default dtype: 1M x 160 DNA int8 -- once the ids are NIBBLES
+                       // and expand through k_expand_rows1<nibbles>: 227 -> 207 us on a resident batch, 257-268 -> 222 us on fresh batches (0.60 ->
+                       // 0.72 of the roof); 4-, 5-, 6-byte rows 188 -> 153, 204 -> 174, 214 -> 198 us cold.  Over 35 shapes
+                       // (profiles/r05/rows1_nib_sweep.txt) the pair runs at 0.73-0.80 whatever the shape, the tiled kernel at 0.62-0.72 -- each of
+                       // its tiles fetches the character lines its neighbours fetch, which fresh inputs pay at HBM -- except long reads at a
+                       // chunk-aligned pitch (0.75-0.84: 262144 x 512, 131072 x 1024), where 7-byte rows still tie (165 vs 166 us) and narrower
+                       // ones lose 6-10 % (DNA5 131072 x 1024: 124 vs 131 us): those narrower ones stay tiled
         else
             path = 1;
     }

@@ -15,7 +15,13 @@ SHAPES = [("DNA4", (1, 1, 1), 1000000, 150, 150, 160), ("DNA4", (1, 1, 1), 50000
           ("DNA4", (1, 1, 1), 65536, 50, 2048, 2048), ("DNA5", (0, 0, 0), 131072, 50, 1024, 1024), ("SEB8", (1, 1, 1), 262144, 30, 512, 512),
           ("SEB14", (0, 0, 0), 131072, 30, 512, 512), ("SEB10", (1, 1, 1), 131072, 30, 512, 512), ("DNA4", (1, 1, 1), 250001, 100, 256, 256),
           ("DNA4", (1, 1, 1), 4000000, 30, 64, 64), ("DNA4", (1, 1, 1), 1500000, 150, 150, 160), ("DNA4", (1, 1, 1), 3000000, 150, 150, 160),
-          ("DNA4", (1, 1, 1), 1000000, 200, 250, 256), ("DNA4", (1, 1, 1), 600000, 250, 300, 320)]
+          ("DNA4", (1, 1, 1), 1000000, 200, 250, 256), ("DNA4", (1, 1, 1), 600000, 250, 300, 320),
+          ("DNA4", (1, 1, 1), 500000, 300, 380, 384), ("DNA4", (1, 1, 1), 400000, 350, 440, 448), ("DNA4", (1, 1, 1), 500000, 100, 380, 384),
+          ("DNA5", (0, 0, 0), 600000, 250, 300, 320), ("DNA4", (0, 0, 0), 800000, 300, 380, 384),
+          ("DNA4", (1, 1, 1), 1048576, 150, 150, 160), ("DNA4", (1, 1, 1), 524288, 100, 250, 256), ("DNA4", (1, 1, 1), 262144, 250, 300, 320),
+          ("DNA5", (0, 0, 0), 1048576, 150, 150, 160),
+          ("DNA4", (1, 1, 1), 299968, 300, 598, 600), ("DNA4", (1, 1, 1), 100032, 500, 1498, 1500), ("DNA4", (1, 1, 1), 262144, 300, 446, 448),
+          ("DNA4", (1, 1, 1), 200000, 300, 598, 600), ("DNA4", (1, 1, 1), 131072, 500, 1022, 1024), ("DNA5", (0, 0, 0), 299968, 300, 598, 600)]
 DT = os.environ.get("DT", "B")   # destchar: B = int8 (the rows1 forms), f = float32 (k_expand_chunks; the sequence-block cut of very large batches)
 SZ = {"B": 1, "f": 4}[DT]
 lo_i = int(sys.argv[1]) if len(sys.argv) > 1 else 0

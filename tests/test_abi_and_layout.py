@@ -57,7 +57,8 @@ def test_host_only_abi_calls(alphabets_golden):
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("AMINO20")), 8192, 1024, capi.F32) == b"k_onehot_chunks"
     # (7-byte rows of SHORT reads: nibble ids + the LDS-free expansion since the end of round 5; long reads stay tiled)
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA4", 1, 1, 1)), 1000000, 160, capi.I8) == b"k_tokens_pb8_fast<raw, nibbles>+k_expand_rows1<nibbles>"
-    assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA4", 1, 1, 1)), 262144, 512, capi.I8) == b"k_onehot_tile"
+    assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA5")), 131072, 1024, capi.I8) == b"k_onehot_tile"   # (5-byte rows, long reads, chunk-aligned pitch)
+    assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA5")), 1000000, 160, capi.I8) == b"k_tokens_pb8_fast<raw, nibbles>+k_expand_rows1<nibbles>"
     # (28-byte rows: ids as nibbles, round 5)
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA4", 1, 1, 1)), 1000000, 160, capi.F32) == b"k_tokens_pb8_fast<raw, nibbles>+k_expand_chunks<nibbles>"
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("BYTES", 1, 1, 1)), 1000, 160, capi.I16) == b"k_onehot_generic"
