@@ -162,8 +162,16 @@ struct EParams {
     Div64 dv_pitch, dv_rb;                 // div64() constants of pitch and rowbytes (scalar chunk arithmetic)
     int32_t nib;                           // 1: `tok` holds NIBBLES (k_expand_chunks<.., NIB>; never with the other expansion kernels)
     int64_t row_gap;                       // column block of a wider tensor: bytes between the end of one position row of the block and
-                                           // the start of the next (0 = the whole tensor).  Non-zero only when pitch % 4096 == 0 and
-                                           // head == 0: no chunk then straddles two position rows
+                                           // the start of the next (0 = the whole tensor).  Without `ragged`: only when pitch % 4096 == 0 and
+                                           // head == 0 -- no chunk then straddles two position rows
+    // ragged (end of round 5): a column block whose position rows do not start on chunk boundaries of MEMORY (any first sequence, any
+    // tensor pitch).  Every row gets npr8 chunk slots (a multiple of 8 >= the pieces a row can be cut into); slot s of row t is the
+    // memory chunk (A_t >> 12) + j(s), A_t the row's address, clipped to the row -- its first and last pieces are partial, all others
+    // whole naturally aligned chunks exactly as in the flat stream; j(s) rotates the slots of every group of eight so that
+    // (memory chunk index) % 8 == (slot index) % 8 == the class of the workgroup that owns it: the XCD pinning of the flat stream holds.
+    int32_t ragged;
+    int64_t npr8;
+    double inv_npr8;
 };
 
 // Where chunk k of the flat output lies: byte range [lo, lo + len) relative to `out`, first row r_lo = t_lo * B +
@@ -178,6 +186,29 @@ struct ChunkCoord {
 template <int MATH>
 __device__ __forceinline__ ChunkCoord chunk_coord(const EParams &p, int64_t k, int32_t rowbytes) {
     ChunkCoord c;
+    if (p.ragged) {
+        int64_t sl;
+        const int64_t t = div_by(k, p.npr8, p.inv_npr8, &sl);
+        const uint64_t a_t = reinterpret_cast<uintptr_t>(p.out) + static_cast<uint64_t>(t) * static_cast<uint64_t>(p.pitch + p.row_gap);
+        const int64_t h = static_cast<int64_t>(a_t & (kChunk - 1));
+        const int64_t d = (8 - static_cast<int64_t>((a_t >> 12) & 7u)) & 7;
+        const int64_t j = (sl & ~int64_t(7)) + ((sl + d) & 7);
+        int64_t lo_r = j * kChunk - h, hi_r = lo_r + kChunk;  // byte range relative to the row's first byte
+        if (lo_r < 0) lo_r = 0;
+        if (hi_r > p.pitch) hi_r = p.pitch;
+        c.live = k < p.nchunks && hi_r > lo_r;
+        c.lo = t * p.pitch + lo_r;  // (the kernels add t_lo * row_gap)
+        c.len = c.live ? static_cast<int32_t>(hi_r - lo_r) : 0;
+        c.t_lo = t;
+        c.b_lo = 0;
+        c.skip = c.nr = 0;
+        if (!c.live) return c;
+        int64_t skip64;
+        c.b_lo = div_by(lo_r, rowbytes, p.inv_rowbytes, &skip64);
+        c.skip = static_cast<int32_t>(skip64);
+        c.nr = static_cast<int32_t>(fast_div(static_cast<uint32_t>(c.skip + c.len + rowbytes - 1), p.rb_magic, p.rb_shift, p.rb_pow2));
+        return c;
+    }
     int64_t lo = k * kChunk - p.head, hi = lo + kChunk;  // byte range relative to `out`
     if (lo < 0) lo = 0;
     if (hi > p.total) hi = p.total;
@@ -926,6 +957,18 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
     e.total = P * B * C * int64_t(sz);
     e.head = int32_t(reinterpret_cast<uintptr_t>(out) & (kChunk - 1));
     e.nchunks = (e.head + e.total + kChunk - 1) / kChunk;
+    // a column block whose rows do not all start on chunk boundaries of memory: the ragged form (see EParams)
+    const int64_t block_row = B * C * int64_t(sz);
+    e.ragged = (row_gap != 0 && (e.head != 0 || block_row % kChunk != 0 || (block_row + row_gap) % kChunk != 0) && bsq_internal::tuning().expand_mode == 0 &&
+                bsq_internal::tuning().chunk_math == 0 && bsq_internal::tuning().xcd_claim == 0) ? 1 : 0;
+    e.npr8 = ((block_row + 2 * int64_t(kChunk) - 2) / kChunk + 7) / 8 * 8;
+    e.inv_npr8 = 1.0 / double(e.npr8);
+    if (e.ragged) {
+        e.head = 0;
+        e.nchunks = P * e.npr8;
+    } else if (row_gap != 0 && (e.head != 0 || block_row % kChunk != 0)) {
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "column block: its rows must be whole chunks under this knob");
+    }
     e.C = C;
     e.one_bits = one_bits;
     e.inv_rowbytes = 1.0 / double(C * int64_t(sz));
@@ -982,8 +1025,9 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
     pl.tiles_per_slice = pl.ntt;
     pl.wants_slices = false;
     const int64_t mb = tn.two_pass_slice_mb;
-    // (a column block -- row_gap != 0 -- needs every slice to start on a chunk boundary like the block itself: no chunk may straddle two rows)
-    const bool gap_ok = row_gap == 0 || (kTT * (k.B * rb + row_gap)) % kChunk == 0;
+    // (a column block -- row_gap != 0: a slice that does not start on a chunk boundary takes the ragged form, see EParams)
+    (void)row_gap;
+    const bool gap_ok = true;
     if (pb8 && mb >= 0 && tn.expand_mode == 0 && gap_ok) {
         const int64_t slice_bytes = (mb > 0 ? mb : 96) << 20;
         if ((mb > 0 && all_bytes > slice_bytes) || all_bytes > (int64_t(128) << 20)) {
@@ -1229,47 +1273,18 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
     // any multiple of 4096 sequences at a 4096-sequence boundary of an aligned tensor) is the two-pass stream with a gap after every
     // row: no chunk straddles two rows.  16 384-sequence blocks of cfg3: 4 x 0.19 ms against 4 x 0.25 ms for the tiles.
     const int64_t block_pitch = B * k.C * int64_t(sz), rb = k.C * int64_t(sz);
-    // (rows that the chunk stream expands well: 16 bytes and more, and -- end of round 5 -- one-byte rows of 3 ... 15 bytes through k_expand_rows1)
-    // (unmasked only: a masked raw pass is k_tokens_raw with byte ids -- such blocks stay with the tiled kernel as before)
+    // (rows that the chunk stream expands well: 16 bytes and more, and -- end of round 5 -- one-byte rows of 3 ... 15 bytes through
+    //  k_expand_rows1; unmasked only: a masked raw pass is k_tokens_raw with byte ids -- such blocks stay with the tiled kernel as before)
     const bool stream_rows = rb >= 16 || (sz == 1 && rb >= 3 && !k.mask && bsq_internal::tuning().expand_rows1 != 1);
-    // (the three-piece cut below stays with rows of 16 bytes and more: the 1/8 shard of cfg4 int8 stored into a root -- 122 880 sequences of
-    //  stream + 2 120 through a tile launch with its ~15-us floor -- took 50-57 us that way against 44 for one tiled launch)
-    if (block_path != 1 && rb >= 16 && !(block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0)) {
-        // Any other large block: the sequences up to the first one that starts a chunk of the result, the run of whole chunks behind
-        // it (a multiple of 4096 / gcd(row bytes, 4096) sequences), the rest -- three calls, the middle one the fast stream; worth it
-        // once the middle is large (the two short ones cost a ~15-us tile launch each).  Ragged shards of a sharded job
-        // (sharding.store_shard_into_root), the last piece of a host batch, results that torch aligned to 512 bytes only.
-        const int64_t mis = int64_t(reinterpret_cast<uintptr_t>(out) % kChunk);
-        int64_t g = rb, h = kChunk;
-        while (h) {
-            const int64_t r = g % h;
-            g = h;
-            h = r;
-        }
-        const int64_t m = kChunk / g;  // sequences per period of (b * rb) mod 4096
-        int64_t lead = -1;
-        for (int64_t b = 0; b < m && lead < 0; ++b)
-            if ((mis + b * rb) % kChunk == 0) lead = b;
-        const int64_t main = lead >= 0 && lead < B ? (B - lead) / m * m : 0;
-        if (main > 0 && main * rb * P >= (int64_t(128) << 20)) {
-            uint8_t *o = static_cast<uint8_t *>(out);
-            // (the two short pieces -- fewer than 4096 / gcd sequences each -- through the element kernel when they are small: the tiled
-            //  kernel has a ~15-us floor, and two of them in front of and behind a 90-us stream cost the 1/8 shard of cfg4 f32 a third of
-            //  its time, 127 vs 91 us: profiles/r05/bench_default.json, cfg4f_shard8.into_root)
-            auto side = [&](const int64_t *offs, int64_t n, uint8_t *dst) {
-                if (n * P * k.C <= (int64_t(1) << 21)) return bsq_internal::onehot_generic_block(d, chars, offs, mask_or_null, n, P, t, dst, row_seqs, hip_stream);
-                return bsq_onehot_block_device(d, chars, offs, mask_or_null, n, P, t, dst, row_seqs, hip_stream);
-            };
-            if (lead > 0) {
-                st = side(offsets, lead, o);
-                if (st != BSQ_OK) return st;
-            }
-            st = bsq_onehot_block_device(d, chars, offsets + lead, mask_or_null, main, P, t, o + lead * rb, row_seqs, hip_stream);
-            if (st != BSQ_OK || lead + main == B) return st;
-            return side(offsets + lead + main, B - lead - main, o + (lead + main) * rb);
-        }
-    }
-    if (block_path != 1 && stream_rows && block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0) {
+    const bool whole_chunks = block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0;
+    // A block whose position rows are whole 4-KiB chunks of memory is the two-pass stream with a gap after every row (16 384-sequence
+    // blocks of cfg3: 4 x 0.19 ms against 4 x 0.25 ms for the tiles).  Any other block of 128 MB and more -- ragged shards of a sharded job
+    // (sharding.store_shard_into_root), the last piece of a host batch, a tensor whose pitch is no multiple of 4 KiB -- takes the RAGGED
+    // form of the same stream (EParams::ragged: every row cut at the chunk boundaries of memory, its first and last piece partial).
+    // Rounds 4-5 cut such blocks in three calls instead (the sequences up to the first chunk boundary, the run of whole chunks, the
+    // rest): two ~15-us side launches, and only row 0 of the middle run aligned when the tensor's pitch was not.
+    // (knob onehot_path = 2: whatever the size -- tests)
+    if (block_path != 1 && stream_rows && (whole_chunks || block_pitch * P >= (int64_t(128) << 20) || bsq_internal::tuning().onehot_path == 2)) {
         if (const int64_t nb = two_pass_sequence_block(k, sz, out)) {  // (a block of very many short reads: sub-blocks, see bsq_onehot_device)
             for (int64_t b0 = 0; b0 < B; b0 += nb) {
                 const int64_t n = B - b0 < nb ? B - b0 : nb;

@@ -293,8 +293,8 @@ def store_shard_into_root(tokenizer, shard_chars, shard_offsets, b0: int, B: int
     the result, written by the streaming kernels; 'tokens_sf' -> the (padlen, B) token matrix (batch_tokenize's default layout):
     a column block through `bsq_tokenize_block_device`; 'tbc' -> the seq-first (padlen, B, C) one-hot: the shard is a column block
     of every position row and goes through `bsq_onehot_block_device` (the two-pass stream with a gap after every position
-    row for the run of whole 4-KiB chunks of a large shard, the tiled kernel with the root tensor's row pitch for its ragged
-    ends and for small shards; the xGMI links, not HBM, bound a remote store).  Returns the whole-batch tensor on `root`,
+    row, every row of the shard cut at the 4-KiB boundaries of the root's memory -- any first sequence, any pitch --; the tiled
+    kernel with the root tensor's row pitch for shards below 128 MB; the xGMI links, not HBM, bound a remote store).  Returns the whole-batch tensor on `root`,
     None elsewhere."""
     import ctypes
 

@@ -122,10 +122,11 @@ bsq_status bsq_onehot_bcl_device(const bsq_desc *d, const uint8_t *chars, const 
 /* The same one-hot written as a COLUMN BLOCK of a larger (P, row_seqs, C) tensor: `out` points at element (0, b0, 0) of it and
  * row t of this batch goes to out + t * row_seqs * C * sizeof(T).  What a rank of a sharded job needs to store its
  * sequences straight into the whole-batch tensor of another GPU (peer-mapped memory, sharding.store_shard_into_root), and what
- * a host batch that arrives in pieces is encoded with (staged batches, below).  A block whose position rows are whole 4-KiB
- * chunks (B * C * sizeof(T) and `out` multiples of 4096, rows >= 16 bytes) runs at the speed of the whole-tensor kernels; any
- * other LARGE block is split inside the call into the sequences in front of its first chunk boundary, the run of whole chunks,
- * and the rest (two short launches of the tiled kernel around the fast one); small blocks go through the tiled kernel. */
+ * a host batch that arrives in pieces is encoded with (staged batches, below).  A block of rows >= 16 bytes (or of one-byte
+ * elements with rows of 3 ... 15 bytes) whose position rows are whole 4-KiB chunks (B * C * sizeof(T) and `out` multiples of
+ * 4096), or any such block of 128 MB and more whatever its first sequence and the tensor's pitch, runs at the speed of the
+ * whole-tensor stream: every position row of the block is cut at the 4-KiB boundaries of MEMORY, only its first and last
+ * piece are partial.  Smaller unaligned blocks, masked small-row blocks go through the tiled kernel. */
 bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,
                                    const uint8_t *mask_or_null, int64_t B, int64_t P, bsq_dtype t, void *out, int64_t row_seqs,
                                    void *hip_stream);
@@ -273,8 +274,8 @@ bsq_status bsq_onehot_bcl_host(const bsq_desc *d, const uint8_t *chars, const in
  *                     -1 = the knob asks for the whole-batch path (host_pieces = 1).  *head_seqs: sequences the FIRST piece holds
  *                     in front of that (pieces [0, head + n), [head + n, head + 2n), ...): column blocks run fastest when they
  *                     start where a 4-KiB chunk of the result starts, and `out` is rarely aligned that far -- encode the head
- *                     with a call of its own (head_seqs may be NULL: pieces [0, n), [n, 2n), ..., each split inside
- *                     bsq_onehot_block_device where it must be).  Knob "host_pieces"; automatic = pieces of ~8 MB when the batch is large and hip_stream is idle (a busy
+ *                     with a call of its own (head_seqs may be NULL: pieces [0, n), [n, 2n), ..., each cut at the chunk
+ *                     boundaries of memory inside bsq_onehot_block_device).  Knob "host_pieces"; automatic = pieces of ~8 MB when the batch is large and hip_stream is idle (a busy
  *                     stream means the caller is not waiting for this batch: one upload costs the host less than several).
  * What it buys (list of 65 536 bytes objects, 35 MB -> f32 one-hot on the device, synchronous): 2.1 ms as one pack + one
  * upload + one encode, 1.5 ms with the encode and the pack of the pieces under the uploads (profiles/r04/host_pieces_lab.txt).
