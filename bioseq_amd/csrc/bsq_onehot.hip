@@ -1052,7 +1052,9 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
 int64_t two_pass_sequence_block(const KParams &k, size_t sz, const void *out) {
     const TwoPassPlan pl = two_pass_plan(k, sz, 0);
     // (fat position slices are fine; thin ones, and a matrix of a single tile -- padlen <= 64 -- that is too large all the same, are cut here)
-    if (!pl.wants_slices || pl.tiles_per_slice >= 4 || reinterpret_cast<uintptr_t>(out) % kChunk != 0) return 0;
+    // (any alignment of the result since the ragged block form: a tensor torch placed 2560 bytes off a chunk is cut like an aligned one)
+    (void)out;
+    if (!pl.wants_slices || pl.tiles_per_slice >= 4) return 0;
     const int64_t mb = bsq_internal::tuning().two_pass_slice_mb;
     const int64_t rb = k.C * int64_t(sz);
     int64_t g = rb, h = kChunk;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """int8 one-hots with rows of 3 ... 15 bytes over shapes: the tiled launch, the two-pass form on byte ids and on NIBBLE ids (both expanding
 through k_expand_rows1), and the automatic choice -- resident (one batch looped) and COLD (inputs and results cycling over > 600 MB of
-distinct buffers).  Every arm is compared with the tiled kernel's result first.      rows1_nib_sweep.py [first_shape [last_shape]]   (DT=f: float32 results)"""
+distinct buffers).  Every arm is compared with the tiled kernel's result first.      rows1_nib_sweep.py [first_shape [last_shape]]   (DT=f: float32 results; SHIFT=n: results n bytes off a 4-KiB boundary)"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,7 +44,9 @@ for si, (key, flags, B, lo, hi, P) in list(enumerate(SHAPES))[lo_i:hi_i]:
     algo = int(offs[-1]) + 8 * (B + 1) + ob
     K = max(2, -(-600_000_000 // algo) + 1)
     ins = [(torch.from_numpy(chars).to(dev), torch.from_numpy(offs).to(dev)) for _ in range(K)]
-    outs = [torch.empty(ob, dtype=torch.uint8, device=dev) for _ in range(K)]
+    SHIFT = int(os.environ.get("SHIFT", "0"))   # results that many bytes off a 4-KiB boundary (torch aligns sub-allocations to 512 bytes only)
+    bufs = [torch.empty(ob + 8192, dtype=torch.uint8, device=dev) for _ in range(K)]
+    outs = [b[(-b.data_ptr()) % 4096 + SHIFT:][:ob] for b in bufs]
     ref = torch.empty(ob, dtype=torch.uint8, device=dev)
 
     def run(i):
@@ -74,6 +76,6 @@ for si, (key, flags, B, lo, hi, P) in list(enumerate(SHAPES))[lo_i:hi_i]:
         res.append("%s %.1f us (%.3f) cold %.1f us (%.3f)" % (name, r * 1e3, algo / r / 8e9, c * 1e3, algo / c / 8e9))
     kn = lib.bsq_onehot_kernel_name(ctypes.byref(desc), B, P, dt)
     print("%-6s %s B=%7d P=%4d C=%2d out=%5.2f GB K=%d | %s | auto = %s" % (key, flags, B, P, C, ob / 1e9, K, " | ".join(res), kn.decode() if kn else ""), flush=True)
-    del ins, outs, ref
+    del ins, outs, bufs, ref
     torch.cuda.empty_cache()
 setk()

@@ -111,8 +111,8 @@ def test_two_pass_slices_equal_the_oracle(gpu, bsq, oracle, knobs, key, flags, l
     lib = knobs
     ora = oracle.OracleTokenizer(key, *flags)
     dev = torch.device("cuda:0")
-    # (aligned results with thin position slices -- fewer than four tiles -- are cut by SEQUENCES into column blocks instead: the first, second and
-    #  fourth shape; the third is misaligned and keeps its thin position slices; the fifth has fat ones: four slices of eight tiles)
+    # (results with thin position slices -- fewer than four tiles -- are cut by SEQUENCES into column blocks instead: the first, second and
+    #  fourth shape, and the third, which is misaligned: its blocks take the ragged form; the fifth has fat slices: four of eight tiles)
     for si, (B, P, shift) in enumerate([(20000, 300, 0), (9001, 257, 0), (5000, 1000, 3), (70000, 129, 0), (2000, 2048, 0), (50000, 48, 0)]):   # (the last: ONE position tile, too large all the same -- sequence blocks)
         hi = P - flags[0] - flags[1]
         chars, offs = synth.synth_packed(5000 + si, B, 0, hi, letters)
