@@ -68,6 +68,27 @@ def run(budget=120.0, seed=1):
             assert g.dtype == e.dtype and g.shape == e.shape and g.tobytes() == e.tobytes(), "onehot"
             g = tok.onehot_packed(dch, dof, P, d, mask=dm, layout="bcl").cpu().numpy()
             assert g.tobytes() == np.ascontiguousarray(e.transpose(1, 2, 0)).tobytes(), "onehot bcl"
+            if mask is None and rng.random() < 0.35:  # the seq-first one-hot written as COLUMN BLOCKS of the whole tensor, any cuts, any alignment
+                dt = ctypes.c_int(0)
+                capi.check(lib.bsq_dtype_from_destchar(d.encode(), ctypes.byref(dt)))
+                cdesc = capi.make_desc(key, eos, bos, pad)
+                rowb = e.shape[2] * e.dtype.itemsize
+                cuts = sorted(set([0, B] + [int(x) for x in rng.integers(0, B + 1, int(rng.integers(1, 4)))]))
+                root = torch.full((e.nbytes + 32768,), 0x5A, dtype=torch.uint8, device=dev)   # (room for the largest shift: 2560 x 8 bytes)
+                base = (-root.data_ptr()) % 4096 + int(rng.choice([0, 0, 512, 2560, 16, 1])) * e.dtype.itemsize
+                for b0, b1 in zip(cuts[:-1], cuts[1:]):
+                    sub = dof[b0:b1 + 1].contiguous()   # (absolute offsets into dch)
+                    capi.check(lib.bsq_onehot_block_device(ctypes.byref(cdesc), dch.data_ptr(), sub.data_ptr(), None, b1 - b0, P, dt,
+                                                           root.data_ptr() + base + b0 * rowb, B, None))
+                h = root.cpu().numpy()
+                if h[base:base + e.nbytes].tobytes() != e.tobytes():   # which block, where, under which knobs
+                    got, exp = h[base:base + e.nbytes].reshape(e.shape[0], -1), np.frombuffer(e.tobytes(), np.uint8).reshape(e.shape[0], -1)
+                    where = [(b0, b1, np.argwhere(got[:, b0 * rowb:b1 * rowb] != exp[:, b0 * rowb:b1 * rowb])[[0, -1]].tolist(),
+                              int((got[:, b0 * rowb:b1 * rowb] != exp[:, b0 * rowb:b1 * rowb]).sum()))
+                             for b0, b1 in zip(cuts[:-1], cuts[1:]) if not np.array_equal(got[:, b0 * rowb:b1 * rowb], exp[:, b0 * rowb:b1 * rowb])]
+                    state = {k.decode(): lib.bsq_tuning_get(k) for k in (b"onehot_path", b"tile_order", b"raw_mode", b"tokens_pb8", b"expand_rows1", b"raw_nibbles", b"two_pass_slice_mb", b"tokens8_lookup")}
+                    raise AssertionError(("column blocks", cuts, base % 4096, rowb, where, state))
+                assert (h[:base] == 0x5A).all() and (h[base + e.nbytes:] == 0x5A).all(), ("column blocks wrote outside the root", cuts)
             if rng.random() < 0.3:  # augmentation + tokens in one call == the two calls (fused launch or not, any shape / type / layout)
                 from bioseq_amd import blosum
                 cl, fr, sd = int(rng.integers(0, 4)), float(rng.choice([0.3, 0.5, 1.0])), int(rng.integers(1 << 30))
