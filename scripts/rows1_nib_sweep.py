@@ -21,7 +21,12 @@ SHAPES = [("DNA4", (1, 1, 1), 1000000, 150, 150, 160), ("DNA4", (1, 1, 1), 50000
           ("DNA4", (1, 1, 1), 1048576, 150, 150, 160), ("DNA4", (1, 1, 1), 524288, 100, 250, 256), ("DNA4", (1, 1, 1), 262144, 250, 300, 320),
           ("DNA5", (0, 0, 0), 1048576, 150, 150, 160),
           ("DNA4", (1, 1, 1), 299968, 300, 598, 600), ("DNA4", (1, 1, 1), 100032, 500, 1498, 1500), ("DNA4", (1, 1, 1), 262144, 300, 446, 448),
-          ("DNA4", (1, 1, 1), 200000, 300, 598, 600), ("DNA4", (1, 1, 1), 131072, 500, 1022, 1024), ("DNA5", (0, 0, 0), 299968, 300, 598, 600)]
+          ("DNA4", (1, 1, 1), 200000, 300, 598, 600), ("DNA4", (1, 1, 1), 131072, 500, 1022, 1024), ("DNA5", (0, 0, 0), 299968, 300, 598, 600),
+          # (35 ...) mid-size results at aligned pitches: where should the 192-MB threshold of the one-byte rows be?
+          ("DNA4", (1, 1, 1), 16384, 150, 150, 160), ("DNA4", (1, 1, 1), 32768, 150, 150, 160), ("DNA4", (1, 1, 1), 65536, 150, 150, 160),
+          ("DNA4", (1, 1, 1), 131072, 150, 150, 160), ("DNA4", (1, 1, 1), 16384, 300, 510, 512), ("DNA4", (1, 1, 1), 32768, 300, 510, 512),
+          ("DNA4", (1, 1, 1), 8192, 300, 1022, 1024), ("DNA5", (0, 0, 0), 65536, 150, 150, 160), ("SEB14", (0, 0, 0), 16384, 300, 510, 512),
+          ("SEB14", (0, 0, 0), 32768, 300, 510, 512), ("SEB8", (1, 1, 1), 65536, 100, 254, 256)]
 DT = os.environ.get("DT", "B")   # destchar: B = int8 (the rows1 forms), f = float32 (k_expand_chunks; the sequence-block cut of very large batches)
 SZ = {"B": 1, "f": 4}[DT]
 lo_i = int(sys.argv[1]) if len(sys.argv) > 1 else 0
