@@ -1006,7 +1006,7 @@ struct TwoPassPlan {
     int64_t ntt, tiles_per_slice;
     size_t ws_bytes;
 };
-TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
+TwoPassPlan two_pass_plan(const KParams &k, size_t sz) {
     const auto &tn = bsq_internal::tuning();
     TwoPassPlan pl;
     pl.pitch = two_pass_pitch(k.B);  // padded: every scratch row is aligned, full-width vector stores
@@ -1025,10 +1025,8 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
     pl.tiles_per_slice = pl.ntt;
     pl.wants_slices = false;
     const int64_t mb = tn.two_pass_slice_mb;
-    // (a column block -- row_gap != 0: a slice that does not start on a chunk boundary takes the ragged form, see EParams)
-    (void)row_gap;
-    const bool gap_ok = true;
-    if (pb8 && mb >= 0 && tn.expand_mode == 0 && gap_ok) {
+    // (slices of a column block that do not start on a chunk boundary take the ragged form, see EParams: no condition on the gap)
+    if (pb8 && mb >= 0 && tn.expand_mode == 0) {
         const int64_t slice_bytes = (mb > 0 ? mb : 96) << 20;
         if ((mb > 0 && all_bytes > slice_bytes) || all_bytes > (int64_t(128) << 20)) {
             pl.wants_slices = true;
@@ -1050,7 +1048,7 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz, int64_t row_gap) {
 // two-pass stream of its own with a gap after every position row (bsq_onehot_block_device) whose ids fit the slice target in one piece.
 // Returns nb, or 0 when the batch is not to be cut this way.
 int64_t two_pass_sequence_block(const KParams &k, size_t sz, const void *out) {
-    const TwoPassPlan pl = two_pass_plan(k, sz, 0);
+    const TwoPassPlan pl = two_pass_plan(k, sz);
     // (fat position slices are fine; thin ones, and a matrix of a single tile -- padlen <= 64 -- that is too large all the same, are cut here)
     // (any alignment of the result since the ragged block form: a tensor torch placed 2560 bytes off a chunk is cut like an aligned one)
     (void)out;
@@ -1077,7 +1075,7 @@ int64_t two_pass_sequence_block(const KParams &k, size_t sz, const void *out) {
 // The caller holds nothing: the scratch is acquired here (shared by the calls of one stream -- workspace cache --, so the launches of a
 // call are enqueued back to back under the workspace mutex).
 bsq_status onehot_two_pass(KParams &k, size_t sz, hipStream_t s, int64_t row_gap = 0) {
-    const TwoPassPlan pl = two_pass_plan(k, sz, row_gap);
+    const TwoPassPlan pl = two_pass_plan(k, sz);
     std::lock_guard<std::mutex> two_pass_turn(bsq_internal::workspace_mutex());
     void *ws = nullptr;
     bsq_status st = bsq_internal::workspace_acquire(pl.ws_bytes, s, &ws);
@@ -1199,7 +1197,7 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
             kp.B = B;
             kp.P = P;
             kp.C = bsq_alphabet_size(d);
-            if (two_pass_plan(kp, bsq_dtype_size(t), 0).nib)
+            if (two_pass_plan(kp, bsq_dtype_size(t)).nib)
                 return rows1 ? "k_tokens_pb8_fast<raw, nibbles>+k_expand_rows1<nibbles>" : "k_tokens_pb8_fast<raw, nibbles>+k_expand_chunks<nibbles>";
             return rows1 ? "k_tokens_pb8_fast<raw>+k_expand_rows1" : "k_tokens_pb8_fast<raw>+k_expand_chunks";
         }
@@ -1271,16 +1269,14 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
     if (block_path == 0) return bsq_internal::onehot_generic_block(d, chars, offsets, mask_or_null, B, P, t, out, row_seqs, hip_stream);
     k.one_bits = one_bits_of(t);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    // A block whose position rows are whole 4-KiB chunks (B * C * sizeof(T) and the address of its first element multiples of 4096: e.g.
-    // any multiple of 4096 sequences at a 4096-sequence boundary of an aligned tensor) is the two-pass stream with a gap after every
-    // row: no chunk straddles two rows.  16 384-sequence blocks of cfg3: 4 x 0.19 ms against 4 x 0.25 ms for the tiles.
     const int64_t block_pitch = B * k.C * int64_t(sz), rb = k.C * int64_t(sz);
     // (rows that the chunk stream expands well: 16 bytes and more, and -- end of round 5 -- one-byte rows of 3 ... 15 bytes through
     //  k_expand_rows1; unmasked only: a masked raw pass is k_tokens_raw with byte ids -- such blocks stay with the tiled kernel as before)
     const bool stream_rows = rb >= 16 || (sz == 1 && rb >= 3 && !k.mask && bsq_internal::tuning().expand_rows1 != 1);
     const bool whole_chunks = block_pitch % kChunk == 0 && reinterpret_cast<uintptr_t>(out) % kChunk == 0;
-    // A block whose position rows are whole 4-KiB chunks of memory is the two-pass stream with a gap after every row (16 384-sequence
-    // blocks of cfg3: 4 x 0.19 ms against 4 x 0.25 ms for the tiles).  Any other block of 128 MB and more -- ragged shards of a sharded job
+    // A block whose position rows are whole 4-KiB chunks of memory (B * C * sizeof(T) and the address of its first element multiples of
+    // 4096: e.g. any multiple of 4096 sequences at a 4096-sequence boundary of an aligned tensor) is the two-pass stream with a gap after
+    // every row: no chunk straddles two rows (16 384-sequence blocks of cfg3: 4 x 0.19 ms against 4 x 0.25 ms for the tiles).  Any other block of 128 MB and more -- ragged shards of a sharded job
     // (sharding.store_shard_into_root), the last piece of a host batch, a tensor whose pitch is no multiple of 4 KiB -- takes the RAGGED
     // form of the same stream (EParams::ragged: every row cut at the chunk boundaries of memory, its first and last piece partial).
     // Rounds 4-5 cut such blocks in three calls instead (the sequences up to the first chunk boundary, the run of whole chunks, the
