@@ -150,3 +150,20 @@ def test_environment_cannot_reach_result_changing_knobs():
     env = dict(os.environ, BSQ_TOKENS8_ABL="4", BSQ_EXPAND_MODE="9", BSQ_ONEHOT_PATH="2")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, check=True).stdout.split()
     assert out == ["0", "0", "2", "1"], out
+
+
+def test_onehot_path_rule_for_one_byte_rows():
+    """The automatic kernel choice for int8 one-hots with rows of 3 ... 15 bytes (end of round 5; no device needed: the rule is host code).
+    From 192 MB on: 7- ... 15-byte rows always take nibble ids + the LDS-free expansion; 3- ... 6-byte rows unless the reads are long
+    (padlen >= 512) AND the row pitch is a multiple of 4 KiB; below 192 MB aligned tensors stay tiled, tensors whose position rows are
+    not 64-byte aligned go two-pass from 32 MB.  (profiles/r05/rows1_nib_sweep.txt)"""
+    from bioseq_amd import capi
+    lib = capi.load()
+    two = b"k_tokens_pb8_fast<raw, nibbles>+k_expand_rows1<nibbles>"
+    name = lambda key, flags, B, P: lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc(key, *flags)), B, P, capi.I8)
+    for key, flags, B, P, want in [("DNA4", (1, 1, 1), 1000000, 160, two), ("DNA4", (1, 1, 1), 262144, 512, two), ("DNA4", (1, 1, 1), 65536, 2048, two),
+                                   ("DNA4", (0, 0, 0), 1000000, 160, two), ("DNA5", (0, 0, 0), 1048576, 160, two), ("DNA5", (0, 0, 0), 299968, 600, two),
+                                   ("DNA5", (0, 0, 0), 131072, 1024, b"k_onehot_tile"), ("DNA4", (1, 1, 0), 262144, 512, b"k_onehot_tile"),
+                                   ("DNA4", (1, 1, 1), 131072, 160, b"k_onehot_tile"), ("DNA4", (1, 1, 1), 125000, 160, two),
+                                   ("SEB14", (0, 0, 0), 131072, 512, two), ("SEB8", (1, 1, 1), 262144, 512, two), ("SEB14", (0, 0, 0), 16384, 512, b"k_onehot_tile")]:
+        assert name(key, flags, B, P) == want, (key, flags, B, P, name(key, flags, B, P))
