@@ -31,6 +31,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 more than 512 MiB (past the 256-MiB Infinity Cache -- a training loop never encodes one batch twice).  Since round 5
                 the cold regime's figures ARE the token workloads' `frac` / `ms_per_step` (their working sets fit the Infinity Cache);
                 the loop over one resident batch is beside them as `frac_cache_resident` / `ms_per_step_cache_resident`.
+                `cold.two_streams` (token workloads): the same cold batches with two streams taking turns -- consecutive batches are
+                independent, and only a caller knows that; a side figure (host clock), never `frac` or `value`.
                 `<w>_shard8` (cfg3, cfg4f, cfg4b, cfg5aug): rank 0's sharding.shard_bounds share of the workload's batch split over 8
                 ranks -- the per-GPU term of the 1/2/4/8 strong-scaling curve, measured on this one GPU -- as a tensor of its own
                 (checked against reference-made folds) and written straight into a whole-batch root tensor (`into_root`: a column
@@ -551,6 +553,39 @@ def cold_regime(b, steps, min_s, stream, verify=True):
            "ms_per_step": loop_ms, "frac": b.algo_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "sustained_steps": n_sus, "sustained_ms_per_step": sus_ms,
            "frac_sustained": b.algo_bytes / (sus_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    # Beside the in-order figure: the same cold batches with TWO streams taking turns.  Consecutive batches are independent, but only
+    # the caller knows that -- on one stream every launch waits for the one before it, so each 16-40-us launch pays its own ramp-up and
+    # drain; on two streams the tail of one hides under the head of the next (round 5, scripts/two_stream_lab.py: cfg2 22.1 -> 18.1 us per
+    # batch, the cold copy stream's own rate).  Host clock over N launches between two device synchronisations; never `frac`, never
+    # `value`; token workloads only (the fused augmentation restores its pristine characters on the main stream); a failure here is
+    # recorded, not raised.
+    if b.op == "tokenize":
+        try:
+            import ctypes
+            side = torch.cuda.Stream(device=dev)
+            handles = [b.sh, ctypes.c_void_p(side.cuda_stream)]
+
+            def run2(nl):
+                for i in range(nl):
+                    b.sh = handles[i & 1]
+                    one(i % nb, i)
+
+            torch.cuda.synchronize()
+            run2(4 * nb)
+            torch.cuda.synchronize()
+            nl = max(1000, 2 * steps)
+            t0 = time.perf_counter()
+            run2(nl)
+            torch.cuda.synchronize()
+            two_ms = (time.perf_counter() - t0) / nl * 1e3
+            res["two_streams"] = {"ms_per_step": two_ms, "frac": b.algo_bytes / (two_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches": nl,
+                                  "what": "the same cold batches, two streams taking turns (independent batches; host clock between two "
+                                          "synchronisations) -- what a loader that alternates streams gets; not the in-order figure above"}
+        except Exception as ex:  # noqa: BLE001 -- a side measurement must never cost the driver its line
+            res["two_streams"] = {"error": repr(ex)}
+        finally:
+            b.sh = handles[0] if "handles" in locals() else b.sh
+            torch.cuda.synchronize()
     # untimed: every batch once more from its pristine characters, compared with batch 0's output rotated
     if not verify:
         res["check"] = "none (a lab run with result-changing ablations)"
