@@ -803,6 +803,91 @@ def run_config(name, lib, dev, stream, steps, warmup):
     return res
 
 
+LINE_LIMIT = 4096  # bytes: the driver's reader lost round 5's 22-KB line (BENCH_r05.json: parsed null); 11.5 KB still parsed in round 4
+
+
+def _r(v, sig=5):
+    """floats to `sig` significant digits (the line is a record, not a transport for doubles); everything else unchanged"""
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, v))
+    return v
+
+
+def compact_line(res):
+    """The ONE stdout line: the contract's keys + `roofline` + `cpu_baseline` + `check.ok` + `build_id`, and `configs` reduced to
+    {name: {ms, frac, cold, ok}} -- at most LINE_LIMIT bytes whatever was measured.  Everything else of `res` (sustained, e2e, two_streams,
+    into_root, yardsticks, prose) goes to bench_full.json (`emit`)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _r(res[k], 7) for k in keep if k in res}
+    cfg = res.get("config") or {}
+    line["config"] = {k: cfg[k] for k in ("workload", "sequences_per_gpu", "padlen", "channels", "input_chars_per_gpu", "output_bytes_per_gpu",
+                                          "job_sequences", "rccl_world_size", "backend") if k in cfg}
+    if "sharding" in cfg:
+        line["config"]["sharding"] = cfg["sharding"].split(";")[0][:48]
+    rf = res.get("roofline") or {}
+    line["roofline"] = {k: _r(rf.get(k), 6) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "kernel",
+                                                      "algorithmic_bytes_per_launch", "kernel_avg_ms") if k in rf}
+    for k in ("frac_wall", "frac_of_fill", "frac_of_copy_mix"):
+        if rf.get(k) is not None:
+            line["roofline"][k] = _r(rf[k], 4)
+    cb = res.get("cpu_baseline")
+    if cb:
+        c = {k: _r(cb.get(k)) for k in ("cpu_model", "value", "unit", "cores", "kind", "seconds") if k in cb}
+        c["sample"] = (cb.get("sample") or "")[:100]
+        st = cb.get("single_thread")
+        if st:
+            c["single_thread"] = {"value": _r(st.get("value")), "cores": st.get("cores")}
+        line["cpu_baseline"] = c
+    line["gb_per_s_written"] = _r(res.get("gb_per_s_written"))
+    line["check"] = {"ok": bool((res.get("check") or {}).get("ok"))}
+    line["build_id"] = res.get("build_id")
+    for k in ("cold", "shard"):
+        if isinstance(res.get(k), dict):
+            line[k] = {"ms": _r(res[k].get("ms_per_step"), 4), "frac": _r(res[k].get("frac"), 4)}
+    if isinstance(res.get("gather"), dict):
+        g = res["gather"]
+        line["gather"] = {"rccl_world_size": g.get("rccl_world_size"), "rccl_version": g.get("rccl_version"),
+                          "ms": {k: _r(v.get("ms"), 4) for k, v in (g.get("forms") or {}).items()}}
+    if "fused_wait_failures" in res:
+        line["fused_wait_failures"] = res["fused_wait_failures"]
+    if res.get("configs"):
+        line["configs"] = {}
+        for name, c in res["configs"].items():
+            e = {"ms": _r(c.get("ms_per_step"), 4), "frac": _r(c.get("frac"), 3), "cold": "cold" in c, "ok": bool((c.get("check") or {}).get("ok"))}
+            m4 = ((c.get("cold") or {}).get("multi4") or {}).get("frac")
+            if m4 is not None:
+                e["multi4"] = _r(m4, 3)
+            line["configs"][name] = e
+    line["full"] = "bench_full.json"
+    text = json.dumps(line, separators=(",", ":"))
+    # whatever a future round adds: the line never outgrows its reader again (drop the optional parts in this order)
+    for drop in ("gather", "shard", "cold", "configs"):
+        if len(text.encode()) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text.encode()) <= LINE_LIMIT, len(text.encode())
+    return text
+
+
+def emit(res, full_line=False):
+    """Full result -> bench_full.json beside this script (and under gpurun_out/ when that exists, so it comes back from the GPU box);
+    the compact line -> stdout, the ONLY thing this process prints there."""
+    blob = json.dumps(res, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, os.environ.get("BSQ_BENCH_FULL", "bench_full.json")), "w") as f:
+                    f.write(blob + "\n")
+            except OSError as ex:
+                print("bench.py: could not write bench_full.json into %s: %r" % (d, ex), file=sys.stderr)
+    sys.stdout.flush()
+    print(json.dumps(res) if full_line else compact_line(res), flush=True)
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -829,6 +914,9 @@ def main():
                     help="N > 1 only: additionally time K whole-batch assemblies over xGMI in every form (all_gather + "
                          "concatenate, grouped point-to-point straight into the destination, to a root and to every "
                          "rank, token matrices + local expansion); reported separately as `gather`, never part of `value`")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the FULL result object on stdout (the lab scripts and gpu_evidence.sh read it) instead of the compact "
+                         "<= 4-KB line the driver parses; bench_full.json is written either way")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -1145,7 +1233,7 @@ def main():
                     full_ms = loop_ms if wname == args.workload else (full or {}).get("ms_per_step_cache_resident", (full or {}).get("ms_per_step"))
                     full_cold = ((full or {}).get("cold") or {}).get("ms_per_step")
                     res["configs"]["%s_shard8" % wname] = run_shard(wname, 8, lib, dev, stream, args.steps, args.warmup, full_ms=full_ms, full_cold_ms=full_cold)
-        print(json.dumps(res), flush=True)
+        emit(res, args.full_line)
     if world > 1:
         dist.destroy_process_group()
 

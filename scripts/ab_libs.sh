@@ -3,7 +3,7 @@
 # source states) on the bench workloads given as arguments and on the (P,B) int8 token shapes.
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
-one() { timeout 300 python3 bench.py --workload $1 --steps 40 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('ms/step %.4f kernel %.4f frac %.3f' % (d['ms_per_step'], r['kernel_avg_ms'], r['frac']))"; }
+one() { timeout 300 python3 bench.py --full-line --workload $1 --steps 40 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('ms/step %.4f kernel %.4f frac %.3f' % (d['ms_per_step'], r['kernel_avg_ms'], r['frac']))"; }
 for rep in 1 2; do
   for v in old new; do
     cp ab/$v.so bioseq_amd/libbsq_hip.so

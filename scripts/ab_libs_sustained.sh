@@ -2,7 +2,7 @@
 # Run ON the GPU box: ab/old.so vs ab/new.so on bench workloads (arguments), interleaved, 3 repetitions; loop and sustained averages.
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
-one() { timeout 300 python3 bench.py --workload $1 --no-cpu-baseline --no-e2e 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('loop %.2f us sustained %.2f us frac %.3f' % (r['kernel_avg_ms']*1e3, d['sustained']['kernel_avg_ms']*1e3, d['sustained']['frac']))"; }
+one() { timeout 300 python3 bench.py --full-line --workload $1 --no-cpu-baseline --no-e2e 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('loop %.2f us sustained %.2f us frac %.3f' % (r['kernel_avg_ms']*1e3, d['sustained']['kernel_avg_ms']*1e3, d['sustained']['frac']))"; }
 for rep in 1 2 3; do
   for v in old new; do
     cp ab/$v.so bioseq_amd/libbsq_hip.so

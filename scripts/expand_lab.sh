@@ -3,7 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 run() { # label, env...
   local label=$1; shift
-  r=$(env "$@" timeout 300 python3 "$REPO/bench.py" --workload $W --steps 30 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('ms %.4f min %.4f frac %.3f' % (r['kernel_avg_ms'], r['kernel_min_ms'], r['frac']))")
+  r=$(env "$@" timeout 300 python3 "$REPO/bench.py" --full-line --workload $W --steps 30 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('ms %.4f min %.4f frac %.3f' % (r['kernel_avg_ms'], r['kernel_min_ms'], r['frac']))")
   echo "$W $label: $r"
 }
 for W in cfg4f cfg4b; do

@@ -15,7 +15,7 @@
 # Every rocprofv3 command runs `python3 bench.py ...` directly (no env / bash -c hop) under its own timeout; counters are never combined
 # with a trace domain.
 set -u
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 ALL="cfg3 cfg3b cfg2 cfg2sf cfg5 cfg5aug cfg4f cfg4b cfg3bcl"
 MODE=${1:-all}; shift || true
@@ -26,8 +26,11 @@ do_tests() { ( cd "$REPO" && time timeout 3000 python3 -m pytest tests -m gpu -q
 do_fuzz() { ( cd "$REPO" && timeout $(( ${1:-300} + 600 )) python3 tests/fuzz_gpu.py "${1:-300}" "${2:-77}" ) 2>&1 | tail -2 | tee "$OUT/fuzz.txt"; }
 do_bench() {
   cd "$REPO"
-  ( time python3 bench.py ) > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-  for w in $ALL; do python3 bench.py --workload $w --no-configs --no-cpu-baseline --cold > "$OUT/bench_$w.json" 2>> "$OUT/bench.err"; done
+  # exactly the driver's command: its stdout is the compact <= 4-KB line; the full object lands in bench_full.json beside bench.py
+  ( time python3 bench.py ) > "$OUT/bench_default_line.json" 2> "$OUT/bench_default.err"
+  cp "$REPO/bench_full.json" "$OUT/bench_default.json"
+  wc -c "$OUT/bench_default_line.json"
+  for w in $ALL; do python3 bench.py --full-line --workload $w --no-configs --no-cpu-baseline --cold > "$OUT/bench_$w.json" 2>> "$OUT/bench.err"; done
   python3 - "$OUT" $ALL <<'PY' | tee "$OUT/bench_lines.txt"
 import json, sys
 out = sys.argv[1]
@@ -51,7 +54,7 @@ PY
 do_profile() {
   for w in "$@"; do
     P=$REPO/gpurun_out/${TAG}_$w; mkdir -p "$P"; cd /tmp
-    A="--workload $w --no-configs --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-sustained"
+    A="--full-line --workload $w --no-configs --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-sustained"
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -- python3 "$REPO/bench.py" $A > "$P/bench_trace.json" 2> "$P/trace.err"
     timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P/pmc_write" -- python3 "$REPO/bench.py" $A > "$P/bench_pmc_write.json" 2> "$P/pmc_write.err"
     timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P/pmc_fetch" -- python3 "$REPO/bench.py" $A > "$P/bench_pmc_fetch.json" 2> "$P/pmc_fetch.err"

@@ -138,3 +138,51 @@ def test_shard_folds_are_reproduced_by_the_oracle(bench, oracle):
     out = oracle.OracleTokenizer(c["key"], c["eos"], c["bos"], c["padchar"]).onehot_packed(chars, offs, c["padlen"], "B", 8)
     x, s, ws = _np_fold(out)
     assert (x, s, ws, out.nbytes) == (folds["xor"], folds["sum"], folds["wsum"], folds["nbytes"])
+
+
+def test_driver_line_is_compact_and_round_trips(bench, tmp_path, monkeypatch, capsys):
+    """round 5's 22-KB line was not parsed by the driver (BENCH_r05.json: parsed null).  The line bench.py
+    prints is built from the full result by `compact_line`: at most 4096 bytes, the contract's keys + roofline + cpu_baseline, whatever
+    was measured -- here from round 5's own full result (profiles/r05/bench_default.json) and from a grotesquely inflated one."""
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r05", "bench_default.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000   # the object that broke the reader
+    text = bench.compact_line(full)
+    assert len(text.encode()) < 4096 and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in line, k
+    assert line["metric"] == full["metric"] and line["n_gpus"] == 1 and line["vs_baseline"] is None
+    assert abs(line["value"] - full["value"]) < 1e-5 * full["value"] and abs(line["ms_per_step"] - full["ms_per_step"]) < 1e-5 * full["ms_per_step"]
+    assert line["config"]["workload"].startswith("cfg3:") and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["traffic"] == full["roofline"]["traffic"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and abs(r["frac"] - full["roofline"]["frac"]) < 1e-5
+    assert r["algorithmic_bytes_per_launch"] == 5404354664 and r["kernel"] and r["kernel_avg_ms"] > 0
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["single_thread"]["cores"] == 1
+    assert line["check"] == {"ok": True} and line["build_id"] == full["build_id"]
+    assert set(line["configs"]) == set(full["configs"])
+    for name, e in line["configs"].items():
+        assert set(e) <= {"ms", "frac", "cold", "ok", "multi4"} and e["ok"] is True
+        assert abs(e["frac"] - full["configs"][name]["frac"]) < 6e-4
+    # whatever a later round measures, the line stays under the limit: optional parts are dropped, the contract's keys never
+    fat = json.loads(json.dumps(full))
+    for i in range(300):
+        fat["configs"]["extra_workload_with_a_long_name_%d" % i] = dict(full["configs"]["cfg2"])
+    fat["config"]["sharding"] = "x" * 5000
+    fat["cpu_baseline"]["sample"] = "y" * 5000
+    text = bench.compact_line(fat)
+    assert len(text.encode()) <= 4096
+    line = json.loads(text)
+    assert "roofline" in line and "cpu_baseline" in line and "configs" not in line and line["value"] > 0
+    # NaN / inf never reach the line (json.loads of the driver would choke on them)
+    bad = json.loads(json.dumps(full))
+    bad["roofline"]["frac_of_copy_mix"] = float("nan")
+    bad["configs"]["cfg2"]["ms_per_step"] = float("inf")
+    assert "NaN" not in bench.compact_line(bad) and "Infinity" not in bench.compact_line(bad)
+    # emit(): stdout is exactly that one line; the full object goes to bench_full.json
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(full)
+    out = capsys.readouterr().out
+    assert out.count("\n") == 1 and json.loads(out) == json.loads(bench.compact_line(full))
+    assert json.load(open(tmp_path / "bench_full.json")) == full
