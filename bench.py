@@ -586,6 +586,37 @@ def cold_regime(b, steps, min_s, stream, verify=True):
         finally:
             b.sh = handles[0] if "handles" in locals() else b.sh
             torch.cuda.synchronize()
+    # The same cold batches FOUR PER LAUNCH (round 6: bsq_tokenize_device_multi -- the grid is the concatenation of four batches' grids,
+    # one ramp-up and one drain per launch): what an in-order caller that has its next batches at hand gets on ONE stream.  HIP events
+    # on the launch stream; per BATCH; never `frac` or `value` of the workload (those stay the one-batch-per-launch figures).
+    multi_out = None
+    if b.op == "tokenize" and hasattr(b.lib, "bsq_tokenize_device_multi"):
+        import ctypes
+        per = 4
+        groups = []
+        for g in range(nb // per):
+            arr = (capi.Batch * per)()
+            for j in range(per):
+                ch, of, out, _ = batches[g * per + j]
+                arr[j].chars, arr[j].offsets, arr[j].B, arr[j].out = ch.data_ptr(), of.data_ptr(), n, out.data_ptr()
+            groups.append(arr)
+        gi = [0]
+
+        def stepm():
+            st = b.lib.bsq_tokenize_device_multi(ctypes.byref(b.desc), per, groups[gi[0] % len(groups)], b.P, int(b.batch_first), b.dt_code, b.sh)
+            if st:
+                capi.check(st)
+            gi[0] += 1
+
+        for _, _, out, _ in batches:
+            out.fill_(7)
+        for _ in groups:
+            stepm()
+        torch.cuda.synchronize()
+        multi_out = [batches[k][2].clone() for k in range(len(groups) * per)] if verify else None
+        m_ms = timed_loop(stepm, max(200, n_sus // per), 4 * len(groups), stream) / per
+        res["multi4"] = {"ms_per_step": m_ms, "frac": b.algo_bytes / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "batches_per_launch": per,
+                         "what": "bsq_tokenize_device_multi: four of the cold batches per launch on the one in-order stream, per batch"}
     # untimed: every batch once more from its pristine characters, compared with batch 0's output rotated
     if not verify:
         res["check"] = "none (a lab run with result-changing ablations)"
@@ -598,6 +629,11 @@ def cold_regime(b, steps, min_s, stream, verify=True):
         for k in range(1, nb):
             assert torch.equal(batches[k][2], torch.roll(base, -batches[k][3], dims=axis)), ("cold batch differs", b.name, k)
         res["check"] = "every batch's output == the reference-checked output of batch 0, rotated"
+        if multi_out is not None:
+            for k, mo in enumerate(multi_out):
+                assert torch.equal(mo, batches[k][2]), ("a batch of the multi-batch launch differs from its own launch", b.name, k)
+            res["multi4"]["check"] = "every batch of the four-batch launches == its one-batch launch (itself checked against batch 0, rotated)"
+        del multi_out
     else:
         capi.check(b.lib.bsq_fused_status(None))
         res["check"] = "bsq_fused_status ok (the mutated batches are checked on batch 0 by `check`)"

@@ -25,6 +25,11 @@ class Desc(ctypes.Structure):
                 ("bos", ctypes.c_int32), ("padchar", ctypes.c_int32)]
 
 
+class Batch(ctypes.Structure):
+    """struct bsq_batch: one packed batch of a multi-batch call (device pointers)"""
+    _fields_ = [("chars", ctypes.c_void_p), ("offsets", ctypes.c_void_p), ("B", ctypes.c_int64), ("out", ctypes.c_void_p)]
+
+
 _lib = None
 
 
@@ -74,6 +79,7 @@ def load():
         "bsq_validate_packed_device": (i32, [vp, i64, i64, i32, i32, i64, i64p, vp]),
         "bsq_xcd_round_robin": (i32, []),
         "bsq_tokenize_device": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, vp]),
+        "bsq_tokenize_device_multi": (i32, [dp, i32, ctypes.POINTER(Batch), i64, i32, c_int, vp]),
         "bsq_onehot_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
         "bsq_onehot_bcl_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
         "bsq_onehot_block_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, i64, vp]),

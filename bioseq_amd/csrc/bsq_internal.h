@@ -128,6 +128,10 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
                              int64_t pitch, hipStream_t stream, bool raw = false, bsq_dtype t = BSQ_I8, bool nib = false,
                              int64_t tt0 = 0, int64_t ntt_count = 0);  // tt0, ntt_count: a SLICE of 64-position tiles (0 = all from tt0 on); `out` = its first row
 
+// bsq_tokens8.hip: n <= 8 independent batches in one launch of the fast token kernel of their layout; *taken = false: nothing launched
+bsq_status launch_tokens_multi(const bsq_desc *d, int32_t n, const bsq_batch *batches, int64_t P, bool batch_first, bsq_dtype t,
+                               hipStream_t stream, bool *taken);
+
 // bsq_tokens.hip: the channels-first (B, C, P) one-hot through the (B,P) chunk kernel's HOT form (the fallback of bsq_onehot_bcl_device for outputs
 // below its two-pass threshold and for masked batches)
 bsq_status launch_onehot_bcl_chunks(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, const uint8_t *mask_or_null, int64_t B,

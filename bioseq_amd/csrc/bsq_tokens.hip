@@ -694,6 +694,37 @@ bsq_status bsq_augment_tokenize_device(const bsq_desc *d, uint8_t *chars, const 
     return bsq_tokenize_device(d, chars, offsets, B, P, batch_first, t, out, hip_stream);
 }
 
+bsq_status bsq_tokenize_device_multi(const bsq_desc *d, int32_t n, const bsq_batch *batches, int64_t P, int32_t batch_first, bsq_dtype t,
+                                     void *hip_stream) {
+    if (!d || n < 0 || (n > 0 && !batches) || P <= 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, n < 0 or padlen <= 0");
+    if (bsq_dtype_size(t) == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    for (int32_t i = 0; i < n; ++i)
+        if (batches[i].B < 0 || (batches[i].B > 0 && (!batches[i].offsets || !batches[i].out)))
+            return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "a batch with a null pointer or B < 0");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    bsq_batch grp[8];
+    int32_t i = 0;
+    while (i < n) {  // groups of up to eight non-empty batches
+        int32_t g = 0;
+        while (i < n && g < 8) {
+            if (batches[i].B > 0) grp[g++] = batches[i];
+            ++i;
+        }
+        if (g == 0) break;
+        bool taken = false;
+        if (g > 1) {
+            const bsq_status st = bsq_internal::launch_tokens_multi(d, g, grp, P, batch_first != 0, t, s, &taken);
+            if (st != BSQ_OK) return st;
+        }
+        if (!taken)
+            for (int32_t k = 0; k < g; ++k) {
+                const bsq_status st = bsq_tokenize_device(d, grp[k].chars, grp[k].offsets, grp[k].B, P, batch_first, t, grp[k].out, hip_stream);
+                if (st != BSQ_OK) return st;
+            }
+    }
+    return BSQ_OK;
+}
+
 bsq_status bsq_fused_status(uint32_t *failures) {
     const uint32_t n = bsq_internal::fused_failures();
     if (failures) *failures = n;

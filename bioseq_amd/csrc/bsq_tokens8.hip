@@ -634,6 +634,38 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast(const int64_t *__r
     tokens_fast_body<NT, 0, EOSV>(blockIdx.x, offsets, chars, out, nchunks, B, PPR, magic, shift, room, packed, tab, rules, FusedWait{});
 }
 
+// SEVERAL INDEPENDENT BATCHES IN ONE LAUNCH (round 6, bsq_tokenize_device_multi).  A cold 16-40-us token launch spends a visible part of
+// its life filling the chip and draining it again, and on one in-order stream the next batch's launch cannot start under the tail of
+// this one (round 5: two alternating streams lifted cfg2 from 0.58 to 0.71 of the roof).  Here the grid is the CONCATENATION of up to
+// kMultiMax batches' grids -- one ramp-up and one drain per launch instead of per batch.  Every batch's block range starts at a multiple
+// of 8, so (block % 8) stays the chunk class of the batch's own stream and the XCD pinning holds; what differs per batch (its three
+// pointers, its chunk count and its sequence count) is a table in the kernel-argument segment, read with scalar loads after a
+// compare chain on the block index; what the batches share -- padlen, alphabet, BOS / EOS / PAD rules -- is as in the one-batch kernel.
+constexpr int kMultiMax = 8;
+struct T8Multi {
+    const int64_t *offsets[kMultiMax];
+    const uint8_t *chars[kMultiMax];
+    uint8_t *out[kMultiMax];
+    uint32_t first_block[kMultiMax];  // multiples of 8, ascending; entries behind the last batch: 0xFFFFFFFF
+    uint32_t units[kMultiMax];        // chunks of the (B,P) matrix / sequence tiles of the (P,B) matrix
+    uint32_t B[kMultiMax];
+};
+__device__ __forceinline__ uint32_t multi_batch_of(const T8Multi &m, uint32_t blk) {
+    uint32_t i = 0;
+#pragma unroll
+    for (int k = 1; k < kMultiMax; ++k) i += blk >= m.first_block[k] ? 1u : 0u;
+    return i;
+}
+
+template <bool NT, bool EOSV>
+__global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast_multi(uint32_t PPR, uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
+                                                                    T8Tab tab, T8Rules rules, T8Multi m) {
+    const uint32_t blk = blockIdx.x;
+    const uint32_t i = multi_batch_of(m, blk);
+    tokens_fast_body<NT, 0, EOSV>(blk - m.first_block[i], m.offsets[i], m.chars[i], m.out[i], m.units[i], m.B[i], PPR, magic, shift, room, packed,
+                                  tab, rules, FusedWait{});
+}
+
 #ifdef BSQ_LABS
 #include "labs/bsq_tokens8_pipe.inc"  // k_tokens_bp8_pipe: the per-wave LDS-DMA pipeline (round 5; lost: profiles/r05/tokens8_pipeline_lost.txt)
 #endif
@@ -793,10 +825,10 @@ __device__ __forceinline__ uint4 widen_tokens(const uint8_t *src) {
 // sequences per byte (sequence 2 m in the low half of byte m of a position row, 255 -> 15 = no one), a row of the tile as TB / 2 bytes: the
 // scratch of the two-pass one-hot is written and re-read at half its bytes (cfg4 f32: 160 -> 80 MB of 318 in the raw pass).
 template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false, bool UA = false, bool NIB = false>
-__global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
-                                                              uint8_t *__restrict__ out, int64_t pitch, uint32_t B, uint32_t P,
-                                                              uint32_t ntb, uint32_t ntt, uint32_t magic, uint32_t shift, int32_t room,
-                                                              uint32_t packed, uint32_t tt0, T8Tab tab, T8Rules rules, T8Lut lut) {
+__device__ __forceinline__ void tokens_pb8_body(const uint32_t vblock, const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
+                                                uint8_t *__restrict__ out, int64_t pitch, uint32_t B, uint32_t P, uint32_t ntb, uint32_t ntt,
+                                                uint32_t magic, uint32_t shift, int32_t room, uint32_t packed, uint32_t tt0, const T8Tab &tab,
+                                                const T8Rules &rules, const T8Lut &lut) {
     // (tt0: the launch covers the position tiles tt0 .. tt0 + ntt - 1 -- a SLICE of the matrix; `out` is then the address row 0 would
     //  have, so that row t of the slice lands at out + t * pitch as everywhere below)
     constexpr int TT = 64, STRIDE = TB + 8, PASSES = TB / 64;
@@ -805,7 +837,6 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
     __shared__ __align__(16) uint8_t s_lut[LK == 0 ? 256 : 16];
     __shared__ __align__(16) uint8_t s_t[TT * STRIDE];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t vblock = blockIdx.x;
     const uint32_t cls = vblock & 7u, i = vblock >> 3;
     const uint32_t quo = (magic ? __umulhi(i, magic) : i) >> shift;  // i / ntt (magic 0: a power of two); contiguous form: i / per
     uint32_t tt = i - quo * ntt, tb = quo * 8u + cls;
@@ -1021,6 +1052,27 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__r
             }
         }
     }
+}
+
+template <bool NT, int TB, int LK, int SZ = 1, bool FLT = false, bool UA = false, bool NIB = false>
+__global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast(const int64_t *__restrict__ offsets, const uint8_t *__restrict__ chars,
+                                                              uint8_t *__restrict__ out, int64_t pitch, uint32_t B, uint32_t P,
+                                                              uint32_t ntb, uint32_t ntt, uint32_t magic, uint32_t shift, int32_t room,
+                                                              uint32_t packed, uint32_t tt0, T8Tab tab, T8Rules rules, T8Lut lut) {
+    tokens_pb8_body<NT, TB, LK, SZ, FLT, UA, NIB>(blockIdx.x, offsets, chars, out, pitch, B, P, ntb, ntt, magic, shift, room, packed, tt0, tab, rules, lut);
+}
+
+// Several independent (P,B) matrices of ONE tokenizer and padlen in one launch (see k_tokens_bp8_fast_multi): the 64-byte aligned form only
+// (block -> class block % 8, position tiles of a sequence tile back to back: the divisor of the block index is ntt, which the batches
+// share); a batch's matrix is its own (pitch = B).
+template <bool NT, int LK, int SZ>
+__global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast_multi(uint32_t P, uint32_t ntt, uint32_t magic, uint32_t shift, int32_t room, uint32_t packed,
+                                                                    T8Tab tab, T8Rules rules, T8Lut lut, T8Multi m) {
+    const uint32_t blk = blockIdx.x;
+    const uint32_t i = multi_batch_of(m, blk);
+    const uint32_t Bi = m.B[i];
+    tokens_pb8_body<NT, 256, LK, SZ>(blk - m.first_block[i], m.offsets[i], m.chars[i], m.out[i], static_cast<int64_t>(Bi), Bi, P, m.units[i], ntt, magic,
+                                     shift, room, packed, 0u, tab, rules, lut);
 }
 
 template <bool NT, int LK>
@@ -1496,6 +1548,111 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
 #undef BSQ_PB8U
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_hip_error("k_tokens_pb8_fast", e);
+    return BSQ_OK;
+}
+
+// n <= kMultiMax independent batches of one tokenizer, padlen, layout and element type in ONE launch (bsq_tokenize_device_multi).  *taken =
+// false and nothing launched when some batch does not qualify for the fast kernel of its layout (the caller then issues the batches
+// one after the other): (B,P): int8, padlen % 16 == 0 and >= 128, 16-byte aligned outputs, a foldable alphabet; (P,B): 1- / 2-byte
+// integers, B * sz % 64 == 0 and 64-byte aligned outputs (the class-pinned tile order whose block-index divisor the batches share).
+bsq_status launch_tokens_multi(const bsq_desc *d, int32_t n, const bsq_batch *bt, int64_t P, bool batch_first, bsq_dtype t, hipStream_t s,
+                               bool *taken) {
+    *taken = false;
+    if (n < 1 || n > kMultiMax || bsq_alphabet_size(d) > 250 || P <= 0 || P > (int64_t(1) << 30)) return BSQ_OK;
+    const Tuning &tn = tuning();
+    if (tn.tokenize_path == 1 || tn.tokens8_abl != 0 || tn.wide_index || tn.tokens8_pad > 0) return BSQ_OK;
+    const size_t sz = bsq_dtype_size(t);
+    const uint32_t none_v = 0u;
+    T8Tab tab;
+    const bool foldable = fold_table(d->lut, tab.t, none_v);
+    int lk = tn.tokens8_lookup;  // 0 automatic (registers when the table folds), 1 LDS byte table, 2 registers
+    if (lk == 0) lk = foldable ? 2 : 1;
+    if (lk == 2 && !foldable) lk = 1;
+    const uint32_t fill = d->padchar ? uint32_t(bsq_pad_id(d)) : none_v;
+    const uint32_t at_len = d->eos ? uint32_t(bsq_eos_id(d)) : fill;
+    const uint32_t bos_id = uint32_t(bsq_bos_id(d)) & 0xFFu;
+    T8Rules rules;
+    build_rules(fill, at_len, rules);
+    const int64_t room64 = P - d->bos - d->eos;
+    const int32_t room = int32_t(room64 < 0 ? 0 : room64);
+    const bool nt = nontemporal_stores();
+    T8Multi m;
+    for (int i = 0; i < kMultiMax; ++i) {
+        m.offsets[i] = nullptr, m.chars[i] = nullptr, m.out[i] = nullptr;
+        m.first_block[i] = 0xFFFFFFFFu, m.units[i] = 0, m.B[i] = 0;
+    }
+    int64_t blocks = 0;
+    if (batch_first) {
+        if (t != BSQ_I8 || lk != 2 || P < 128 || P % 16 != 0 || tn.tokens8 == 1 || tn.tokens8_fast == 1) return BSQ_OK;
+        const uint32_t ppr = uint32_t(P / 16);
+        uint32_t magic = 0, shift = 0, pow2 = 0;
+        div_constants(ppr, &magic, &shift, &pow2);
+        if (pow2) {  // d = 2^s, s >= 3: mulhi(n, 2^(32 - s)) == n >> s
+            magic = uint32_t(1) << (32 - shift);
+            shift = 0;
+        }
+        for (int i = 0; i < n; ++i) {
+            const int64_t B = bt[i].B;
+            if (B <= 0 || B >= (int64_t(1) << 31) || !tokens_bp8_applicable(d, B, P, bt[i].out) || reinterpret_cast<uintptr_t>(bt[i].out) % 16 != 0) return BSQ_OK;
+            const int64_t nchunks = (B * int64_t(ppr) + kChunk / 16 - 1) / (kChunk / 16);
+            if (nchunks >= (int64_t(1) << 23)) return BSQ_OK;
+            m.offsets[i] = bt[i].offsets, m.chars[i] = bt[i].chars, m.out[i] = static_cast<uint8_t *>(bt[i].out);
+            m.first_block[i] = uint32_t(blocks), m.units[i] = uint32_t(nchunks), m.B[i] = uint32_t(B);
+            blocks += ((nchunks + 7) / 8 + 3) / 4 * 8;
+        }
+        if (blocks >= (int64_t(1) << 31)) return BSQ_OK;
+        const uint32_t packed = uint32_t(d->bos != 0) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
+        const bool eosv = (at_len & 0xFFu) != (fill & 0xFFu);
+#define BSQ_T8M(NTV, EV) \
+    hipLaunchKernelGGL((k_tokens_bp8_fast_multi<NTV, EV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, ppr, magic, shift, room, packed, tab, rules, m)
+        if (nt) { if (eosv) BSQ_T8M(true, true); else BSQ_T8M(true, false); }
+        else { if (eosv) BSQ_T8M(false, true); else BSQ_T8M(false, false); }
+#undef BSQ_T8M
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return set_hip_error("k_tokens_bp8_fast_multi", e);
+        *taken = true;
+        return BSQ_OK;
+    }
+    if (sz > 2 || (t != BSQ_I8 && t != BSQ_I16) || tn.tokens_pb8 == 1 || tn.tokens_pb8 == 3) return BSQ_OK;
+    const int TB = 256, TT = 64;
+    const int64_t ntt = (P + TT - 1) / TT;
+    for (int i = 0; i < n; ++i) {
+        const int64_t B = bt[i].B;
+        if (B <= 0 || !tokens_pb8_applicable(d, B, P, bt[i].out, B, t) || (B * int64_t(sz)) % 64 != 0 || reinterpret_cast<uintptr_t>(bt[i].out) % 64 != 0)
+            return BSQ_OK;
+        const int64_t ntb = (B + TB - 1) / TB;
+        m.offsets[i] = bt[i].offsets, m.chars[i] = bt[i].chars, m.out[i] = static_cast<uint8_t *>(bt[i].out);
+        m.first_block[i] = uint32_t(blocks), m.units[i] = uint32_t(ntb), m.B[i] = uint32_t(B);
+        blocks += (ntb + 7) / 8 * 8 * ntt;
+    }
+    if (blocks >= (int64_t(1) << 31)) return BSQ_OK;
+    T8Lut lut;
+    for (int w = 0; w < 64; ++w) {
+        uint32_t v = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * w + k;
+            v |= ((c < 128 && d->lut[c] >= 0) ? uint32_t(uint8_t(d->lut[c])) : none_v) << (8 * k);
+        }
+        lut.w[w] = v;
+    }
+    uint32_t magic = 0, shift = 0, pow2 = 0;
+    div_constants(uint32_t(ntt), &magic, &shift, &pow2);
+    if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)
+    const uint32_t packed = uint32_t(d->bos != 0) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
+#define BSQ_PB8M(NTV, LKV, SZV)                                                                                                            \
+    hipLaunchKernelGGL((k_tokens_pb8_fast_multi<NTV, LKV, SZV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, uint32_t(P), uint32_t(ntt), magic, \
+                       shift, room, packed, tab, rules, lut, m)
+#define BSQ_PB8M_T(SZV)                                                              \
+    do {                                                                             \
+        if (lk == 2) { if (nt) BSQ_PB8M(true, 1, SZV); else BSQ_PB8M(false, 1, SZV); } \
+        else { if (nt) BSQ_PB8M(true, 0, SZV); else BSQ_PB8M(false, 0, SZV); }         \
+    } while (0)
+    if (sz == 1) BSQ_PB8M_T(1); else BSQ_PB8M_T(2);
+#undef BSQ_PB8M_T
+#undef BSQ_PB8M
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_hip_error("k_tokens_pb8_fast_multi", e);
+    *taken = true;
     return BSQ_OK;
 }
 

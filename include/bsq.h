@@ -136,6 +136,22 @@ bsq_status bsq_onehot_block_device(const bsq_desc *d, const uint8_t *chars, cons
  * kernel.  (The (B, P) matrix needs no block form: rows [b0, b0 + n) are contiguous -- bsq_tokenize_device on a sub-batch.) */
 bsq_status bsq_tokenize_block_device(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets, int64_t B, int64_t P,
                                      bsq_dtype t, void *out, int64_t row_seqs, void *hip_stream);
+/* SEVERAL INDEPENDENT BATCHES IN ONE CALL (round 6).  The reference encodes one batch per call and its training loop issues the
+ * calls back to back (bioseq/loaders.py:76-104; Tokenizer::transencode, tokenize.h:451-479, is one OpenMP region per batch); on the
+ * GPU a 16-40-us token launch pays its own ramp-up and drain, and on one in-order stream the next batch cannot start under the tail
+ * of this one.  bsq_tokenize_device_multi encodes n packed batches of ONE tokenizer, padlen, layout and element type -- each with its
+ * own characters, offsets and output matrix ((B_i, P) or (P, B_i), contiguous) -- with results identical to n calls of
+ * bsq_tokenize_device on the same stream, in ceil(n / 8) launches when every batch qualifies for the fast kernel of its layout
+ * (int8 (B,P) with padlen % 16 == 0 and >= 128; 1- / 2-byte (P,B) with 64-byte aligned rows; ids < 251), and as n launches otherwise.
+ * Batches with B == 0 are skipped.  n < 0 or a null table: BSQ_ERR_INVALID_ARG. */
+typedef struct bsq_batch {
+    const uint8_t *chars;   /* device: packed characters of this batch */
+    const int64_t *offsets; /* device: B + 1 offsets into chars */
+    int64_t B;              /* sequences */
+    void *out;              /* device: B * P elements, (B, P) or (P, B) */
+} bsq_batch;
+bsq_status bsq_tokenize_device_multi(const bsq_desc *d, int32_t n, const bsq_batch *batches, int64_t P, int32_t batch_first,
+                                     bsq_dtype t, void *hip_stream);
 /* Name of the kernel(s) bsq_onehot_device would launch for this shape (profiling / bench labels). */
 const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_dtype t);
 /* Same results through the simple one-thread-per-element kernels (any shape/alignment/alphabet).

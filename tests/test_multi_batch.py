@@ -1,0 +1,162 @@
+"""bsq_tokenize_device_multi (round 6): n independent packed batches of one tokenizer / padlen / layout / element type in ONE launch
+(k_tokens_bp8_fast_multi, k_tokens_pb8_fast_multi: the grid is the concatenation of the batches' grids, the per-batch pointers a table
+in the kernel arguments) -- against the oracle (/root/reference/src/tokenize.h:381-485 restated in oracle/bsq_oracle.c) batch by
+batch, bit-exact, for qualifying groups (one launch), mixed groups (fall back to n launches), empty batches, more than eight batches,
+and with guard bytes around every output."""
+import ctypes
+import itertools
+
+import numpy as np
+import pytest
+
+from bioseq_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DT = {"b": ("I8", np.int8), "h": ("I16", np.int16), "i": ("I32", np.int32), "f": ("F32", np.float32)}
+
+
+def _batch(seed, n, lo, hi, nasty=False):
+    lens = synth.synth_lengths(seed, n, lo, hi)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer((synth.AA + synth.AA.lower()).encode(), dtype=np.uint8)
+    chars = letters[rng.integers(0, letters.size, size=int(offs[-1]))].copy()
+    if nasty and chars.size:
+        k = rng.random(chars.size) < 0.05
+        chars[k] = rng.integers(0, 256, size=int(k.sum()), dtype=np.uint8)
+    return chars, offs
+
+
+def _run_multi(lib, capi, desc, batches, P, batch_first, destchar, gpu, stream=None):
+    """batches: list of (chars, offs) numpy pairs -> list of numpy results; every output sits between 64 guard elements"""
+    import torch
+    code, npdt = DT[destchar]
+    tdt = {np.int8: torch.int8, np.int16: torch.int16, np.int32: torch.int32, np.float32: torch.float32}[npdt]
+    n = len(batches)
+    arr = (capi.Batch * max(n, 1))()
+    keep, outs = [], []
+    for i, (chars, offs) in enumerate(batches):
+        B = len(offs) - 1
+        dch = torch.from_numpy(np.concatenate([chars, np.full(16, 0x41, np.uint8)])).to(gpu)
+        dof = torch.from_numpy(offs).to(gpu)
+        buf = torch.full((B * P + 128,), 99, dtype=tdt, device=gpu)
+        keep.append((dch, dof, buf))
+        outs.append((buf, B))
+        arr[i].chars, arr[i].offsets, arr[i].B, arr[i].out = dch.data_ptr(), dof.data_ptr(), B, buf[64:].data_ptr()
+    capi.check(lib.bsq_tokenize_device_multi(ctypes.byref(desc), n, arr, P, int(batch_first), getattr(capi, code), stream))
+    torch.cuda.synchronize()
+    res = []
+    for buf, B in outs:
+        h = buf.cpu().numpy()
+        assert (h[:64] == 99).all() and (h[64 + B * P:] == 99).all(), "wrote outside a batch's matrix"
+        res.append(h[64:64 + B * P].reshape((B, P) if batch_first else (P, B)))
+    return res
+
+
+def _want(oracle, key, flags, batches, P, batch_first, destchar):
+    ora = oracle.OracleTokenizer(key, *flags)
+    return [ora.tokenize_packed(c, o, P, destchar, batch_first) if len(o) > 1 else
+            np.zeros((0, P) if batch_first else (P, 0), dtype=DT[destchar][1]) for c, o in batches]
+
+
+@pytest.mark.parametrize("batch_first", [True, False], ids=["BP", "PB"])
+def test_multi_equals_oracle_all_flags(gpu, oracle, batch_first):
+    """2 .. 8 qualifying batches (sequence counts multiples of 64, so that the (P,B) rows are 64-byte aligned) of different sizes,
+    every flag combination, three alphabets (foldable register table; DNA with BOS ids; a 250-class-free LDS table is covered below)"""
+    from bioseq_amd import capi
+    lib = capi.load()
+    P = 192
+    sizes = [64, 1024, 320, 2048, 128, 704, 4096, 256]
+    batches = [_batch(100 + i, b, 0, P - 2, nasty=True) for i, b in enumerate(sizes)]
+    for key in ("AMINO20", "DNA", "SEB8"):
+        for flags in itertools.product([0, 1], repeat=3):
+            desc = capi.make_desc(key, *flags)
+            for n in (2, 3, 5, 8):
+                got = _run_multi(lib, capi, desc, batches[:n], P, batch_first, "b", gpu)
+                want = _want(oracle, key, flags, batches[:n], P, batch_first, "b")
+                for i in range(n):
+                    assert np.array_equal(got[i], want[i]), (key, flags, n, i)
+
+
+@pytest.mark.parametrize("batch_first", [True, False], ids=["BP", "PB"])
+def test_more_than_eight_batches_empty_ones_and_mixed_groups(gpu, oracle, batch_first):
+    """19 batches (three launches of the fast form), some of them EMPTY (skipped), then a group in which one batch does not qualify
+    (a sequence count that is no multiple of 64 / an odd count: the whole group runs as single launches) -- same results."""
+    from bioseq_amd import capi
+    lib = capi.load()
+    P = 256
+    key, flags = "PROTEIN", (1, 1, 1)
+    desc = capi.make_desc(key, *flags)
+    sizes = [128, 0, 64, 640, 0, 0, 192, 1280, 64, 64, 0, 2560, 448, 64, 832, 0, 128, 1920, 64]
+    batches = [_batch(300 + i, b, 0, P - 2) for i, b in enumerate(sizes)]
+    got = _run_multi(lib, capi, desc, batches, P, batch_first, "b", gpu)
+    want = _want(oracle, key, flags, batches, P, batch_first, "b")
+    for i in range(len(sizes)):
+        assert got[i].shape == want[i].shape and np.array_equal(got[i], want[i]), i
+    sizes = [128, 333, 1000, 64, 1]
+    batches = [_batch(400 + i, b, 0, P - 2) for i, b in enumerate(sizes)]
+    got = _run_multi(lib, capi, desc, batches, P, batch_first, "b", gpu)
+    want = _want(oracle, key, flags, batches, P, batch_first, "b")
+    for i in range(len(sizes)):
+        assert np.array_equal(got[i], want[i]), i
+
+
+def test_other_types_and_shapes_fall_back_or_run_multi(gpu, oracle):
+    """int16 (P,B) runs the multi kernel; int32 / float32 and a padlen that is no multiple of 16 take the single launches; BYTES-like
+    LDS-table alphabets ("lds-table" knob) the LDS form of the multi kernels.  All equal the oracle."""
+    from bioseq_amd import capi
+    lib = capi.load()
+    key, flags = "AMINO", (1, 0, 1)
+    desc = capi.make_desc(key, *flags)
+    for P, destchar, bf in ((160, "h", False), (160, "h", True), (144, "i", False), (200, "b", True), (130, "b", False), (128, "f", True)):
+        batches = [_batch(500 + i, b, 0, P - 2, nasty=True) for i, b in enumerate([256, 64, 1088])]
+        got = _run_multi(lib, capi, desc, batches, P, bf, destchar, gpu)
+        want = _want(oracle, key, flags, batches, P, bf, destchar)
+        for i in range(3):
+            assert np.array_equal(got[i], want[i]), (P, destchar, bf, i)
+    capi.check(lib.bsq_tuning_set(b"tokens8_lookup", 1))
+    try:
+        for bf in (True, False):
+            batches = [_batch(600 + i, b, 0, 190, nasty=True) for i, b in enumerate([256, 64, 1088])]
+            got = _run_multi(lib, capi, desc, batches, 192, bf, "b", gpu)
+            want = _want(oracle, key, flags, batches, 192, bf, "b")
+            for i in range(3):
+                assert np.array_equal(got[i], want[i]), (bf, i)
+    finally:
+        capi.check(lib.bsq_tuning_set(b"tokens8_lookup", 0))
+
+
+def test_multi_equals_single_calls_at_cfg2_shape_and_on_a_side_stream(gpu):
+    """Four batches of BASELINE config 2's shape (16 384 sequences each, padlen 1024) in one launch on a non-default stream == four
+    bsq_tokenize_device calls, both layouts; and the argument errors."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    c = synth.CONFIGS["cfg2"]
+    desc = capi.make_desc(c["key"], c["eos"], c["bos"], c["padchar"])
+    P, nb, B = c["padlen"], 4, 16384
+    side = torch.cuda.Stream(device=gpu)
+    sh = ctypes.c_void_p(side.cuda_stream)
+    for bf in (1, 0):
+        arr = (capi.Batch * nb)()
+        keep = []
+        for i in range(nb):
+            ch, of = synth.synth_packed(c["seed"], B, c["lo"], c["hi"], c["letters"], first=i * B)
+            dch, dof = torch.from_numpy(ch).to(gpu), torch.from_numpy(of).to(gpu)
+            out = torch.full((B * P,), 77, dtype=torch.int8, device=gpu)
+            ref = torch.full((B * P,), 78, dtype=torch.int8, device=gpu)
+            capi.check(lib.bsq_tokenize_device(ctypes.byref(desc), dch.data_ptr(), dof.data_ptr(), B, P, bf, capi.I8, ref.data_ptr(), None))
+            keep.append((dch, dof, out, ref))
+            arr[i].chars, arr[i].offsets, arr[i].B, arr[i].out = dch.data_ptr(), dof.data_ptr(), B, out.data_ptr()
+        torch.cuda.synchronize()
+        capi.check(lib.bsq_tokenize_device_multi(ctypes.byref(desc), nb, arr, P, bf, capi.I8, sh))
+        side.synchronize()
+        for i in range(nb):
+            assert torch.equal(keep[i][2], keep[i][3]), (bf, i)
+    assert lib.bsq_tokenize_device_multi(ctypes.byref(desc), -1, arr, P, 1, capi.I8, None) == capi.ERR_INVALID_ARG
+    assert lib.bsq_tokenize_device_multi(ctypes.byref(desc), 2, None, P, 1, capi.I8, None) == capi.ERR_INVALID_ARG
+    assert lib.bsq_tokenize_device_multi(ctypes.byref(desc), 0, None, P, 1, capi.I8, None) == capi.OK
+    arr[1].out = None
+    assert lib.bsq_tokenize_device_multi(ctypes.byref(desc), 2, arr, P, 1, capi.I8, None) == capi.ERR_INVALID_ARG
