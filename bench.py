@@ -747,6 +747,73 @@ def run_shard(name, world, lib, dev, stream, steps, warmup, full_ms=None, full_c
     return res
 
 
+def loader_epochs(dev, batch_size=4096, epochs=3, consumer_n=0):
+    """The loader layer (reference: DataLoader over FlatFileDataset, bioseq/loaders.py:76-104) on a resident store of
+    BASELINE config 5's sequences (262 144 SEB8 sequences, len ~ U(30,512)): one shuffled epoch of `FlatFileDataset.batches` -- device-side
+    permutation, gather, (augmentation,) encode; 64 batches of 4096 -- in order on one stream, with `prefetch=2` (the next batches on
+    two side streams, round 6) and with `group=4` (four batches gathered + encoded as one super-batch, handed out as views).  Microseconds per batch, host clock over whole epochs (median of `epochs`), the consumer only keeps a
+    reference to the batch -- the WORST case for prefetching (the loop is then bound by the host's ~20 us of launches per batch, and
+    the hand-off adds its own) --, or (consumer_n > 0) runs a model-sized kernel per batch on its stream (a consumer_n^3 bf16 matmul) that
+    the next batch's encode can hide under.  A side figure: never `value`."""
+    import tempfile
+    import torch
+    import bioseq_amd
+    from bioseq_amd import synth
+    from bioseq_amd.flatfile import FlatFile
+    from bioseq_amd.loaders import AugmentedSeqDataset, FlatFileDataset
+    c = synth.CONFIGS["cfg5"]
+    chars, offs = synth.synth_packed(c["seed"], c["n"], c["lo"], c["hi"], c["letters"])
+    res = {"sequences": c["n"], "batch_size": batch_size, "batches_per_epoch": -(-c["n"] // batch_size), "consumer_matmul_n": consumer_n}
+    if consumer_n:
+        wa = torch.randn(consumer_n, consumer_n, device=dev, dtype=torch.bfloat16)
+        wb = torch.randn(consumer_n, consumer_n, device=dev, dtype=torch.bfloat16)
+        wc = torch.empty_like(wa)
+        for _ in range(3):
+            torch.mm(wa, wb, out=wc)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            torch.mm(wa, wb, out=wc)
+        torch.cuda.synchronize()
+        res["consumer_us"] = (time.perf_counter() - t0) / 50 * 1e6
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "store.ff")
+        with open(path, "wb") as f:  # the FlatFile layout (src/fxstats.cpp:33-64): count, offsets, characters
+            f.write(np.array([c["n"]], dtype="<u8").tobytes())
+            f.write(offs.astype("<u8").tobytes())
+            f.write(chars.tobytes())
+        ff = FlatFile(path)
+        tok = bioseq_amd.Tokenizer(c["key"], bool(c["eos"]), bool(c["bos"]), bool(c["padchar"]))
+        kinds = {"tokens_int64": lambda: FlatFileDataset(ff, tok, device=dev),
+                 "tokens_int8": lambda: FlatFileDataset(ff, tok, device=dev, token_dtype="b"),
+                 "augment_tokens_int8": lambda: AugmentedSeqDataset(ff, tok, device=dev, token_dtype="b"),
+                 "onehot_bcl_f32": lambda: FlatFileDataset(ff, tok, device=dev, cnn=True)}
+        for name, make in kinds.items():
+            ds = make()
+            out = {}
+            for label, opts in (("prefetch0", {}), ("prefetch2", {"prefetch": 2}), ("group4", {"group": 4})):
+                ts = []
+                for ep in range(epochs + 1):
+                    g = torch.Generator(device=dev).manual_seed(ep)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    last = None
+                    for batch in ds.batches(batch_size, shuffle=True, generator=g, **opts):
+                        last = batch
+                        if consumer_n:
+                            torch.mm(wa, wb, out=wc)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                    del last
+                out["%s_us_per_batch" % label] = float(np.median(ts[1:])) / res["batches_per_epoch"] * 1e6
+            out["speedup"] = out["prefetch0_us_per_batch"] / out["prefetch2_us_per_batch"]
+            res[name] = out
+            del ds
+        del ff
+    torch.cuda.empty_cache()
+    return res
+
+
 def traffic_of(workload):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -888,6 +955,9 @@ def compact_line(res):
                           "ms": {k: _r(v.get("ms"), 4) for k, v in (g.get("forms") or {}).items()}}
     if "fused_wait_failures" in res:
         line["fused_wait_failures"] = res["fused_wait_failures"]
+    if isinstance(res.get("loader"), dict) and "error" not in res["loader"]:  # us per batch: [in order, prefetch = 2, group = 4]
+        line["loader_us_per_batch"] = {k: [_r(v.get("prefetch0_us_per_batch"), 3), _r(v.get("prefetch2_us_per_batch"), 3), _r(v.get("group4_us_per_batch"), 3)]
+                                       for k, v in res["loader"].items() if isinstance(v, dict)}
     if res.get("configs"):
         line["configs"] = {}
         for name, c in res["configs"].items():
@@ -899,7 +969,7 @@ def compact_line(res):
     line["full"] = "bench_full.json"
     text = json.dumps(line, separators=(",", ":"))
     # whatever a future round adds: the line never outgrows its reader again (drop the optional parts in this order)
-    for drop in ("gather", "shard", "cold", "configs"):
+    for drop in ("loader_us_per_batch", "gather", "shard", "cold", "configs"):
         if len(text.encode()) <= LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -1245,6 +1315,11 @@ def main():
             res["gather"] = gather_info
         if world == 1 and not args.no_e2e and op in ("onehot", "tokenize"):
             res["e2e"] = e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev)
+        if world == 1 and not args.no_e2e and args.workload == "cfg3":
+            try:
+                res["loader"] = loader_epochs(dev)
+            except Exception as ex:  # noqa: BLE001 -- a side figure must never cost the driver its line
+                res["loader"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, args.cpu_threads or None)
         # every other BASELINE workload in the same line (N = 1; default: only beside the headline workload)

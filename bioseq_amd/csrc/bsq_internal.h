@@ -68,7 +68,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   expand_rows1          the LDS-free expansion k_expand_rows1 (one-byte elements, rows of 3 ... 15 bytes): 0 automatic, 1 never, 2 whenever it applies
 //   tokens8_ring          LABS: N > 0: the (B,P) int8 token matrix through k_tokens_bp8_pipe (every wave walks N chunks with its offsets and
 //                         characters arriving by LDS-DMA two / four chunks ahead) instead of k_tokens_bp8_fast; lost, profiles/r05/tokens8_pipeline_lost.txt
-//   gather_small          bsq_gather_packed_device for n <= 4096: 0 one launch (k_gather_small), 1 the three launches of larger lists
+//   gather_small          bsq_gather_packed_device: 0 one launch up to 4096 indices (k_gather_small), two beyond (k_gather_lengths2 + k_gather_place); 1 the three launches of rounds 2-5
 //   host_pieces           list / host batch -> seq-first one-hot on the device: upload + encode in pieces (0 automatic: 4 pieces when the
 //                         stream is idle and the batch large; 1 never; 2 ... 8 that many) -- bsq_host.cpp, piece_sequences()
 //   fused_spins           fault injection (tests): polls of a fused launch's token wave before it gives up, poisons its chunk and reports

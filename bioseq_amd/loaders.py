@@ -43,7 +43,7 @@ class FlatFileDataset(torch.utils.data.Dataset):
     stacked batch -- (B, P) int64 or (B, C, P) float32 on `device` -- from a single encode.
     """
 
-    def __init__(self, ff, tokenizer, *, augment=0, augment_frac=0.5, cnn=False, device=None, maskfrac=0.15, seed=13, token_dtype="q"):
+    def __init__(self, ff, tokenizer, *, augment=0, augment_frac=0.5, cnn=False, device=None, maskfrac=0.15, seed=13, token_dtype="q", prefetch=0):
         super().__init__()
         if not isinstance(ff, FlatFile):
             raise TypeError("FlatFileDataset expects a FlatFile")
@@ -62,6 +62,9 @@ class FlatFileDataset(torch.utils.data.Dataset):
         # element type of the token rows: 'q' = int64 as the reference's loader hands them to nn.Embedding (loaders.py:84-86);
         # 'b' = int8 -- an eighth of the bytes, and with `augment` set the whole batch step is ONE launch (bsq_augment_tokenize_device)
         self.token_dtype = token_dtype
+        # `batches()`: how many batches are encoded ahead of the consumer on the two side streams (0: in order on the current stream)
+        self.prefetch = int(prefetch)
+        self._side = None
 
     def __len__(self):
         return self.ff.nseqs()
@@ -122,24 +125,100 @@ class FlatFileDataset(torch.utils.data.Dataset):
             return self.get_batch(idx[0], idx[-1] + 1)
         return self._encode(*self._packed_device(0, 0, idx))
 
-    def batches(self, batch_size, shuffle=True, drop_last=False, generator=None):
+    def batches(self, batch_size, shuffle=True, drop_last=False, generator=None, prefetch=None, group=1):
         """One epoch of encoded batches with the sampler ON THE DEVICE: a `torch.randperm` drawn on `self.device` (or the
         identity), cut into index tensors that never leave HBM.  Nothing is copied host -> device per batch: the store is
         resident (FlatFile.to_device), the indices are device tensors, the batch is gathered, augmented and encoded there.
-        Yields (B, P) int64 tokens or (B, C, P) float32 one-hots, like `__getitems__`."""
+        Yields (B, P) int64 tokens or (B, C, P) float32 one-hots, like `__getitems__`.
+
+        Consecutive batches are independent, and this loop is the one place that knows it (round 6):
+
+        group = G > 1   G consecutive batches are gathered and encoded as ONE super-batch (one gather launch, one encode launch) and
+                        handed out as its row blocks -- both layouts are batch-first, so batch k is rows [k * batch_size, (k + 1) *
+                        batch_size) of the super-batch, a view.  A batch step of <= 4096 sequences is bound by the host's ~20 us of
+                        launches, not by the GPU: G = 4 brings the epoch of 4096-sequence batches from 23 to ~8 us per batch.  The
+                        batches are bit for bit those of G = 1, except with `augment`: the mutations are then one draw over the
+                        super-batch (seeded like its first batch) instead of G draws -- the same law, other random numbers.
+        prefetch = k > 0 (None: the dataset's `prefetch` attribute)  the gather + augmentation + encode of the next k (super-)batches
+                        are issued on two SIDE STREAMS that take turns while the consumer still holds the current one; a batch is
+                        handed over with an event the consumer's current stream waits for (no host synchronisation) and
+                        `record_stream`.  Same tensors bit for bit as prefetch = 0.  The hand-off costs ~14 us of host time per
+                        (super-)batch: it pays when the encode is long enough to hide under the consumer's own kernels (large
+                        batches, one-hot outputs), and LOSES in a host-bound loop of small batches (profiles/r06/loader_prefetch.txt)
+                        -- hence off by default."""
         n = len(self)
         order = (torch.randperm(n, device=self.device, generator=generator) if shuffle
                  else torch.arange(n, device=self.device))
         fused = bool(self.augment) and not self.cnn and str(self.token_dtype)[:1].lower() == "b"  # int8 rows take the one-launch entry, whose in-kernel wait can (in theory) expire
+        depth = int(self.prefetch if prefetch is None else prefetch)
+        batch_size = int(batch_size)
+        if batch_size <= 0:
+            raise ValueError("batch_size must be positive")
+        span = batch_size * max(1, int(group))
+        n_eff = n - n % batch_size if drop_last else n
+        firsts = list(range(0, n_eff, span))
+
+        def encode(first):
+            stop = min(n_eff, first + span)
+            if shuffle:
+                return self._encode(*self._packed_device(0, 0, order[first:stop], trusted=True))
+            return self.get_batch(first, stop)
+
+        def hand_out(big):
+            if big.shape[0] <= batch_size:
+                yield big
+            else:
+                for r in range(0, big.shape[0], batch_size):
+                    yield big[r:r + batch_size]
+
         try:
-            for first in range(0, n, batch_size):
-                idx = order[first:first + batch_size]
-                if drop_last and idx.numel() < batch_size:
-                    return
-                batch = self._encode(*self._packed_device(0, 0, idx, trusted=True)) if shuffle else self.get_batch(first, min(n, first + batch_size))
-                if fused:
-                    blosum.check_fused()  # host memory only: the launches that have completed so far (a poisoned batch raises here or below)
-                yield batch
+            if depth <= 0:
+                for first in firsts:
+                    big = encode(first)
+                    if fused:
+                        blosum.check_fused()  # host memory only: the launches that have completed so far (a poisoned batch raises here or below)
+                    yield from hand_out(big)
+                return
+            import collections
+            with torch.cuda.device(self.device):
+                self.ff.to_device(self.device)  # (the store goes up once, before any side stream reads it)
+                consumer = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = (torch.cuda.Stream(), torch.cuda.Stream())
+                for side in self._side:  # whatever produced the store and `order` on the consumer's stream comes first
+                    side.wait_stream(consumer)
+                order.record_stream(self._side[0]), order.record_stream(self._side[1])
+                queue = collections.deque()
+                it = iter(enumerate(firsts))
+                events = [torch.cuda.Event() for _ in range(depth + 1)]  # reused in turn: at most depth + 1 batches are in flight
+                set_stream = torch.cuda.set_stream  # (cheaper than entering a `torch.cuda.stream` context per batch)
+
+                def issue():
+                    k, first = next(it, (None, None))
+                    if first is None:
+                        return
+                    side = self._side[k & 1]
+                    back = torch.cuda.current_stream()
+                    set_stream(side)
+                    try:
+                        big = encode(first)
+                        ready = events[k % (depth + 1)]
+                        ready.record(side)
+                    finally:
+                        set_stream(back)
+                    queue.append((big, ready))
+
+                for _ in range(depth):
+                    issue()
+                while queue:
+                    big, ready = queue.popleft()
+                    issue()  # the next one goes out BEFORE this one is handed over: it runs under whatever the consumer does with it
+                    now = torch.cuda.current_stream()
+                    now.wait_event(ready)
+                    big.record_stream(now)
+                    if fused:
+                        blosum.check_fused()
+                    yield from hand_out(big)
         finally:
             if fused:  # the epoch's last batches: the one synchronising check, where an epoch synchronises anyway
                 blosum.check_fused(synchronize=True)

@@ -205,3 +205,72 @@ def test_a_loader_step_as_one_hip_graph(gpu, bsq, oracle, tmp_path):
             else:
                 ndiff = (got != exp).sum(axis=1)
                 assert set(np.unique(ndiff)) <= {0, 1} and 0.35 * nb < (ndiff == 1).sum() < 0.65 * nb
+
+
+@pytest.mark.parametrize("forced_general", [0, 1], ids=["one-launch", "three-launches"])
+def test_gather_mid_and_large_lists(gpu, tmp_path, forced_general):
+    """Lists beyond the 4096 indices of k_gather_small: k_gather_mid (one launch, up to 65 536) and the three-launch path behind it
+    (and, knob gather_small = 1, for every size) -- offsets and characters against numpy, repeats / empty sequences / bad indices /
+    a capacity that is too small included."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    ff, seqs = make_store(tmp_path, n=3000, lo=0, hi=90, letters=synth.DIRTY)
+    chars, offs = ff.to_device(gpu)
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    store = np.frombuffer(b"".join(bytes(s) for s in seqs), dtype=np.uint8)
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    rng = np.random.default_rng(77)
+    capi.check(lib.bsq_tuning_set(b"gather_small", forced_general))
+    try:
+        for n in (4097, 8191, 16384, 20001, 65536, 65537, 70003):
+            idx = rng.integers(0, len(seqs), size=n).astype(np.int64)
+            want_offs = np.concatenate([[0], np.cumsum(lens[idx])]).astype(np.int64)
+            pos = np.repeat(starts[idx] - want_offs[:-1], lens[idx]) + np.arange(want_offs[-1])
+            want = store[pos]
+            d_idx = torch.from_numpy(idx).to(gpu)
+            cap = int(want_offs[-1])
+            out_c = torch.full((cap + 64,), 0xEE, dtype=torch.uint8, device=gpu)
+            out_o = torch.full((n + 1,), -5, dtype=torch.int64, device=gpu)
+            st = torch.empty(1, dtype=torch.int64, device=gpu)
+            capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), len(seqs), d_idx.data_ptr(), n, out_c.data_ptr(), cap,
+                                                    out_o.data_ptr(), st.data_ptr(), None))
+            assert int(st.item()) == -1
+            assert (out_o.cpu().numpy() == want_offs).all(), n
+            host = out_c.cpu().numpy()
+            assert (host[:cap] == want).all(), n
+            assert (host[cap:] == 0xEE).all()
+            # without a status word (a caller that vouches for its indices): the same batch
+            out_c2 = torch.full((cap + 64,), 0xEE, dtype=torch.uint8, device=gpu)
+            capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), len(seqs), d_idx.data_ptr(), n, out_c2.data_ptr(), cap,
+                                                    out_o.data_ptr(), None, None))
+            assert torch.equal(out_c, out_c2)
+        # bad indices contribute empty sequences and are reported (the first one); a short capacity is cut, reported, never overrun
+        n = 9000
+        idx = rng.integers(0, len(seqs), size=n).astype(np.int64)
+        idx[[17, 4500, 8999]] = [len(seqs), -1, 1 << 40]
+        d_idx = torch.from_numpy(idx).to(gpu)
+        ok = (idx >= 0) & (idx < len(seqs))
+        ln = np.where(ok, lens[np.where(ok, idx, 0)], 0)
+        want_offs = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+        out_c = torch.full((int(want_offs[-1]) + 64,), 0xEE, dtype=torch.uint8, device=gpu)
+        out_o = torch.empty(n + 1, dtype=torch.int64, device=gpu)
+        st = torch.empty(1, dtype=torch.int64, device=gpu)
+        capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), len(seqs), d_idx.data_ptr(), n, out_c.data_ptr(), int(want_offs[-1]),
+                                                out_o.data_ptr(), st.data_ptr(), None))
+        assert int(st.item()) == 17 and (out_o.cpu().numpy() == want_offs).all()
+        idx = rng.integers(0, len(seqs), size=n).astype(np.int64)
+        d_idx = torch.from_numpy(idx).to(gpu)
+        want_offs = np.concatenate([[0], np.cumsum(lens[idx])]).astype(np.int64)
+        cap = int(want_offs[6000]) + 3
+        out_c = torch.full((int(want_offs[-1]) + 64,), 0xEE, dtype=torch.uint8, device=gpu)
+        capi.check(lib.bsq_gather_packed_device(chars.data_ptr(), offs.data_ptr(), len(seqs), d_idx.data_ptr(), n, out_c.data_ptr(), cap,
+                                                out_o.data_ptr(), st.data_ptr(), None))
+        first_cut = int(np.argmax(want_offs[1:] > cap))
+        assert int(st.item()) == n + first_cut
+        host = out_c.cpu().numpy()
+        assert (host[cap:] == 0xEE).all()
+        pos = np.repeat(starts[idx] - want_offs[:-1], lens[idx]) + np.arange(want_offs[-1])
+        assert (host[:cap] == store[pos][:cap]).all()
+    finally:
+        capi.check(lib.bsq_tuning_set(b"gather_small", 0))
