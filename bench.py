@@ -149,7 +149,7 @@ def cpu_baseline(cfg, op, destchar, batch_first, chars, offsets, cap_threads=Non
                                         % (B1, int(o1[-1]), nbytes1 / 1e9)}}
 
 
-def e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev):
+def e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev, ndev=2):
     """PCIe-inclusive timings of the DROP-IN surface (bioseq.Tokenizer's Python API) on the same batch -- reported beside the
     kernel numbers, never part of `value`: list[bytes] -> device tensor (every call synchronised, and 20 calls back to back),
     list[bytes] -> numpy (the reference's default return type: includes the D2H copy of the result), packed batch resident
@@ -217,7 +217,40 @@ def e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev):
         return {"tokens_to_numpy_us": median_ms(lambda: t1.batch_tokenize(s1, padlen=c1["padlen"], batch_first=True), 200) * 1e3,
                 "tokens_to_device_sync_us": median_ms(lambda: t1.batch_tokenize(s1, padlen=c1["padlen"], batch_first=True, device=dev), 200) * 1e3}
 
+    def on_devices():
+        """ONE process, `ndev` devices (sharding.encode_on_devices: the host packs once into pinned memory, device g receives its slice on
+        its own copy stream and encodes it on its own stream).  With fewer GPUs visible than `ndev` the entries repeat (stream pairs of one
+        GPU: the code path, not N PCIe links)."""
+        from bioseq_amd import sharding
+        have = torch.cuda.device_count()
+        devs = ["cuda:%d" % ((dev.index + g) % have) for g in range(ndev)]
+
+        def shards():
+            return sharding.encode_on_devices(tok, seqs, P, destchar, devices=devs, op=op, batch_first=batch_first, nthreads=nthreads)
+
+        def rooted():
+            return sharding.encode_on_devices(tok, seqs, P, destchar, devices=devs, op=op, batch_first=batch_first, nthreads=nthreads, root=devs[0])
+
+        def sync_all(fn, n):
+            r = fn()
+            del r
+            for d in range(have):
+                torch.cuda.synchronize(d)
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                r = fn()
+                for d in range(have):
+                    torch.cuda.synchronize(d)
+                ts.append(time.perf_counter() - t0)
+                del r
+            return float(np.median(ts) * 1e3)
+
+        return {"devices": devs, "distinct_gpus": len(set(devs)), "shards_sync_ms": sync_all(shards, 7), "into_root_sync_ms": sync_all(rooted, 7),
+                "what": "list -> N per-device shards (what parallel_apply consumes) / -> one whole-batch tensor on the first device, all devices synchronised"}
+
     out = {"nthreads": nthreads, "sequences": len(seqs), "host_cpus": os.cpu_count(), "cfg1_call": cfg1_call_us(),
+           "list_to_devices": on_devices(),
            "list_to_device_sync_ms": median_ms(lambda: call(dev), 10),
            "list_to_device_sync_one_upload_one_encode_ms": whole_batch_ms(),
            "list_to_device_sync_default_nthreads_ms": median_ms(lambda: (tok.batch_onehot_encode(seqs, padlen=P, destchar=destchar, device=dev) if op == "onehot" else tok.batch_tokenize(seqs, padlen=P, destchar=destchar, batch_first=batch_first, device=dev)), 10),
@@ -1020,6 +1053,9 @@ def main():
                     help="N > 1 only: additionally time K whole-batch assemblies over xGMI in every form (all_gather + "
                          "concatenate, grouped point-to-point straight into the destination, to a root and to every "
                          "rank, token matrices + local expansion); reported separately as `gather`, never part of `value`")
+    ap.add_argument("--devices", type=int, default=2, metavar="N",
+                    help="N = 1 process: the e2e figure `e2e.list_to_devices` shards the list over N devices from this ONE process "
+                         "(sharding.encode_on_devices); with fewer GPUs visible the entries repeat")
     ap.add_argument("--full-line", action="store_true",
                     help="print the FULL result object on stdout (the lab scripts and gpu_evidence.sh read it) instead of the compact "
                          "<= 4-KB line the driver parses; bench_full.json is written either way")
@@ -1314,7 +1350,7 @@ def main():
         if gather_info is not None:
             res["gather"] = gather_info
         if world == 1 and not args.no_e2e and op in ("onehot", "tokenize"):
-            res["e2e"] = e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev)
+            res["e2e"] = e2e_python_surface(cfg, op, destchar, batch_first, chars, offsets, dev, args.devices)
         if world == 1 and not args.no_e2e and args.workload == "cfg3":
             try:
                 res["loader"] = loader_epochs(dev)

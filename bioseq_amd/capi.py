@@ -113,6 +113,7 @@ def load():
         "bsq_stage_piece_hint": (i64, [i64, sz, sz, vp, vp, i64p]),
         "bsq_fastx_to_flatfile": (i32, [ctypes.c_char_p, ctypes.c_char_p, i64p, i64p]),
         "bsq_fastx_lengths": (i32, [ctypes.c_char_p, vp, i64, i64p]),
+        "bsq_enable_peer_access": (i32, [i32, i32]),
         "bsq_pinned_scratch": (vp, [sz]),
         "bsq_release_staging": (None, []),
     }

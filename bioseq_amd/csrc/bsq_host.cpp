@@ -702,6 +702,33 @@ int32_t bsq_device_count(void) {
     return n;
 }
 
+bsq_status bsq_enable_peer_access(int32_t device, int32_t peer) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        return bsq_internal::set_error(BSQ_ERR_NO_DEVICE, "no HIP device");
+    }
+    if (device < 0 || device >= n || peer < 0 || peer >= n) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_enable_peer_access: no such device");
+    if (device == peer) return BSQ_OK;
+    int can = 0;
+    hipError_t e = hipDeviceCanAccessPeer(&can, device, peer);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipDeviceCanAccessPeer", e);
+    if (!can) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bsq_enable_peer_access: the device cannot map the peer's memory");
+    int cur = 0;
+    e = hipGetDevice(&cur);
+    if (e == hipSuccess && cur != device) e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        e = hipDeviceEnablePeerAccess(peer, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) {  // (torch enables it lazily for its own copies)
+            (void)hipGetLastError();
+            e = hipSuccess;
+        }
+    }
+    if (cur != device) (void)hipSetDevice(cur);
+    if (e != hipSuccess) return bsq_internal::set_hip_error("hipDeviceEnablePeerAccess", e);
+    return BSQ_OK;
+}
+
 void *bsq_pinned_scratch(size_t nbytes) {
     std::lock_guard<std::mutex> lock(g_mu);
     Staging *sp = nullptr;

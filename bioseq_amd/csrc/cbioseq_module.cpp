@@ -1316,6 +1316,36 @@ PYBIND11_MODULE(cbioseq, m) {
         if (offsets[size_t(upto)]) std::memcpy(c.mutable_data(), chars.data(), size_t(offsets[size_t(upto)]));
         return py::make_tuple(o, c, bad, fast);
     }, py::arg("batch"), py::arg("piece"), py::arg("maxlen"), py::arg("nthreads") = 0);
+    // "Host packs once" (sharding.encode_on_devices): ONE scan of the list under the GIL, then ONE pack into memory the caller
+    // allocates once the total is known -- `alloc(nbytes)` returns a writable, C-contiguous uint8 buffer of at least nbytes (a numpy view
+    // of a PINNED torch tensor: the slices of the N devices then go up as asynchronous copies on N copy streams).  Returns (offsets
+    // int64[n + 1], the buffer alloc returned, index of the first item longer than maxlen or -1).  Nothing is packed when an item is too long.
+    m.def("_pack_list_into", [](py::sequence batch, int64_t maxlen, int nthreads, py::function alloc) -> py::tuple {
+        Gathered g;
+        const Scan sc = scan_begin(batch, py::none(), g, nthreads);
+        scan_range(sc, g, 0, sc.n, nthreads);
+        py::array_t<int64_t> offsets(sc.n + 1);
+        int64_t *o = offsets.mutable_data();
+        int64_t bad = -1, acc = 0;
+        o[0] = 0;
+        for (Py_ssize_t i = 0; i < sc.n; ++i) {
+            const int64_t len = int64_t(g.items[size_t(i)].len);
+            if (len > maxlen && bad < 0) bad = i;
+            acc += len;
+            o[i + 1] = acc;
+        }
+        if (bad >= 0) return py::make_tuple(offsets, py::object(py::none()), bad);
+        py::object buf = alloc(py::int_(size_t(acc) + 16));  // (+16: the kernels' unaligned 16-byte loads never leave the allocation)
+        py::buffer_info info = py::reinterpret_borrow<py::buffer>(buf).request(true);
+        if (info.itemsize != 1 || info.ndim != 1 || size_t(info.shape[0]) < size_t(acc) || (info.strides[0] != 1 && info.shape[0] > 1))
+            throw std::invalid_argument("_pack_list_into: alloc() must return a writable, contiguous buffer of bytes of the requested size");
+        Packed p;
+        p.B = sc.n;
+        p.offsets = o;
+        p.chars = static_cast<uint8_t *>(info.ptr);
+        pack_range(g, p, 0, sc.n, nthreads);
+        return py::make_tuple(offsets, buf, bad);
+    }, py::arg("batch"), py::arg("maxlen"), py::arg("nthreads"), py::arg("alloc"));
     m.def("alphabet_keys", [] {
         std::vector<std::string> k;
         for (int i = 0; i < bsq_num_keys(); ++i) k.emplace_back(bsq_key_name(i));

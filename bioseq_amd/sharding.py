@@ -414,3 +414,179 @@ def encode_sharded(encode: Callable, chars, offsets, gather: Optional[str] = Non
     if gather == "direct_tokens_bf":
         return gather_direct(local, 0, B, None, group)
     raise ValueError("gather must be None, 'onehot', 'tokens_bf', 'tokens_sf' or one of their 'direct_' forms")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ONE process, N devices: "host packs once; GPU g receives its slice" (SURVEY.md section 8e).  The reference's only multi-GPU consumer is
+# single-process: nn.DataParallel over the batch `load_next` made on the host (/root/reference/training/cnnpretrain.py:85-94), whose
+# OpenMP encode partitions the batch by sequence (src/tokenize.h:339-342).  Everything above is the one-process-per-GPU form of the
+# same partition; this is the form a DataParallel-style caller uses.
+
+def _pinned_alloc(nbytes):
+    """A writable uint8 numpy view of a PINNED torch tensor of `nbytes` (what `cbioseq._pack_list_into` packs into)."""
+    import torch
+    t = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True)
+    a = t.numpy()
+    _pinned_alloc.keep = t  # (the numpy view holds a reference to the tensor's storage; this only documents who owns the pages)
+    return a
+
+
+def pack_once(tokenizer, batch, padlen: int, nthreads: int = 0, onehot: bool = False):
+    """ONE GIL-held scan + ONE pack of a Python list of str / bytes / bytearray / 8-bit arrays into PINNED host memory:
+    (chars uint8[total (+16 spare)], offsets int64[B + 1]) as torch CPU tensors (pinned: their slices go up as asynchronous copies).
+    A sequence longer than padlen - bos - eos raises the reference's error (tokenize.h:359-362 / :456-459; `onehot` picks its type) before anything is packed.
+    Also accepts an already packed (chars, offsets) pair of numpy arrays / CPU tensors (pinned as it is, or after one copy)."""
+    import torch
+    from . import cbioseq
+    room = int(padlen) - int(tokenizer.includes_bos()) - int(tokenizer.includes_eos())
+    if isinstance(batch, tuple) and len(batch) == 2 and not isinstance(batch[0], (str, bytes, bytearray)):
+        chars = torch.as_tensor(batch[0]).reshape(-1).view(torch.uint8) if not isinstance(batch[0], torch.Tensor) else batch[0]
+        offsets = torch.as_tensor(batch[1]).to(torch.int64).contiguous()
+        if chars.is_cuda or offsets.is_cuda:
+            raise ValueError("pack_once: a packed batch must live in host memory (device batches are sharded with shard_packed)")
+        lens = offsets[1:] - offsets[:-1]
+        if lens.numel() and int(lens.max()) > room:
+            first = int((lens > room).nonzero()[0])
+            _raise_too_long(tokenizer, int(lens[first]), padlen, onehot)
+        if not chars.is_pinned():
+            chars = chars.contiguous().pin_memory()
+        return chars, offsets
+    offs, buf, bad = cbioseq._pack_list_into(batch, max(room, 0), int(nthreads), _pinned_alloc)
+    if bad >= 0:
+        _raise_too_long(tokenizer, int(offs[bad + 1] - offs[bad]), padlen, onehot)
+    return torch.from_numpy(buf), torch.from_numpy(offs)
+
+
+def _raise_too_long(tokenizer, length, padlen, onehot):
+    """The reference's error for an over-long sequence, type and text (RuntimeError from batch_tokenize, tokenize.h:456-459;
+    ValueError from batch_onehot_encode, :359-362) -- as `Tokenizer.batch_tokenize` / `batch_onehot_encode` raise it here."""
+    tl = int(length) + int(tokenizer.includes_bos()) + int(tokenizer.includes_eos())
+    msg = "seq len + bos + eos > padlen: %d, vs padlen %d" % (tl, int(padlen))
+    raise (ValueError if onehot else RuntimeError)(msg)
+
+
+class _DeviceSlot:
+    """Streams of one entry of `devices` (a device may appear more than once: every entry gets its own pair)."""
+
+    def __init__(self, device):
+        import torch
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            self.copy = torch.cuda.Stream()
+            self.encode = torch.cuda.Stream()
+            self.uploaded = torch.cuda.Event()
+
+
+_slots = {}
+
+
+def encode_on_devices(tokenizer, batch, padlen: int, destchar: str = "B", devices=None, op: str = "onehot", batch_first: bool = False,
+                      layout: str = "tbc", root=None, nthreads: int = 0):
+    """Sharded encode from ONE process: the host packs `batch` once (`pack_once`: one scan under the GIL, one pack into pinned
+    memory); device g of `devices` gets sequences `shard_bounds(B, len(devices), g)` -- its slice of the characters and its rebased
+    offsets uploaded on ITS copy stream, encoded on ITS encode stream by the ordinary kernels -- with all devices in flight together
+    (N PCIe links, N GPUs); no collective, nothing synchronises.
+
+    op 'tokenize' (batch_first as in `batch_tokenize`) or 'onehot' (layout 'tbc' = the reference's (padlen, B, C), or 'bcl' = (B, C, padlen)).
+    devices: list of devices; an entry may repeat (`['cuda:0', 'cuda:0']`: two stream pairs of one GPU -- how this pool tests it).
+    Returns the list of per-device shards (what `nn.parallel.parallel_apply` consumes), each safe to use on its device's current stream.
+    root = a device: the whole-batch tensor is allocated THERE and every device stores its shard straight into it (column blocks through
+    `bsq_onehot_block_device` / `bsq_tokenize_block_device`, row slabs for batch-first layouts) over peer access; returns that one tensor."""
+    import ctypes
+
+    import torch
+
+    from . import capi
+    if op not in ("tokenize", "onehot"):
+        raise ValueError("op must be 'tokenize' or 'onehot'")
+    if op == "onehot" and layout not in ("tbc", "bcl"):
+        raise ValueError("layout must be 'tbc' or 'bcl'")
+    devs = [torch.device(d) for d in (devices if devices is not None else ["cuda:%d" % i for i in range(torch.cuda.device_count())])]
+    if not devs or any(d.type != "cuda" for d in devs):
+        raise ValueError("encode_on_devices needs a non-empty list of HIP devices")
+    devs = [torch.device("cuda", torch.cuda.current_device() if d.index is None else d.index) for d in devs]
+    chars, offsets = pack_once(tokenizer, batch, padlen, nthreads, onehot=(op == "onehot"))
+    B = int(offsets.shape[0]) - 1
+    G = len(devs)
+    lib = capi.load()
+    desc = capi.make_desc(tokenizer.key, tokenizer.includes_eos(), tokenizer.includes_bos(), tokenizer.is_padded())
+    C = int(tokenizer.alphabet_size())
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt)))
+    tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt.value]
+    seq_first = (op == "onehot" and layout == "tbc") or (op == "tokenize" and not batch_first)
+
+    def shape_of(n):
+        if op == "tokenize":
+            return (n, padlen) if batch_first else (padlen, n)
+        return (padlen, n, C) if layout == "tbc" else (n, C, padlen)
+
+    # every device's rebased offsets in ONE pinned buffer (device g: entries [b0 + g, b1 + g + 1))
+    bounds = [shard_bounds(B, G, g) for g in range(G)]
+    reb = torch.empty(B + G, dtype=torch.int64, pin_memory=True)
+    o_np, r_np = offsets.numpy(), reb.numpy()
+    for g, (b0, b1) in enumerate(bounds):
+        np.subtract(o_np[b0:b1 + 1], o_np[b0], out=r_np[b0 + g:b1 + g + 1])
+    full = None
+    root_dev = None
+    if root is not None:
+        root_dev = torch.device(root)
+        root_dev = torch.device("cuda", torch.cuda.current_device() if root_dev.index is None else root_dev.index)
+        with torch.cuda.device(root_dev):
+            full = torch.empty(shape_of(B), dtype=tdt, device=root_dev)
+            root_ready = torch.cuda.Event()
+            root_ready.record(torch.cuda.current_stream())  # (the allocator may hand out memory that this stream's queued work still uses)
+        for d in devs:
+            capi.check(lib.bsq_enable_peer_access(d.index, root_dev.index))
+    outs, slots = [], []
+    for g, dev in enumerate(devs):
+        b0, b1 = bounds[g]
+        nb = b1 - b0
+        c0, c1 = int(o_np[b0]), int(o_np[b1])
+        slot = _slots.get((g, dev.index))
+        if slot is None:
+            slot = _slots[(g, dev.index)] = _DeviceSlot(dev)
+        slots.append(slot)
+        with torch.cuda.device(dev):
+            with torch.cuda.stream(slot.copy):
+                # (+16 spare bytes ride along when the buffer has them: the kernels' unaligned 16-byte loads stay inside the allocation)
+                d_chars = chars[c0:min(c1 + 16, chars.numel())].to(dev, non_blocking=True)
+                d_offs = reb[b0 + g:b1 + g + 1].to(dev, non_blocking=True)
+                slot.uploaded.record(slot.copy)
+            with torch.cuda.stream(slot.encode):
+                slot.encode.wait_event(slot.uploaded)
+                d_chars.record_stream(slot.encode), d_offs.record_stream(slot.encode)
+                if full is None:
+                    out = torch.empty(shape_of(nb), dtype=tdt, device=dev)
+                    dst, pitch = out, nb
+                else:
+                    slot.encode.wait_event(root_ready)
+                    out = None
+                    dst, pitch = (full[:, b0:b1] if seq_first else full[b0:b1]), B
+                if nb > 0:
+                    stream = ctypes.c_void_p(slot.encode.cuda_stream)
+                    a = (ctypes.byref(desc), d_chars.data_ptr(), d_offs.data_ptr())
+                    if op == "tokenize" and batch_first:
+                        st = lib.bsq_tokenize_device(*a, nb, padlen, 1, dt, dst.data_ptr(), stream)
+                    elif op == "tokenize":
+                        st = lib.bsq_tokenize_block_device(*a, nb, padlen, dt, dst.data_ptr(), pitch, stream)
+                    elif layout == "bcl":
+                        st = lib.bsq_onehot_bcl_device(*a, None, nb, padlen, dt, dst.data_ptr(), stream)
+                    else:
+                        st = lib.bsq_onehot_block_device(*a, None, nb, padlen, dt, dst.data_ptr(), pitch, stream)
+                    capi.check(st)
+                outs.append(out)
+    # hand-over: every device's CURRENT stream waits for that device's encode stream (events only; the host never blocks)
+    for g, dev in enumerate(devs):
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(slots[g].encode)
+            if outs[g] is not None:
+                outs[g].record_stream(cur)
+    if full is not None:
+        with torch.cuda.device(root_dev):
+            cur = torch.cuda.current_stream()
+            for g in range(G):  # the root's stream waits for every device's stores
+                cur.wait_stream(slots[g].encode)
+        return full
+    return outs

@@ -316,6 +316,12 @@ bsq_status bsq_stage_fetch(bsq_stage *stage, size_t offset, size_t nbytes, int32
 bsq_status bsq_stage_wait(bsq_stage *stage, int32_t ticket);
 int64_t bsq_stage_piece_hint(int64_t B, size_t nchars, size_t block_row_bytes, const void *out, void *hip_stream, int64_t *head_seqs);
 
+/* One process, several devices ("host packs once; GPU g receives its slice" -- the reference's only multi-GPU consumer is a
+ * single-process nn.DataParallel, training/cnnpretrain.py:85-94): lets kernels launched on `device` store into memory of `peer`
+ * (hipDeviceEnablePeerAccess; already enabled is not an error), so that the block entry points above can write a device's shard straight
+ * into the whole-batch tensor that lives on another device.  device == peer: nothing to do. */
+bsq_status bsq_enable_peer_access(int32_t device, int32_t peer);
+
 /* Pinned host scratch for callers that pack Python objects themselves (the pybind11 layer): returns a buffer of
  * at least nbytes; pack offsets | chars | mask into it and hand those pointers to the next bsq_*_host call.
  * Three buffers take turns (the call waits until the batch packed three calls ago has left the GPU), so packing
