@@ -49,16 +49,25 @@ def _is_hip_device(device) -> bool:
     return torch.device(device).type == "cuda"
 
 
-def onehot_encode(tokenizer, seqbatch, padlen=-1, destchar='B', batch_first=False, to_pytorch=False, device=None):
+def onehot_encode(tokenizer, seqbatch, padlen=-1, destchar='B', batch_first=False, to_pytorch=False, device=None, *, devices=None):
     """One-hot encode a batch (or a single sequence) -- reference bioseq/__init__.py:36-66.
 
     seqbatch: list/tuple of str/bytes/bytearray -> ``batch_onehot_encode`` -> (padlen, B, C),
     or (B, padlen, C) as a strided view when ``batch_first``.  ``to_pytorch`` wraps the result in a
     tensor; with ``device`` set to a HIP device the batch is encoded directly on that device
     (the reference encodes on the host and copies, ``__init__.py:61-65``).
+
+    ``devices=[...]`` (keyword-only, with ``to_pytorch``; not in the reference): the batch is sharded BY SEQUENCE over these HIP devices from
+    this one process -- packed once on the host, every device receives and encodes its slice (``sharding.encode_on_devices``) -- and the
+    list of per-device shards comes back, what a ``nn.DataParallel``-style consumer (training/cnnpretrain.py:85-94) feeds its replicas.
     """
-    on_device = to_pytorch and _is_hip_device(device)
     single = isinstance(seqbatch, (str, bytes))
+    if devices is not None and to_pytorch and not single:
+        if padlen is None or padlen <= 0:
+            raise ValueError("devices= needs an explicit padlen")
+        shards = sharding.encode_on_devices(tokenizer, seqbatch, padlen, destchar, devices=devices, op="onehot")
+        return [s.permute(1, 0, 2) for s in shards] if batch_first else shards
+    on_device = to_pytorch and _is_hip_device(device)
     if single:  # one sequence: (max(L, padlen) + bos + eos, C), tokenize.h:188-216
         if on_device:
             encoded = tokenizer.onehot_encode(seqbatch, padlen, destchar, device=device)
@@ -76,12 +85,12 @@ def onehot_encode(tokenizer, seqbatch, padlen=-1, destchar='B', batch_first=Fals
 
 
 def f_encode(seqbatch, key="DNA", bos=False, eos=False, padchar=False, padlen=-1, destchar='B', batch_first=False,
-             to_pytorch=False, device=None):
+             to_pytorch=False, device=None, *, devices=None):
     """Functional form: build ``Tokenizer(key, bos=, eos=, padchar=)`` then ``onehot_encode``
     (reference bioseq/__init__.py:69-116)."""
     tokenizer = Tokenizer(key, bos=bos, eos=eos, padchar=padchar)
     return onehot_encode(tokenizer, seqbatch, padlen=padlen, destchar=destchar, batch_first=batch_first,
-                         to_pytorch=to_pytorch, device=device)
+                         to_pytorch=to_pytorch, device=device, devices=devices)
 
 
 # Pre-built tokenizers and dictionaries -- same names and keys as bioseq/__init__.py:119-156.

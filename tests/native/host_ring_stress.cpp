@@ -98,6 +98,8 @@ extern "C" {
 hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned int) { return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char *hipGetErrorString(hipError_t) { return "mock HIP error"; }
 hipError_t hipMalloc(void **p, size_t n) {  // (device allocations are at least page-aligned)

@@ -119,3 +119,22 @@ def test_a_consumer_on_its_own_stream_sees_finished_shards(gpu, bsq, oracle):
         got = np.concatenate([s.cpu().numpy() for s in shards])
         assert got.tobytes() == want.tobytes()
         assert int(sum(int(x) for x in sums)) == int(want.astype(np.int64).sum())
+
+
+def test_facade_devices_keyword(gpu, bsq, oracle):
+    """bioseq.onehot_encode(..., to_pytorch=True, devices=[...]): the list of per-device (padlen, B_g, C) shards -- (B_g, padlen, C) views
+    with batch_first -- equal to the reference call's result cut by sequence"""
+    from bioseq_amd import sharding
+    seqs, _, _ = _seqs(3, 999, 0, 60)
+    tok, ora = bsq.pbeos_tokenizers["DNA"], oracle.OracleTokenizer("DNA", 1, 1, 1)
+    want = ora.batch_onehot_encode(seqs, padlen=64, destchar="f")
+    devs = _devices(3)
+    got = bsq.onehot_encode(tok, seqs, padlen=64, destchar="f", to_pytorch=True, devices=devs)
+    gotb = bsq.f_encode(seqs, key="DNA", bos=True, eos=True, padchar=True, padlen=64, destchar="f", batch_first=True, to_pytorch=True, devices=devs)
+    for g in range(3):
+        b0, b1 = sharding.shard_bounds(999, 3, g)
+        assert got[g].cpu().numpy().tobytes() == np.ascontiguousarray(want[:, b0:b1]).tobytes()
+        assert gotb[g].shape == (b1 - b0, 64, want.shape[2])
+        assert gotb[g].cpu().numpy().tobytes() == np.ascontiguousarray(want[:, b0:b1].transpose(1, 0, 2)).tobytes()
+    with pytest.raises(ValueError):
+        bsq.onehot_encode(tok, seqs, to_pytorch=True, devices=devs)   # padlen must be explicit
