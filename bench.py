@@ -650,6 +650,42 @@ def cold_regime(b, steps, min_s, stream, verify=True):
         m_ms = timed_loop(stepm, max(200, n_sus // per), 4 * len(groups), stream) / per
         res["multi4"] = {"ms_per_step": m_ms, "frac": b.algo_bytes / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "batches_per_launch": per,
                          "what": "bsq_tokenize_device_multi: four of the cold batches per launch on the one in-order stream, per batch"}
+    if b.op == "augment+tokenize" and hasattr(b.lib, "bsq_augment_tokenize_device_multi"):
+        # BASELINE config 5 with augmentation, FOUR fresh batches per call (round 6: bsq_augment_tokenize_device_multi -- one augmentation
+        # launch + one token launch for the four; nobody waits inside a kernel, the characters are read once by plain loads).  Same
+        # restore discipline as the one-batch loop above; per BATCH; beside the one-batch-per-call figure, never instead of it.
+        import ctypes
+        per = 4
+        groups = []
+        for g in range(nb // per):
+            arr = (capi.Batch * per)()
+            for j in range(per):
+                ch, of, out, _ = batches[g * per + j]
+                arr[j].chars, arr[j].offsets, arr[j].B, arr[j].out = ch.data_ptr(), of.data_ptr(), n, out.data_ptr()
+            groups.append(arr)
+        gi = [0]
+
+        def stepa():
+            k = gi[0]
+            g = k % len(groups)
+            sd = (ctypes.c_uint64 * per)(*[4 * k + j + 1 for j in range(per)])
+            st = b.lib.bsq_augment_tokenize_device_multi(ctypes.byref(b.desc), per, groups[g], b.P, int(b.batch_first), b.dt_code, 1, 0.5, sd, b.sh)
+            if st:
+                capi.check(st)
+            if (k // len(groups)) % 64 == 63:
+                for j in range(per):
+                    batches[g * per + j][0].copy_(pristine[g * per + j])
+            gi[0] += 1
+
+        for k in range(nb):
+            batches[k][0].copy_(pristine[k])
+        a_ms = timed_loop(stepa, max(200, n_sus // per), 4 * len(groups), stream) / per
+        for k in range(nb):
+            batches[k][0].copy_(pristine[k])
+        torch.cuda.synchronize()
+        res["multi4"] = {"ms_per_step": a_ms, "frac": b.algo_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "batches_per_call": per,
+                         "what": "bsq_augment_tokenize_device_multi: four of the cold batches per call (one augmentation launch + one token launch), per batch",
+                         "check": "tests/test_multi_batch.py: bit-identical to the per-batch calls with the same seeds"}
     # untimed: every batch once more from its pristine characters, compared with batch 0's output rotated
     if not verify:
         res["check"] = "none (a lab run with result-changing ablations)"

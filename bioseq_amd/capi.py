@@ -101,6 +101,9 @@ def load():
         "bsq_blosum62_normrows": (i32, [vp]),
         "bsq_augment_device": (i32, [vp, vp, i64, i32, ctypes.c_double, ctypes.c_uint64, vp]),
         "bsq_augment_tokenize_device": (i32, [vp, vp, vp, i64, i64, i32, i32, vp, i32, ctypes.c_double, ctypes.c_uint64, vp]),
+        "bsq_augment_device_multi": (i32, [i32, ctypes.POINTER(Batch), i32, ctypes.c_double, ctypes.POINTER(ctypes.c_uint64), vp]),
+        "bsq_augment_tokenize_device_multi": (i32, [dp, i32, ctypes.POINTER(Batch), i64, i32, c_int, i32, ctypes.c_double,
+                                                    ctypes.POINTER(ctypes.c_uint64), vp]),
         "bsq_tokenize_host": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, c_int, vp, i64p]),
         "bsq_onehot_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),
         "bsq_onehot_bcl_host": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, c_int, vp, i64p]),

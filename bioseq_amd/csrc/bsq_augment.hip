@@ -150,6 +150,26 @@ __global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const in
     augment_groups_body<K>(blockIdx.x, chars, offsets, B, chain_len, frac, seed, tab);
 }
 
+// Several independent batches in ONE launch (round 6, bsq_augment_device_multi): the augmentation of a batch is one short-lived, latency-
+// bound generation of waves (~7-16 us as its own launch whatever the batch: launch latency and completion are exposed); the grids of up to
+// eight batches concatenated cost about as much as one.  The per-batch pointers / counts / seeds are a table in the kernel arguments.
+constexpr int kAugMultiMax = 8;
+struct AugMulti {
+    uint8_t *chars[kAugMultiMax];
+    const int64_t *offsets[kAugMultiMax];
+    int64_t B[kAugMultiMax];
+    uint64_t seed[kAugMultiMax];
+    uint32_t first_block[kAugMultiMax];  // ascending; entries behind the last batch: 0xFFFFFFFF
+};
+template <int K>
+__global__ __launch_bounds__(256) void k_augment_groups_multi(AugMulti m, int32_t chain_len, double frac, const AugTable *tab) {
+    const uint32_t blk = blockIdx.x;
+    uint32_t i = 0;
+#pragma unroll
+    for (int k = 1; k < kAugMultiMax; ++k) i += blk >= m.first_block[k] ? 1u : 0u;
+    augment_groups_body<K>(blk - m.first_block[i], m.chars[i], m.offsets[i], m.B[i], chain_len, frac, m.seed[i], tab);
+}
+
 AugTable *g_dev_table[16] = {};
 std::mutex g_table_mu;
 
@@ -248,6 +268,48 @@ bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B,
                            offsets, B, chain_len, frac, seed, tab);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bsq_internal::set_hip_error("k_augment", e);
+    return BSQ_OK;
+}
+
+bsq_status bsq_augment_device_multi(int32_t n, const bsq_batch *batches, int32_t chain_len, double frac, const uint64_t *seeds, void *hip_stream) {
+    if (n < 0 || (n > 0 && (!batches || !seeds)) || chain_len < 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "bad augment arguments");
+    for (int32_t i = 0; i < n; ++i)
+        if (batches[i].B < 0 || (batches[i].B > 0 && (!batches[i].offsets || !batches[i].chars)))
+            return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "a batch with a null pointer or B < 0");
+    if (n == 0 || chain_len == 0 || !(frac > 0.0)) return BSQ_OK;
+    AugTable *tab = nullptr;
+    const bsq_status st = device_table(&tab);
+    if (st != BSQ_OK) return st;
+    int32_t i = 0;
+    while (i < n) {  // groups of up to eight non-empty batches
+        AugMulti m;
+        for (int k = 0; k < kAugMultiMax; ++k) {
+            m.chars[k] = nullptr, m.offsets[k] = nullptr, m.B[k] = 0, m.seed[k] = 0;
+            m.first_block[k] = 0xFFFFFFFFu;
+        }
+        int g = 0;
+        int64_t blocks = 0;
+        while (i < n && g < kAugMultiMax) {
+            if (batches[i].B > 0) {
+                m.chars[g] = const_cast<uint8_t *>(batches[i].chars);  // (mutated in place: the caller passes writable memory)
+                m.offsets[g] = batches[i].offsets;
+                m.B[g] = batches[i].B;
+                m.seed[g] = seeds[i];
+                m.first_block[g] = uint32_t(blocks);
+                blocks += (batches[i].B + 255) / 256;
+                ++g;
+            }
+            ++i;
+        }
+        if (g == 0) break;
+        if (blocks >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "batches too large");
+        const int ak = bsq_internal::tuning().augment_k;  // attempts per lane and round (0 automatic = 4; results never depend on it)
+        if (ak == 1) hipLaunchKernelGGL(k_augment_groups_multi<1>, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), m, chain_len, frac, tab);
+        else if (ak == 2) hipLaunchKernelGGL(k_augment_groups_multi<2>, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), m, chain_len, frac, tab);
+        else hipLaunchKernelGGL(k_augment_groups_multi<4>, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), m, chain_len, frac, tab);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return bsq_internal::set_hip_error("k_augment_groups_multi", e);
+    }
     return BSQ_OK;
 }
 

@@ -725,6 +725,24 @@ bsq_status bsq_tokenize_device_multi(const bsq_desc *d, int32_t n, const bsq_bat
     return BSQ_OK;
 }
 
+bsq_status bsq_augment_tokenize_device_multi(const bsq_desc *d, int32_t n, const bsq_batch *batches, int64_t P, int32_t batch_first, bsq_dtype t,
+                                             int32_t chain_len, double frac, const uint64_t *seeds, void *hip_stream) {
+    if (!d || n < 0 || (n > 0 && (!batches || !seeds)) || P <= 0 || chain_len < 0)
+        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "null pointer, n < 0, padlen <= 0 or chain_len < 0");
+    if (bsq_dtype_size(t) == 0) return bsq_internal::set_error(BSQ_ERR_DTYPE, "bad bsq_dtype");
+    for (int32_t i = 0; i < n; ++i)
+        if (batches[i].B < 0 || (batches[i].B > 0 && (!batches[i].offsets || !batches[i].out || !batches[i].chars)))
+            return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "a batch with a null pointer or B < 0");
+    // Two launches per eight batches: every batch's augmentation (one concatenated grid), then every batch's tokens (one concatenated grid
+    // where the fast kernel of the layout applies) -- nobody waits inside a kernel, no write-through, every character streamed once by plain
+    // loads.  (Round 6 also built the augmentation of the NEXT group beside the tokens of THIS group in one launch, in front of the token
+    // blocks and interleaved with them: the same 51 us per batch -- the augmentation's cost is its ~0.5 M random gathers from HBM per batch,
+    // not a latency that could hide: profiles/r06/cfg5aug_multi.txt, scripts/probes/augment_next_tokens_pipeline.inc.)
+    bsq_status st = bsq_augment_device_multi(n, batches, chain_len, frac, seeds, hip_stream);
+    if (st != BSQ_OK) return st;
+    return bsq_tokenize_device_multi(d, n, batches, P, batch_first, t, hip_stream);
+}
+
 bsq_status bsq_fused_status(uint32_t *failures) {
     const uint32_t n = bsq_internal::fused_failures();
     if (failures) *failures = n;

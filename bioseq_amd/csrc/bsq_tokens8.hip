@@ -1551,6 +1551,71 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     return BSQ_OK;
 }
 
+// What the batches of a multi-batch (B,P) int8 launch share (k_tokens_bp8_fast's scalar arguments), and their per-batch table.
+struct Bp8Shared {
+    uint32_t ppr, magic, shift, packed;
+    int32_t room;
+    T8Tab tab;
+    T8Rules rules;
+    bool eosv, nt;
+};
+// false: the fast (B,P) int8 kernel does not take this tokenizer / padlen (or a knob says no)
+static bool bp8_shared_setup(const bsq_desc *d, int64_t P, Bp8Shared &c) {
+    const Tuning &tn = tuning();
+    if (bsq_alphabet_size(d) > 250 || P < 128 || P % 16 != 0 || P > (int64_t(1) << 30)) return false;
+    if (tn.tokenize_path == 1 || tn.tokens8_abl != 0 || tn.wide_index || tn.tokens8_pad > 0 || tn.tokens8 == 1 || tn.tokens8_fast == 1) return false;
+    const bool foldable = fold_table(d->lut, c.tab.t, 0u);
+    if (!foldable || tn.tokens8_lookup == 1) return false;  // (the LDS byte-table form has no fast kernel)
+    const uint32_t fill = d->padchar ? uint32_t(bsq_pad_id(d)) : 0u;
+    const uint32_t at_len = d->eos ? uint32_t(bsq_eos_id(d)) : fill;
+    const uint32_t bos_id = uint32_t(bsq_bos_id(d)) & 0xFFu;
+    build_rules(fill, at_len, c.rules);
+    const int64_t room64 = P - d->bos - d->eos;
+    c.room = int32_t(room64 < 0 ? 0 : room64);
+    c.nt = nontemporal_stores();
+    c.ppr = uint32_t(P / 16);
+    uint32_t pow2 = 0;
+    div_constants(c.ppr, &c.magic, &c.shift, &pow2);
+    if (pow2) {  // d = 2^s, s >= 3: mulhi(n, 2^(32 - s)) == n >> s
+        c.magic = uint32_t(1) << (32 - c.shift);
+        c.shift = 0;
+    }
+    c.packed = uint32_t(d->bos != 0) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
+    c.eosv = (at_len & 0xFFu) != (fill & 0xFFu);
+    return true;
+}
+static void multi_clear(T8Multi &m) {
+    for (int i = 0; i < kMultiMax; ++i) {
+        m.offsets[i] = nullptr, m.chars[i] = nullptr, m.out[i] = nullptr;
+        m.first_block[i] = 0xFFFFFFFFu, m.units[i] = 0, m.B[i] = 0;
+    }
+}
+// false: some batch does not qualify (alignment, size); *blocks = the grid of the n batches' chunk streams
+static bool bp8_multi_table(const bsq_desc *d, int32_t n, const bsq_batch *bt, int64_t P, uint32_t ppr, T8Multi &m, int64_t *blocks) {
+    multi_clear(m);
+    *blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t B = bt[i].B;
+        if (B <= 0 || B >= (int64_t(1) << 31) || !tokens_bp8_applicable(d, B, P, bt[i].out) || reinterpret_cast<uintptr_t>(bt[i].out) % 16 != 0) return false;
+        const int64_t nchunks = (B * int64_t(ppr) + kChunk / 16 - 1) / (kChunk / 16);
+        if (nchunks >= (int64_t(1) << 23)) return false;
+        m.offsets[i] = bt[i].offsets, m.chars[i] = bt[i].chars, m.out[i] = static_cast<uint8_t *>(bt[i].out);
+        m.first_block[i] = uint32_t(*blocks), m.units[i] = uint32_t(nchunks), m.B[i] = uint32_t(B);
+        *blocks += ((nchunks + 7) / 8 + 3) / 4 * 8;
+    }
+    return *blocks < (int64_t(1) << 31);
+}
+static bsq_status launch_bp8_multi(const Bp8Shared &c, const T8Multi &m, int64_t blocks, hipStream_t s) {
+#define BSQ_T8M(NTV, EV) \
+    hipLaunchKernelGGL((k_tokens_bp8_fast_multi<NTV, EV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, c.ppr, c.magic, c.shift, c.room, c.packed, c.tab, c.rules, m)
+    if (c.nt) { if (c.eosv) BSQ_T8M(true, true); else BSQ_T8M(true, false); }
+    else { if (c.eosv) BSQ_T8M(false, true); else BSQ_T8M(false, false); }
+#undef BSQ_T8M
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_hip_error("k_tokens_bp8_fast_multi", e);
+    return BSQ_OK;
+}
+
 // n <= kMultiMax independent batches of one tokenizer, padlen, layout and element type in ONE launch (bsq_tokenize_device_multi).  *taken =
 // false and nothing launched when some batch does not qualify for the fast kernel of its layout (the caller then issues the batches
 // one after the other): (B,P): int8, padlen % 16 == 0 and >= 128, 16-byte aligned outputs, a foldable alphabet; (P,B): 1- / 2-byte
@@ -1562,6 +1627,16 @@ bsq_status launch_tokens_multi(const bsq_desc *d, int32_t n, const bsq_batch *bt
     const Tuning &tn = tuning();
     if (tn.tokenize_path == 1 || tn.tokens8_abl != 0 || tn.wide_index || tn.tokens8_pad > 0) return BSQ_OK;
     const size_t sz = bsq_dtype_size(t);
+    if (batch_first) {
+        Bp8Shared c;
+        T8Multi m;
+        int64_t blocks = 0;
+        if (t != BSQ_I8 || !bp8_shared_setup(d, P, c) || !bp8_multi_table(d, n, bt, P, c.ppr, m, &blocks)) return BSQ_OK;
+        const bsq_status st = launch_bp8_multi(c, m, blocks, s);
+        if (st != BSQ_OK) return st;
+        *taken = true;
+        return BSQ_OK;
+    }
     const uint32_t none_v = 0u;
     T8Tab tab;
     const bool foldable = fold_table(d->lut, tab.t, none_v);
@@ -1577,42 +1652,8 @@ bsq_status launch_tokens_multi(const bsq_desc *d, int32_t n, const bsq_batch *bt
     const int32_t room = int32_t(room64 < 0 ? 0 : room64);
     const bool nt = nontemporal_stores();
     T8Multi m;
-    for (int i = 0; i < kMultiMax; ++i) {
-        m.offsets[i] = nullptr, m.chars[i] = nullptr, m.out[i] = nullptr;
-        m.first_block[i] = 0xFFFFFFFFu, m.units[i] = 0, m.B[i] = 0;
-    }
+    multi_clear(m);
     int64_t blocks = 0;
-    if (batch_first) {
-        if (t != BSQ_I8 || lk != 2 || P < 128 || P % 16 != 0 || tn.tokens8 == 1 || tn.tokens8_fast == 1) return BSQ_OK;
-        const uint32_t ppr = uint32_t(P / 16);
-        uint32_t magic = 0, shift = 0, pow2 = 0;
-        div_constants(ppr, &magic, &shift, &pow2);
-        if (pow2) {  // d = 2^s, s >= 3: mulhi(n, 2^(32 - s)) == n >> s
-            magic = uint32_t(1) << (32 - shift);
-            shift = 0;
-        }
-        for (int i = 0; i < n; ++i) {
-            const int64_t B = bt[i].B;
-            if (B <= 0 || B >= (int64_t(1) << 31) || !tokens_bp8_applicable(d, B, P, bt[i].out) || reinterpret_cast<uintptr_t>(bt[i].out) % 16 != 0) return BSQ_OK;
-            const int64_t nchunks = (B * int64_t(ppr) + kChunk / 16 - 1) / (kChunk / 16);
-            if (nchunks >= (int64_t(1) << 23)) return BSQ_OK;
-            m.offsets[i] = bt[i].offsets, m.chars[i] = bt[i].chars, m.out[i] = static_cast<uint8_t *>(bt[i].out);
-            m.first_block[i] = uint32_t(blocks), m.units[i] = uint32_t(nchunks), m.B[i] = uint32_t(B);
-            blocks += ((nchunks + 7) / 8 + 3) / 4 * 8;
-        }
-        if (blocks >= (int64_t(1) << 31)) return BSQ_OK;
-        const uint32_t packed = uint32_t(d->bos != 0) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
-        const bool eosv = (at_len & 0xFFu) != (fill & 0xFFu);
-#define BSQ_T8M(NTV, EV) \
-    hipLaunchKernelGGL((k_tokens_bp8_fast_multi<NTV, EV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, ppr, magic, shift, room, packed, tab, rules, m)
-        if (nt) { if (eosv) BSQ_T8M(true, true); else BSQ_T8M(true, false); }
-        else { if (eosv) BSQ_T8M(false, true); else BSQ_T8M(false, false); }
-#undef BSQ_T8M
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return set_hip_error("k_tokens_bp8_fast_multi", e);
-        *taken = true;
-        return BSQ_OK;
-    }
     if (sz > 2 || (t != BSQ_I8 && t != BSQ_I16) || tn.tokens_pb8 == 1 || tn.tokens_pb8 == 3) return BSQ_OK;
     const int TB = 256, TT = 64;
     const int64_t ntt = (P + TT - 1) / TT;

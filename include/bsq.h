@@ -232,6 +232,16 @@ bsq_status bsq_augment_tokenize_device(const bsq_desc *d, uint8_t *chars, const 
                                        uint64_t seed, void *hip_stream);
 bsq_status bsq_fused_status(uint32_t *failures);
 void bsq_fused_status_clear(void);
+/* The same for n independent batches (`bsq_batch`, below; `chars` is mutated in place, seeds[i] is batch i's seed): results identical to n
+ * calls of bsq_augment_device / bsq_augment_tokenize_device with those seeds.  The augmentations of up to eight batches are ONE launch
+ * (a batch's augmentation is a short, latency-bound generation of waves: eight cost about as much as one), their token matrices one more
+ * (bsq_tokenize_device_multi) -- no wait inside a kernel, every character read once: BASELINE config 5 with augmentation on fresh batches,
+ * four per call, runs at 0.6 of the HBM roof where one batch per call reaches 0.45.  This is how a training loop
+ * that has its next batches at hand (bioseq/loaders.py:76-104) should call the path. */
+bsq_status bsq_augment_device_multi(int32_t n, const bsq_batch *batches, int32_t chain_len, double frac, const uint64_t *seeds,
+                                    void *hip_stream);
+bsq_status bsq_augment_tokenize_device_multi(const bsq_desc *d, int32_t n, const bsq_batch *batches, int64_t P, int32_t batch_first,
+                                             bsq_dtype t, int32_t chain_len, double frac, const uint64_t *seeds, void *hip_stream);
 
 /* ---- index-list batches from a packed store resident in HBM: replaces the per-item fetch of FlatFileDataset.__getitem__
  * (bioseq/loaders.py:76-104: ff.access(i) on the host for every sample) under a shuffling sampler.  Rebuilds the packed

@@ -160,3 +160,66 @@ def test_multi_equals_single_calls_at_cfg2_shape_and_on_a_side_stream(gpu):
     assert lib.bsq_tokenize_device_multi(ctypes.byref(desc), 0, None, P, 1, capi.I8, None) == capi.OK
     arr[1].out = None
     assert lib.bsq_tokenize_device_multi(ctypes.byref(desc), 2, arr, P, 1, capi.I8, None) == capi.ERR_INVALID_ARG
+
+
+def test_augment_multi_equals_single_calls(gpu):
+    """bsq_augment_device_multi / bsq_augment_tokenize_device_multi (one augmentation launch + one token launch per eight batches) ==
+    the per-batch calls with the same seeds, bit for bit: mutated characters AND token matrices, 1 .. 11 batches incl. an empty one,
+    both layouts; the mutation law itself is pinned on the single-batch entry by tests/test_augment.py."""
+    import torch
+    from bioseq_amd import capi
+    lib = capi.load()
+    key, flags = "SEB8", (0, 0, 1)
+    desc = capi.make_desc(key, *flags)
+    P = 256
+    sizes = [512, 64, 0, 2048, 192, 1024, 64, 320, 128, 4096, 256]
+    base = [_batch(900 + i, b, 1, P - 2) for i, b in enumerate(sizes)]
+    seeds = [1000 + 7 * i for i in range(len(sizes))]
+    for bf in (1, 0):
+        for n in (1, 3, 8, 11):
+            single_c, single_t, multi_c, multi_t = [], [], [], []
+            arr = (capi.Batch * n)()
+            sd = (ctypes.c_uint64 * n)(*seeds[:n])
+            keep = []
+            for i in range(n):
+                chars, offs = base[i]
+                B = len(offs) - 1
+                dof = torch.from_numpy(offs).to(gpu)
+                c1 = torch.from_numpy(np.concatenate([chars, np.full(16, 0x41, np.uint8)])).to(gpu)
+                c2 = c1.clone()
+                o1 = torch.full((max(B * P, 1),), 55, dtype=torch.int8, device=gpu)
+                o2 = torch.full((max(B * P, 1),), 56, dtype=torch.int8, device=gpu)
+                if B:
+                    capi.check(lib.bsq_augment_tokenize_device(ctypes.byref(desc), c1.data_ptr(), dof.data_ptr(), B, P, bf, capi.I8, o1.data_ptr(), 1, 0.5,
+                                                               seeds[i], None))
+                arr[i].chars, arr[i].offsets, arr[i].B, arr[i].out = c2.data_ptr(), dof.data_ptr(), B, o2.data_ptr()
+                keep.append((dof, c1, c2, o1, o2, B))
+            capi.check(lib.bsq_augment_tokenize_device_multi(ctypes.byref(desc), n, arr, P, bf, capi.I8, 1, 0.5, sd, None))
+            torch.cuda.synchronize()
+            capi.check(lib.bsq_fused_status(None))
+            for i, (dof, c1, c2, o1, o2, B) in enumerate(keep):
+                assert torch.equal(c1, c2), ("mutated characters differ", bf, n, i)
+                if B:
+                    assert torch.equal(o1[:B * P], o2[:B * P]), ("tokens differ", bf, n, i)
+                    changed = int((c2[:len(base[i][0])].cpu() != torch.from_numpy(base[i][0])).sum())
+                    assert 0.3 * B < changed < 0.7 * B or B < 100
+    # augmentation alone, chains of 3, every sequence (frac 1)
+    n = 5
+    arr = (capi.Batch * n)()
+    sd = (ctypes.c_uint64 * n)(*seeds[:n])
+    keep = []
+    for i in range(n):
+        chars, offs = base[i]
+        B = len(offs) - 1
+        dof = torch.from_numpy(offs).to(gpu)
+        c1 = torch.from_numpy(np.concatenate([chars, np.full(16, 0x41, np.uint8)])).to(gpu)
+        c2 = c1.clone()
+        if B:
+            capi.check(lib.bsq_augment_device(c1.data_ptr(), dof.data_ptr(), B, 3, 1.0, seeds[i], None))
+        arr[i].chars, arr[i].offsets, arr[i].B, arr[i].out = c2.data_ptr(), dof.data_ptr(), B, None
+        keep.append((dof, c1, c2))
+    capi.check(lib.bsq_augment_device_multi(n, arr, 3, 1.0, sd, None))
+    torch.cuda.synchronize()
+    for dof, c1, c2 in keep:
+        assert torch.equal(c1, c2)
+    assert lib.bsq_augment_device_multi(2, arr, 1, 0.5, None, None) == capi.ERR_INVALID_ARG
