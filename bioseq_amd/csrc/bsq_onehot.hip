@@ -1151,18 +1151,22 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool m
         const int64_t rowbytes = C * int64_t(sz), pitch = B * rowbytes, total = pitch * P;
         const bool pinned_columns = pitch % (8 * kChunk) == 0;
         const bool owner_big = rowbytes >= 48 && ((pinned_columns && B <= 131072) || B <= 16384);
-        const bool owner_small = total <= (int64_t(8) << 20) || (rowbytes >= 24 && total <= (int64_t(128) << 20));
+        // (round 6, scripts/check_dispatch.py: rows of 16 ... 23 bytes up to 40 MB too -- 4096 x 512 DNA f32 10.2 us against 14.4 tiled, 2048 x 512
+        //  6.3 against 14.2; at 67 MB and beyond the tiled kernel is level or ahead: profiles/r06/dispatch_check.txt)
+        const bool owner_small = total <= (int64_t(8) << 20) || (rowbytes >= 24 && total <= (int64_t(128) << 20)) ||
+                                 (rowbytes >= 16 && total <= (int64_t(40) << 20));
         // (end of round 2: two-pass is 3-4 % ahead from 2 GB on -- 32768 x 1024 AMINO20 f32 0.376 vs 0.389 ms --, level at
         // 1.3 GB and behind below: profiles/r02/sweep_shapes_final.txt)
         if ((owner_big || owner_small) && total < (int64_t(3) << 29))
             path = 3;
-        else if ((rowbytes >= (sz == 1 ? 8 : 16) && total >= (int64_t(192) << 20)) || ((pitch % 64 != 0 || misaligned_out) && total >= (int64_t(32) << 20)))
+        else if ((rowbytes >= 16 && total >= (int64_t(128) << 20)) || (sz <= 2 && rowbytes >= (sz == 1 ? 8 : 14) && total >= (int64_t(192) << 20)) ||
+                 ((pitch % 64 != 0 || misaligned_out) && total >= (int64_t(32) << 20)))
             path = 2;  // (second case: position rows that are not 64-byte aligned -- the tiles would share memory sectors or
                        // fall to element stores: 250001 x 256 int8 DNA 187 -> 120 us, profiles/r02/path_unaligned.txt; round 5: -> 94 us.
                        // Round 5: one-byte rows of 8 ... 15 bytes too -- their expansion is k_expand_rows1: SEB14 131072 x 512 int8
                        // 187 -> 156 us, SEB8 + BOS / EOS / PAD (11-byte rows) 281 -> 248 us; rows of 3 ... 7 bytes on BYTE ids: cfg4 int8
                        // 225 us tiled, 240 two-pass -- profiles/r05/rows1_lab.txt; on nibble ids: the next rule)
-        else if (sz == 1 && rowbytes >= 3 && rowbytes < 8 && (rowbytes == 7 || P < 8 * kTT || pitch % kChunk != 0) && total >= (int64_t(192) << 20) &&
+        else if (sz == 1 && rowbytes >= 3 && rowbytes < 8 && total >= (int64_t(192) << 20) &&
                  !masked && bsq_internal::tuning().expand_rows1 != 1 && bsq_internal::tuning().raw_nibbles != 1 && bsq_internal::tuning().raw_mode == 0 &&
                  bsq_internal::tuning().tokens_pb8 != 1)
             path = 2;  // (end of round 5) rows of 3 ... 7 bytes -- BASELINE config 4's default dtype: 1M x 160 DNA int8 -- once the ids are NIBBLES
@@ -1171,7 +1175,13 @@ static int choose_onehot_path(int32_t C, size_t sz, int64_t B, int64_t P, bool m
                        // (profiles/r05/rows1_nib_sweep.txt) the pair runs at 0.73-0.80 whatever the shape, the tiled kernel at 0.62-0.72 -- each of
                        // its tiles fetches the character lines its neighbours fetch, which fresh inputs pay at HBM -- except long reads at a
                        // chunk-aligned pitch (0.75-0.84: 262144 x 512, 131072 x 1024), where 7-byte rows still tie (165 vs 166 us) and narrower
-                       // ones lose 6-10 % (DNA5 131072 x 1024: 124 vs 131 us): those narrower ones stay tiled
+                       // ones lost 6-10 % (DNA5 131072 x 1024: 124 vs 131 us) -- round 5 kept those tiled.  Round 6's on-box check
+                       // (scripts/check_dispatch.py, fresh inputs, full-length and ragged reads) finds the tiled kernel 15-33 % BEHIND on exactly
+                       // those shapes (DNA5 131072 x 1024: 170-183 us against 137; DNA4 C = 4: 145-157 against 119; 6-byte rows 262144 x 512:
+                       // 187-197 against 154-163): the exception is gone (profiles/r06/dispatch_check.txt).
+                       // Rules of round 6 next to it: rows >= 16 B go two-pass from 128 MB (16384 x 512 DNA f32: 28.0 us against 30.7 tiled);
+                       // 2-byte elements with rows of 14 / 15 bytes from 192 MB (1M x 160 DNA int16: 412 against 445; 262144 x 512: 332 against 388 --
+                       // rows of 8 ... 12 bytes of 2-byte elements stay tiled: 270 against 280-309, 316 against 328-354, 184 against 196)
         else
             path = 1;
     }

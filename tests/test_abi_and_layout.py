@@ -57,7 +57,7 @@ def test_host_only_abi_calls(alphabets_golden):
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("AMINO20")), 8192, 1024, capi.F32) == b"k_onehot_chunks"
     # (7-byte rows of SHORT reads: nibble ids + the LDS-free expansion since the end of round 5; long reads stay tiled)
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA4", 1, 1, 1)), 1000000, 160, capi.I8) == b"k_tokens_pb8_fast<raw, nibbles>+k_expand_rows1<nibbles>"
-    assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA5")), 131072, 1024, capi.I8) == b"k_onehot_tile"   # (5-byte rows, long reads, chunk-aligned pitch)
+    assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA5")), 131072, 1024, capi.I8) == b"k_tokens_pb8_fast<raw, nibbles>+k_expand_rows1<nibbles>"   # (5-byte rows, long reads, chunk-aligned pitch: tiled until round 6's on-box check)
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA5")), 1000000, 160, capi.I8) == b"k_tokens_pb8_fast<raw, nibbles>+k_expand_rows1<nibbles>"
     # (28-byte rows: ids as nibbles, round 5)
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA4", 1, 1, 1)), 1000000, 160, capi.F32) == b"k_tokens_pb8_fast<raw, nibbles>+k_expand_chunks<nibbles>"
@@ -154,16 +154,21 @@ def test_environment_cannot_reach_result_changing_knobs():
 
 def test_onehot_path_rule_for_one_byte_rows():
     """The automatic kernel choice for int8 one-hots with rows of 3 ... 15 bytes (end of round 5; no device needed: the rule is host code).
-    From 192 MB on: 7- ... 15-byte rows always take nibble ids + the LDS-free expansion; 3- ... 6-byte rows unless the reads are long
-    (padlen >= 512) AND the row pitch is a multiple of 4 KiB; below 192 MB aligned tensors stay tiled, tensors whose position rows are
-    not 64-byte aligned go two-pass from 32 MB.  (profiles/r05/rows1_nib_sweep.txt)"""
+    From 192 MB on: 3- ... 15-byte rows take nibble ids + the LDS-free expansion (round 5 kept 3- ... 6-byte rows of long reads at a chunk-aligned
+    pitch tiled; round 6's on-box check found the tiled kernel 15-33 % behind there: profiles/r06/dispatch_check.txt); below 192 MB aligned
+    tensors stay tiled, tensors whose position rows are not 64-byte aligned go two-pass from 32 MB.  Round 6 also: rows of 16 ... 23 bytes up to
+    40 MB take the one-launch chunk-owner kernel, rows >= 16 bytes go two-pass from 128 MB, 2-byte elements with 14- / 15-byte rows from 192 MB."""
     from bioseq_amd import capi
     lib = capi.load()
     two = b"k_tokens_pb8_fast<raw, nibbles>+k_expand_rows1<nibbles>"
     name = lambda key, flags, B, P: lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc(key, *flags)), B, P, capi.I8)
     for key, flags, B, P, want in [("DNA4", (1, 1, 1), 1000000, 160, two), ("DNA4", (1, 1, 1), 262144, 512, two), ("DNA4", (1, 1, 1), 65536, 2048, two),
                                    ("DNA4", (0, 0, 0), 1000000, 160, two), ("DNA5", (0, 0, 0), 1048576, 160, two), ("DNA5", (0, 0, 0), 299968, 600, two),
-                                   ("DNA5", (0, 0, 0), 131072, 1024, b"k_onehot_tile"), ("DNA4", (1, 1, 0), 262144, 512, b"k_onehot_tile"),
+                                   ("DNA5", (0, 0, 0), 131072, 1024, two), ("DNA4", (1, 1, 0), 262144, 512, two),
                                    ("DNA4", (1, 1, 1), 131072, 160, b"k_onehot_tile"), ("DNA4", (1, 1, 1), 125000, 160, two),
                                    ("SEB14", (0, 0, 0), 131072, 512, two), ("SEB8", (1, 1, 1), 262144, 512, two), ("SEB14", (0, 0, 0), 16384, 512, b"k_onehot_tile")]:
         assert name(key, flags, B, P) == want, (key, flags, B, P, name(key, flags, B, P))
+    nm = lambda key, flags, B, P, t: lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc(key, *flags)), B, P, t)
+    assert nm("DNA", (0, 0, 0), 4096, 512, capi.F32) == b"k_onehot_chunks" and nm("DNA", (0, 0, 0), 8192, 512, capi.F32) == b"k_onehot_tile"
+    assert nm("DNA", (0, 0, 0), 16384, 512, capi.F32) == b"k_tokens_pb8_fast<raw>+k_expand_chunks"
+    assert nm("DNA4", (1, 1, 1), 1000000, 160, capi.I16).startswith(b"k_tokens_pb8_fast<raw") and nm("DNA4", (0, 0, 0), 1000000, 160, capi.I16) == b"k_onehot_tile"
