@@ -1105,7 +1105,13 @@ def main():
         # torch yet, and the ranks are CHILD processes (never an exec): torch.distributed.run starts one rank per GPU,
         # rank 0 prints the one JSON line, which is relayed unchanged; exit code = the launcher's.
         sys.exit(self_launch(args.gpus))
+    requested_gpus = args.gpus
     if world != args.gpus:
+        if args.gather > 0 and args.gpus > 1:
+            # a gather figure is only worth reporting for the world it was asked for: a launcher that started
+            # another number of ranks than --gpus must not produce a line that reads as the N-GPU gather
+            sys.exit("bench.py: --gpus %d --gather %d, but the launcher started %d ranks (WORLD_SIZE): refusing to report a gather for another world size"
+                     % (args.gpus, args.gather, world))
         args.gpus = world
 
     import ctypes
@@ -1310,6 +1316,8 @@ def main():
             nccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
         except Exception:
             nccl_version = None
+        if dist.get_world_size() != requested_gpus:
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus asked for %d: no gather line" % (dist.get_world_size(), requested_gpus))
         gather_info = {"rccl_world_size": dist.get_world_size(), "backend": backend, "rccl_version": nccl_version,
                        "shard_bytes_this_rank": out_bytes, "staging_cap_bytes_direct": 256 << 20,
                        "bytes_received_per_rank": recv_bytes, "forms": forms, "note": "encode time excluded; mean of %d "

@@ -104,7 +104,28 @@ def _gather(local, batch_axis: int, B: int, group=None):
     return torch.cat(_all_gather_padded(local, batch_axis, B, group), dim=batch_axis)
 
 
-def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, group=None, rows_per_call: int = 0, stage_bytes: int = 0):
+_checked_same = set()
+
+
+def _check_same_on_every_rank(value: int, what: str, group, like):
+    """One MIN / MAX all-reduce the first time a (group, value) is seen in this process: raises ValueError on EVERY rank when the ranks
+    disagree (a disagreement on something that decides how many exchanges a rank posts would otherwise hang the job)."""
+    import torch
+    dist = _dist()
+    key = (id(group) if group is not None else 0, what, int(value))
+    if key in _checked_same:
+        return
+    dev = like.device if str(dist.get_backend(group)) == "nccl" else "cpu"
+    v = torch.tensor([int(value), -int(value)], dtype=torch.int64, device=dev)
+    dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+    lo, hi = int(v[0].item()), -int(v[1].item())
+    if lo != hi:
+        raise ValueError("%s differs between the ranks of the group (min %d, max %d): it must be identical everywhere" % (what, lo, hi))
+    _checked_same.add(key)
+
+
+def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, group=None, rows_per_call: int = 0, stage_bytes: int = 0,
+                  check_stage_bytes: bool = True):
     """Whole batch from per-rank shards by grouped point-to-point transfers: ONE message per peer.
 
     local: this rank's shard, contiguous; batch_axis 0 = (B_g, ...) slabs, 1 = (P, B_g, ...) column blocks.
@@ -115,9 +136,15 @@ def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, gr
     every position row of every peer was its own message: P x (world - 1) sends and as many receives per rank, 7168 +
     7168 at cfg3 on 8 ranks -- per-operation overhead, not link bandwidth, would have bounded it.  rows_per_call > 0
     keeps that form, in calls of that many rows, for measurement.)
+    stage_bytes: cap of one peer's staging buffer for column blocks (default 256 MB); a shard above it travels in ROW GROUPS, one grouped
+    exchange per group.  It MUST BE THE SAME ON EVERY RANK of the group: the ranks cut their groups from it, and ranks that cut different
+    groups post different numbers of exchanges -- the job would hang.  The first call of a process with a given (group, value) checks that
+    with one MIN / MAX all-reduce of two integers and raises ValueError on every rank when they differ (`check_stage_bytes=False` skips it).
     """
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if batch_axis == 1 and rows_per_call <= 0 and check_stage_bytes:
+        _check_same_on_every_rank(int(stage_bytes) if stage_bytes and stage_bytes > 0 else (256 << 20), "stage_bytes", group, local)
     if batch_axis not in (0, 1) or (batch_axis == 1 and local.dim() < 2):
         raise ValueError("batch_axis must be 0, or 1 for (P, B_g, ...) shards")
     if root is not None and not 0 <= root < world:
@@ -155,7 +182,8 @@ def gather_direct(local, batch_axis: int, B: int, root: Optional[int] = None, gr
         # result.  A row group holds at most `stage_bytes` (default 256 MB) of the largest shard, so the staging beside the result is
         # (world - 1) x 256 MB however large the shards are -- at cfg3 on 8 ranks 7 x 671 MB were staged per receiving rank until
         # round 4; one group when the shards are smaller than that (one message per peer, as before).
-        # Every rank cuts the SAME groups (they depend on P and the largest shard only), so sends and receives pair up group by group.
+        # Every rank cuts the SAME groups (they depend on P, the largest shard and `stage_bytes` -- checked above to be the same on every
+        # rank), so sends and receives pair up group by group.
         P = int(local.shape[0])
         inner = 1
         for d in local.shape[2:]:
@@ -256,6 +284,24 @@ def device_passes(tokenizer, padlen: int, destchar: str, device):
     return raw_tokens, expand
 
 
+def require_dmabuf_ipc():
+    """Sharing device memory between processes (`open_root_buffer`, RCCL's own intra-node transports) needs the dmabuf IPC path on this
+    driver: HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the process makes its first HIP call -- the runtime reads it once; with the
+    legacy mode hipIpcGetMemHandle fails with 'invalid argument' in the middle of a collective.  If no HIP call has been made yet the
+    variable is set here; otherwise a process that started without it gets a clear error instead of that failure."""
+    import os
+    import torch
+    if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0":
+        return
+    if not torch.cuda.is_initialized():
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        return
+    raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment before the first HIP call of the process (it is %r): device "
+                       "memory cannot be shared between processes otherwise (hipIpcGetMemHandle: invalid argument).  Export it in the launcher "
+                       "(bench.py and the tests do), or call bioseq_amd.sharding.require_dmabuf_ipc() before anything touches the GPU."
+                       % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+
+
 def open_root_buffer(shape, dtype, device, root: int = 0, group=None):
     """SURVEY.md section 8e option 3, step 1 (collective): rank `root` allocates the whole-batch tensor in ITS HBM, every
     other rank maps the same memory into its own address space through an IPC handle (torch.multiprocessing's
@@ -269,6 +315,7 @@ def open_root_buffer(shape, dtype, device, root: int = 0, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if not 0 <= root < world:
         raise ValueError("bad root")
+    require_dmabuf_ipc()
     src = dist.get_global_rank(group, root) if group is not None else root
     payload = [None]
     full = None

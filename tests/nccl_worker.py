@@ -30,6 +30,26 @@ def main():
         dist.init_process_group("gloo")
     ship = (lambda t: t) if nccl else (lambda t: t.cpu())
     ok = True
+    report = {"backend": "nccl" if nccl else "gloo", "world_size": dist.get_world_size(), "rccl_version": None,
+              "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "gb_per_s_into_each_rank": {}}
+    if nccl:
+        try:
+            report["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as ex:  # noqa: BLE001
+            report["rccl_version"] = repr(ex)
+
+    def rate(name, fn, nbytes):
+        """one assembly form once more, timed between two barriers (MAX over ranks is taken by rank 0's clock around the barriers)"""
+        import time
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        report["gb_per_s_into_each_rank"][name] = nbytes / dt / 1e9
+        return r
     tok, ora = bioseq_amd.Tokenizer("AMINO20", 1, 1, 1), O.OracleTokenizer("AMINO20", 1, 1, 1)
     # B: equal shards, ragged shards, fewer sequences than ranks (empty shards), one big batch
     for B, hi in ((world * 64, 120), (world * 50 + 1, 250), (max(1, world - 1), 60), (20011, 300)):
@@ -87,6 +107,20 @@ def main():
     ok = ok and ((got is not None and got.cpu().numpy().tobytes() == full4.tobytes()) if rank == 0 else got is None)
     del got
     dist.barrier()
+    # per-form rates on this 70-MB tensor (bytes a rank RECEIVES / time between two barriers): small, but the first numbers RCCL gives this code
+    recv = full4.nbytes * (world - 1) / world
+    rate("all_gather", lambda: sharding.encode_sharded(enc4, chars4, offs4, gather="onehot"), recv)
+    rate("direct_all", lambda: sharding.gather_direct(keep4, 1, B4, None), recv)
+    rate("direct_root", lambda: sharding.gather_direct(keep4, 1, B4, 0), recv)
+    rate("store_into_root", lambda: sharding.encode_into_root(tok4, chars4, offs4, P4, "f", "tbc", dev, root=0), recv)
+    # ranks that disagree on stage_bytes must get an error on EVERY rank, not a hang
+    differs = False
+    try:
+        sharding.gather_direct(keep4, 1, B4, None, stage_bytes=(3 << 20) + rank)
+    except ValueError:
+        differs = True
+    ok = ok and (differs or world == 1)
+    dist.barrier()
     bad_rank = world - 1
     c_bad, o_bad = sharding.shard_packed(chars4, offs4, world, rank)
     b0_bad = sharding.shard_bounds(B4, world, rank)[0]
@@ -104,6 +138,8 @@ def main():
     flag = torch.tensor([1 if ok else 0], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
+        import json
+        print(json.dumps(report), flush=True)
         print("MULTI_GPU_OK" if int(flag.item()) == 1 else "MULTI_GPU_MISMATCH", flush=True)
     dist.destroy_process_group()
 

@@ -75,6 +75,14 @@ def _worker(rank, world, port, B, P, q):
             else:
                 direct_ok = direct_ok and r_oh is None and r_bf is None
 
+        # ranks that pass DIFFERENT stage_bytes would cut different row groups and hang: the first call with a value checks it with
+        # one all-reduce and raises on every rank
+        try:
+            sharding.gather_direct(torch.from_numpy(keep), 1, B, None, stage_bytes=777 + rank)
+            direct_ok = direct_ok and world == 1
+        except ValueError as ex:
+            direct_ok = direct_ok and "stage_bytes differs" in str(ex)
+
         # token-gather assembly (onehot_gathered) with CPU stand-ins for the two device passes
         def raw_tokens(c, o):
             oh_ = tok.onehot_packed(c, o, P, "b")
