@@ -48,7 +48,8 @@ def build_lib(force=False):
     # every header of csrc/ and include/ is a dependency of every object (a handful of files: an exact depfile graph would
     # save nothing, and a header missing from a hand-kept list once left two kernels disagreeing about a table layout)
     import glob
-    headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "labs", "*.inc")) + glob.glob(os.path.join(INCLUDE, "*.h")))
+    # (csrc/labs/ is history, not a dependency: nothing there is compiled and the build id does not depend on it)
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h")))
     extra = os.environ.get("BSQ_EXTRA_HIPCC_FLAGS", "").split()
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
@@ -63,6 +64,12 @@ def build_lib(force=False):
     build_id = h.hexdigest()[:16]
     id_stamp = os.path.join(objdir, "build_id.txt")
     id_changed = not os.path.exists(id_stamp) or open(id_stamp).read() != build_id
+    # objects of sources that are no longer part of the library (a split or renamed translation unit) must not survive in _obj/: whoever
+    # links `_obj/*.o` (scripts/asan_host.sh did) would get duplicate symbols or stale kernels
+    keep = {f + ".o" for f in LIB_SRCS}
+    for stale in os.listdir(objdir):
+        if stale.endswith(".o") and stale not in keep:
+            os.remove(os.path.join(objdir, stale))
     jobs, objs = [], []
     for f in LIB_SRCS:
         src, obj = os.path.join(CSRC, f), os.path.join(objdir, f + ".o")
@@ -98,9 +105,17 @@ def build_ext(force=False):
     return EXT
 
 
+def kernel_objects():
+    """The hipcc-built objects of the library's .hip sources, in link order (scripts/asan_host.sh links exactly these)."""
+    return [os.path.join(CSRC, "_obj", f + ".o") for f in LIB_SRCS if f.endswith(".hip")]
+
+
 def build_all(force=False):
     return build_lib(force), build_ext(force)
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--kernel-objects" in sys.argv:
+        print(" ".join(kernel_objects()))
+    else:
+        build_all(force="--force" in sys.argv)

@@ -78,71 +78,6 @@ uint32_t accept_threshold(double pself) {
 }
 
 
-#ifdef BSQ_LABS  // round-1 form (knob augment_mode 1): kept for A/B runs in diagnostic builds only
-// One mutation = the reference's loop `repeat { idx = choice(L); new = choice(letters, p = row(seq[idx])) } until
-// new != seq[idx]` (bioseq/blosum.py:63-87), sampled in two steps with the same joint distribution: a position is
-// ACCEPTED with probability 1 - row(old)[old] (what the reference's rejection amounts to), and only then is the
-// new residue drawn -- from row(old) without its own entry.  An attempt costs one random word, one character
-// gather and one table lookup instead of two words and a 20-step search; the gathers of kBatch attempts are
-// issued together (attempts are still evaluated strictly in counter order, so results do not depend on kBatch).
-// Random words of thread b: 0 = augment_frac decision; then one per attempt (high bits: position, low 32 bits:
-// acceptance) and one per accepted mutation (the new residue).
-__global__ __launch_bounds__(256) void k_augment(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len,
-                                                 double frac, uint64_t seed, const AugTable *tab) {
-    __shared__ AugTable s_tab;
-    for (int i = threadIdx.x; i < int(sizeof(AugTable) / 4); i += 256)
-        reinterpret_cast<uint32_t *>(&s_tab)[i] = reinterpret_cast<const uint32_t *>(tab)[i];
-    __syncthreads();
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (b >= B) return;
-    const int64_t start = offsets[b];
-    const int64_t L = offsets[b + 1] - start;
-    if (L <= 0) return;
-    if (frac < 1.0 && !(unit(rnd(seed, b, 0)) < frac)) return;  // word 0 decides whether b is augmented
-    uint64_t ctr = 1;
-    // One round of NB attempts: gathers first, then evaluation in counter order.  Returns true once a mutation is made.
-    auto round = [&](auto nb_tag) -> bool {
-        constexpr int NB = decltype(nb_tag)::value;
-        int64_t idx[NB];
-        uint32_t lo[NB];
-        uint8_t old[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const uint64_t r = rnd(seed, b, ctr + j);
-            idx[j] = static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(L)));  // uniform in [0, L)
-            lo[j] = static_cast<uint32_t>(r);
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) old[j] = chars[start + idx[j]];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            ctr += 1;
-            const int row = s_tab.row_of[old[j]];
-            const double pself = s_tab.self[row];
-            if (static_cast<double>(lo[j]) * 0x1.0p-32 < 1.0 - pself) {  // position accepted
-                const double *cdf = s_tab.cdf[row];
-                const double u = unit(rnd(seed, b, ctr)) * (cdf[kCols - 1] - pself);
-                ctr += 1;
-                int pick = -1;  // first k != row with u < cdf[k] minus the removed diagonal mass; else the last such k
-                for (int k = 0; k < kCols; ++k) {
-                    if (k == row) continue;
-                    pick = k;
-                    if (u < cdf[k] - (k > row ? pself : 0.0)) break;
-                }
-                chars[start + idx[j]] = s_tab.letter[pick];
-                return true;
-            }
-        }
-        return false;
-    };
-    // The kernel ends with its unluckiest thread (~30 attempts among 10^5 threads at 30 % acceptance), and every
-    // round is a dependent memory round trip: 4 attempts in the first round, 16 in the later ones.
-    for (int32_t m = 0; m < chain_len; ++m) {
-        bool done = round(std::integral_constant<int, 4>{});
-        for (int a0 = 4; a0 < kMaxAttempts && !done; a0 += 16) done = round(std::integral_constant<int, 16>{});
-    }
-}
-#endif  // BSQ_LABS
 
 template <int K>
 __global__ __launch_bounds__(256) void k_augment_groups(uint8_t *chars, const int64_t *offsets, int64_t B, int32_t chain_len,
@@ -246,15 +181,6 @@ bsq_status bsq_augment_device(uint8_t *chars, const int64_t *offsets, int64_t B,
     if (st != BSQ_OK) return st;
     const int64_t blocks = (B + 255) / 256;
     if (blocks >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "batch too large");
-#ifdef BSQ_LABS
-    if (bsq_internal::tuning().augment_mode == 1) {  // one lane per sequence (round 1)
-        hipLaunchKernelGGL(k_augment, dim3(unsigned(blocks)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), chars,
-                           offsets, B, chain_len, frac, seed, tab);
-        const hipError_t e1 = hipGetLastError();
-        if (e1 != hipSuccess) return bsq_internal::set_hip_error("k_augment", e1);
-        return BSQ_OK;
-    }
-#endif
     // knob "augment_k": attempts per lane and round (0 automatic = 4; 1 = the round-2 form; 2) -- speed only
     const int ak = bsq_internal::tuning().augment_k;
     if (ak == 1)

@@ -26,11 +26,6 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 }
 // i-th 64-bit word of the stream keyed by (seed, sequence): mix64(h0 + 0xD1342543DE82EF95 * (i + 1)) with
 // h0 = mix64(seed + 0x9E3779B97F4A7C15 * (seq + 1)).  Host twin: tests/test_augment.py.
-#ifdef BSQ_LABS
-__device__ __forceinline__ uint64_t rnd(uint64_t seed, uint64_t seq, uint64_t i) {
-    return mix64(mix64(seed + 0x9E3779B97F4A7C15ull * (seq + 1)) + 0xD1342543DE82EF95ull * (i + 1));
-}
-#endif
 __device__ __forceinline__ double unit(uint64_t x) { return static_cast<double>(x >> 11) * 0x1.0p-53; }
 // floor(r * len / 2^64) for len < 2^32: two 32 x 32 multiplies instead of the four of __umul64hi (quarter-rate instructions)
 __device__ __forceinline__ uint64_t mulhi_64x32(uint64_t r, uint32_t len) {

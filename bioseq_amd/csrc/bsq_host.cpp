@@ -486,27 +486,18 @@ namespace {
 struct KnobInfo {
     const char *name;
     int32_t Tuning::*field;
-    bool labs;
 };
 const KnobInfo g_knobs[] = {
-#define BSQ_KNOB_PRODUCT(n, d) {#n, &Tuning::n, false},
-#define BSQ_KNOB_LABS(n, d) {#n, &Tuning::n, true},
-    BSQ_KNOB_LIST(BSQ_KNOB_PRODUCT, BSQ_KNOB_LABS)
-#undef BSQ_KNOB_PRODUCT
-#undef BSQ_KNOB_LABS
+#define BSQ_KNOB_ENTRY(n, d) {#n, &Tuning::n},
+    BSQ_KNOB_LIST(BSQ_KNOB_ENTRY)
+#undef BSQ_KNOB_ENTRY
 };
-#ifdef BSQ_LABS
-constexpr bool kLabs = true;
-#else
-constexpr bool kLabs = false;
-#endif
 std::mutex g_knob_mu;                          // writers only
 std::atomic<const Tuning *> g_tuning{nullptr};  // the published snapshot (superseded ones: see set_tuning)
 
 const Tuning *initial_tuning() {  // defaults, then BSQ_<NAME> from the environment -- once
     Tuning *t = new Tuning();
     for (const KnobInfo &k : g_knobs) {
-        if (k.labs && !kLabs) continue;
         std::string env = "BSQ_";
         for (const char *c = k.name; *c; ++c) env.push_back(char(std::toupper(static_cast<unsigned char>(*c))));
         const char *e = std::getenv(env.c_str());
@@ -661,7 +652,7 @@ int get_tuning(const char *name) {
 
 bool set_tuning(const char *name, int value) {
     const KnobInfo *k = find_knob(name);
-    if (!k || (k->labs && !kLabs)) return false;
+    if (!k) return false;
     (void)tuning();  // (the initial snapshot exists)
     std::lock_guard<std::mutex> lock(g_knob_mu);
     const Tuning *cur = g_tuning.load(std::memory_order_acquire);
@@ -688,7 +679,7 @@ const char *bsq_last_error(void) { return t_last_error.c_str(); }
 
 bsq_status bsq_tuning_set(const char *name, int32_t value) {
     return bsq_internal::set_tuning(name, value) ? BSQ_OK
-                                                 : bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "unknown tuning knob (or one that exists only in a -DBSQ_LABS build)");
+                                                 : bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "unknown tuning knob");
 }
 int32_t bsq_tuning_get(const char *name) { return bsq_internal::get_tuning(name); }
 uint64_t bsq_host_upload_bytes(void) { return g_upload_bytes.load(std::memory_order_relaxed); }

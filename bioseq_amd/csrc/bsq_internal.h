@@ -12,42 +12,32 @@ namespace bsq_internal {
 bsq_status set_error(bsq_status st, const char *msg);
 bsq_status set_hip_error(const char *what, hipError_t e);
 // Tuning / diagnostic knobs (bsq_tuning_set, or environment BSQ_<NAME> read once, at the first launch):
-// (speed only -- in the product build results never depend on them; every variant is covered by the GPU parity tests.
-//  LABS = exists only with -DBSQ_LABS: chunks_cpw, tokenize_nch, expand_mode, xcd_claim, chunk_math, tokens8_abl, tokens8_ring, augment_mode
-//  (1: the round-1 one-lane-per-sequence k_augment), and the
-//  values 2 / 3 of raw_mode)
+// (speed only -- results never depend on them; every variant is covered by the GPU parity tests.  The knobs of experiments that lost
+//  -- chunks_cpw, tokenize_nch, expand_mode, xcd_claim, chunk_math, tokens8_abl, tokens8_ring, augment_mode, raw_mode 2 / 3 -- left the
+//  library in round 6 together with their kernels: csrc/labs/README.md)
 //   nt_stores     1: `global_store ... nt` for the output streams (default 1)
 //   onehot_path   0: automatic, 1: tiled kernel, 2: two-pass (tokens + expansion), 3: chunk-owner kernel
 //   expand_pad    unused dynamic LDS of k_expand_chunks = occupancy cap: 0 automatic, > 0 bytes, < 0 none
 //   expand_slots  4: k_expand_chunks always issues four token loads per step (0: as many as the chunk needs)
 //   chunks_pad    the same cap for k_onehot_chunks (0: 22528 bytes = 4 workgroups per CU)
-//   chunks_cpw    chunks per wave of k_onehot_chunks (default 1)
 //   tokenize_path 1: never use k_tokenize_chunks / the raw-token kernel for batch_tokenize
 //   tokenize_pad  unused dynamic LDS of k_tokenize_chunks (experiments: no cap helps it)
-//   tokenize_nch  4: software-pipelined four chunks per wave in k_tokenize_chunks (experiments: slower than 1)
 //   tile_group    G > 1: XCD-aware tile order in groups of 8 x G sequence tiles (G = 16..64: +1 % on cfg4 int8; >= 128 loses
 //                 the L2 reuse: cfg4 f32 0.69 -> 0.90 ms at 512; profiles/r02/tile_lab3.txt)
 //   bcl_path      channels-first one-hot: 0 automatic (two-pass k_tokens_bp8<raw> + k_expand_bcl for outputs >= 256 MB),
 //                 1 never two-pass, 2 two-pass whenever it applies;  bcl_pad  occupancy cap of k_expand_bcl (0: 3 workgroups per CU)
-//   raw_mode      2 / 3: k_tokens_raw2 (4 x 4 byte transpose in registers via v_permlane32/16_swap; LDS / register
-//                 alphabet table) instead of k_tokens_raw; measured 7-15 % slower (profiles/r02/raw_lab.txt);
-//                 1 / 4: force the 256 x 64 / the wide 1024 x 16 tile of k_tokens_raw (0: wide for the final (P,B)
-//                 int8 matrix of >= 4096 sequences, 256 x 64 for the expansion scratch)
-//   xcd_claim     1: k_expand_chunks takes its chunk class from HW_REG_XCC_ID and its slot from per-class atomic counters
-//                 (placement-independent; measured 17-32 % slower: profiles/r02/claim_lab.txt)
-//   chunk_math    2: scalar 64-bit integer reciprocals (div64) for the chunk coordinates of the expansion kernels
-//                 instead of the double reciprocals (div_by); measured 1 % slower at the optimum occupancy
+//   raw_mode      1 / 4: force the 256 x 64 / the wide 1024 x 16 tile of k_tokens_raw (0: wide for the final (P,B)
+//                 int8 matrix of >= 4096 sequences, 256 x 64 for the expansion scratch); any value != 0 also keeps the raw-id pass
+//                 out of k_tokens_pb8_fast
 //   tokens8       1: never use k_tokens_bp8 for the (B,P) int8 token matrix (falls back to k_tokenize_chunks / _rows);
 //                 2: only for padlen % 16 == 0 and 16-byte aligned outputs (no row-piece form)
 //   tokens8_lookup  0 automatic, 1 LDS byte table, 2 register table (v_perm_b32)
-//   tokens8_pad   unused dynamic LDS of k_tokens_bp8;  tokens8_abl  ablation experiments (diagnostic)
+//   tokens8_pad   unused dynamic LDS of k_tokens_bp8
 //   onehot_tb     0: automatic, else force 64 / 128 / 256 sequences per tile of k_onehot_tile
 //   tile_order    0: automatic (XCD-aware), 1: position-tile index fastest, 2: XCD-aware, 3: sequence-tile index fastest,
 //                 4: every XCD walks its own contiguous range of sequence tiles (automatic for (P,B) tokens of 2- / 4-byte
 //                 elements whose rows are not 64-byte aligned), 5: as 4 with the position tiles of a sequence tile back to
 //                 back (automatic for the (P,B) int8 token matrix)
-//   expand_mode   0 / 1: k_expand_chunks, 2: k_expand_small (dword token loads; an experiment that lost), 9: the same
-//                 without token loads (ablation)
 //   fill_mode, fill_pad   access pattern / occupancy of bsq_fill_device (write-bandwidth yardsticks)
 //   tokenize_tb           sequences per tile of k_tokenize_tile ((P,B) tokens of 2- / 4- / 8-byte elements): 64 / 128 / 256
 //   wide_index            1: the (B,P) chunk kernels take their 64-bit index arithmetic whatever the size (tests: the path
@@ -66,8 +56,6 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   two_pass_slice_mb     the two-pass one-hot in SLICES of position rows whose id scratch stays cache-resident: 0 automatic (slices of <= 96 MB once the
 //                         id matrix exceeds 128 MB), > 0 that many MB per slice (whatever the size), < 0 never
 //   expand_rows1          the LDS-free expansion k_expand_rows1 (one-byte elements, rows of 3 ... 15 bytes): 0 automatic, 1 never, 2 whenever it applies
-//   tokens8_ring          LABS: N > 0: the (B,P) int8 token matrix through k_tokens_bp8_pipe (every wave walks N chunks with its offsets and
-//                         characters arriving by LDS-DMA two / four chunks ahead) instead of k_tokens_bp8_fast; lost, profiles/r05/tokens8_pipeline_lost.txt
 //   gather_small          bsq_gather_packed_device: 0 one launch up to 4096 indices (k_gather_small), two beyond (k_gather_lengths2 + k_gather_place); 1 the three launches of rounds 2-5
 //   host_pieces           list / host batch -> seq-first one-hot on the device: upload + encode in pieces (0 automatic: 4 pieces when the
 //                         stream is idle and the batch large; 1 never; 2 ... 8 that many) -- bsq_host.cpp, piece_sequences()
@@ -76,23 +64,20 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //   augment_k             attempts per lane and round of the augmentation kernel: 0 automatic (4), 1 (the round-2 form), 2
 // The knobs are ONE plain struct, published as an immutable snapshot: a launcher reads it with a single atomic load
 // (tuning()), never a name lookup under a mutex.  bsq_tuning_set() copies the current snapshot, changes one field and
-// publishes the copy.  Knobs marked LABS select experiment kernels that LOST their measurement, or ablations that
-// CHANGE RESULTS; both are compiled -- and settable -- only in a diagnostic build (-DBSQ_LABS, scripts/build_labs.sh).
-// In the product build bsq_tuning_set() refuses them and no environment variable reaches them.
-#define BSQ_KNOB_LIST(X, L)                                                                                             \
+// publishes the copy.
+#define BSQ_KNOB_LIST(X)                                                                                                \
     X(nt_stores, 1) X(onehot_tb, 0) X(tile_order, 0) X(fill_mode, 0) X(onehot_path, 0) X(expand_pad, 0) X(tokenize_path, 0)   \
     X(fill_pad, 0) X(chunks_pad, 0) X(host_copy_threads, 0) X(tokenize_pad, 0) X(expand_slots, 0) X(tile_group, 0)             \
     X(bcl_path, 0) X(bcl_pad, 0) X(raw_mode, 0) X(workspace_cache, 0) X(tokens8, 0) X(tokens8_fast, 0) X(tokens8_lookup, 0)    \
-    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0) X(expand_gate, 0) X(host_pieces, 0) X(gather_small, 0) X(expand_rows1, 0) X(raw_nibbles, 0) X(two_pass_slice_mb, 0)                                               \
-    L(chunks_cpw, 0) L(tokenize_nch, 0) L(expand_mode, 0) L(xcd_claim, 0) L(chunk_math, 0) L(tokens8_abl, 0) L(augment_mode, 0) L(tokens8_ring, 0)
+    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0) X(expand_gate, 0) X(host_pieces, 0) X(gather_small, 0) X(expand_rows1, 0) X(raw_nibbles, 0) X(two_pass_slice_mb, 0)
 struct Tuning {
 #define BSQ_KNOB_FIELD(name, def) int32_t name = def;
-    BSQ_KNOB_LIST(BSQ_KNOB_FIELD, BSQ_KNOB_FIELD)
+    BSQ_KNOB_LIST(BSQ_KNOB_FIELD)
 #undef BSQ_KNOB_FIELD
 };
 const Tuning &tuning();
 int get_tuning(const char *name);             // by name (bsq_tuning_get); 0 for unknown names
-bool set_tuning(const char *name, int value);  // false: unknown name, or a LABS knob in a product build
+bool set_tuning(const char *name, int value);  // false: unknown name
 inline bool nontemporal_stores() { return tuning().nt_stores != 0; }
 
 // Stream-ordered scratch: the buffer of the last few (device, stream) pairs is kept between calls (knob

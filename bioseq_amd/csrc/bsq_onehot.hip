@@ -155,10 +155,7 @@ struct EParams {
     double inv_rowbytes, inv_B;  // reciprocals for div_by()
     uint32_t rb_magic, rb_shift, rb_pow2;  // fast_div() constants of rowbytes
     int32_t force4;                        // experiment knob "expand_slots" = 4: always four token slots per step
-    int32_t mode;                          // k_expand_small: 9 = no token loads (ablation)
     int64_t pitch;                         // B * rowbytes: bytes of one position row of the output
-    unsigned int *claim;                   // CLAIM: 8 counters, 128 bytes apart, zeroed before the launch
-    int64_t groups_per_class;              // CLAIM: slots-of-4 per class
     Div64 dv_pitch, dv_rb;                 // div64() constants of pitch and rowbytes (scalar chunk arithmetic)
     int32_t nib;                           // 1: `tok` holds NIBBLES (k_expand_chunks<.., NIB>; never with the other expansion kernels)
     int64_t row_gap;                       // column block of a wider tensor: bytes between the end of one position row of the block and
@@ -238,7 +235,7 @@ __device__ __forceinline__ ChunkCoord chunk_coord(const EParams &p, int64_t k, i
 
 // (A variant with the four waves of a workgroup sharing one chunk -- the shape of the fastest plain fill --
 // measured 1.6x slower: every wave then pays the token-load latency for a single 1-KiB store.)
-// (-DBSQ_LABS builds add a CLAIM parameter: labs/bsq_expand_claim.inc.)
+// (Experiments that lost -- a placement-independent chunk claim, scalar 64-bit chunk arithmetic, dword token loads -- are history: csrc/labs/.)
 // GATE (rows of 24 ... 63 bytes; knob "expand_gate"): every wave first issues ONE agent-scope load -- of the head of the token scratch, a
 // line that is always at the memory side -- and makes its token loads depend on it.  The load means nothing; what it does is pace the
 // waves: the small-row expansion runs at 5 workgroups per CU, all of whose waves otherwise reach their token loads and their 4 KiB of
@@ -248,11 +245,7 @@ __device__ __forceinline__ ChunkCoord chunk_coord(const EParams &p, int64_t k, i
 // NIB (round 5): the id matrix holds NIBBLES -- the id of (t, b) in bits 4 (b & 1) ... of byte (t * Bp + b) / 2 (Bp is even), 15 = no one:
 // the scratch of alphabets with at most 15 classes at half its bytes (see two_pass_nibbles).  A template flag: as a runtime one its
 // shift / mask arithmetic cost the BYTE form 13 % on cfg4 f32 (670 -> 759 us).
-#ifdef BSQ_LABS
-template <typename ST, bool NT, int MATH, bool GATE = false, int CLAIM = 0, bool NIB = false>
-#else
 template <typename ST, bool NT, int MATH, bool GATE = false, bool NIB = false>
-#endif
 __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     constexpr int PIECE = kChunk;             // bytes per wave
     constexpr int NS = PIECE / 1024;          // 16-byte stores per lane
@@ -267,9 +260,6 @@ __global__ __launch_bounds__(kThreads) void k_expand_chunks(const EParams p) {
     const int wave_s = MATH == 1 ? __builtin_amdgcn_readfirstlane(wave) : wave;
     int64_t group = static_cast<int64_t>(blockIdx.x >> 3);
     int32_t cls = static_cast<int32_t>(blockIdx.x & 7u);
-#ifdef BSQ_LABS
-#include "labs/bsq_expand_claim.inc"  // CLAIM == 1: placement-independent chunk classes (measurement only)
-#endif
     const int64_t slot = group * 4 + wave_s;
     const int64_t k = static_cast<int64_t>(cls) + 8 * slot;
     if (k >= p.nchunks) return;
@@ -479,9 +469,6 @@ __global__ __launch_bounds__(kThreads) void k_expand_rows1(const EParams p) {
     }
 }
 
-#ifdef BSQ_LABS
-#include "labs/bsq_expand_small.inc"  // k_expand_small
-#endif
 
 // ------------------------------------------------------------------------------------------
 // Channels-first one-hot (B, C, P), two-pass form: raw (B, P) uint8 ids from k_tokens_bp8 (bsq_tokens8.hip), then
@@ -762,8 +749,7 @@ bsq_status onehot_chunk_owner(const KParams &k, size_t sz, hipStream_t s) {
     c.at_len_id = k.eos ? uint32_t(k.eos_id) : c.fill_id;
     const int64_t room = k.P - k.bos - k.eos;
     c.room = int32_t(room < 0 ? 0 : room);
-    const int cpw = bsq_internal::tuning().chunks_cpw;  // chunks per wave (1 is fastest: 0.75 / 0.86 / 0.93 ms for 1 / 2 / 4 on cfg3)
-    c.cpw = cpw > 0 ? cpw : 1;
+    c.cpw = 1;  // chunks per wave (1 is fastest: 0.75 / 0.86 / 0.93 ms for 1 / 2 / 4 on cfg3; the other forms are labs/ history)
     c.one_bits = k.one_bits;
     c.inv_rowbytes = 1.0 / double(k.C * int64_t(sz));
     c.inv_B = 1.0 / double(k.B);
@@ -795,60 +781,17 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     // the optimum also with 2-wave workgroups (16 / 14 / 12 / 10 waves: 0.83 / 0.81 / 0.76 / 0.93 ms), and 3 x 4 waves
     // (0.73 ms) beats 6 x 2.
     // Knob "expand_pad": 0 = this rule, > 0 = that many bytes, < 0 = none.
-    // Knob "expand_mode": 0 / 1 k_expand_chunks; 2 k_expand_small (dword token loads), 9 the same without token loads
-    // (ablation).  k_expand_small is an experiment that lost: once the token scratch is written in XCD-aware tile
-    // order the byte-load kernel under an occupancy cap is 1-2 % ahead of it, and two or four chunks per wave were
-    // 20-40 % slower (profiles/r02/pad_lab*.txt, expand_lab3.txt; those instantiations are no longer built).
-#ifdef BSQ_LABS
-    const int mode = e.mode;
-    const int64_t rb = e.C * int64_t(sizeof(ST));
-    if (rb >= 4 && (mode == 2 || mode == 9)) {
-        const int padv2 = bsq_internal::tuning().expand_pad;
-        const size_t pad2 = padv2 > 0 ? size_t(padv2) : 0;
-        if (bsq_internal::nontemporal_stores())
-            hipLaunchKernelGGL((k_expand_small<ST, true, 1, 0>), grid, dim3(kThreads), pad2, s, e);
-        else
-            hipLaunchKernelGGL((k_expand_small<ST, false, 1, 0>), grid, dim3(kThreads), pad2, s, e);
-        return check_launch("k_expand_small");
-    }
-#endif
+    // (k_expand_small -- dword token loads -- lost: once the token scratch is written in XCD-aware tile order the byte-load kernel under
+    // an occupancy cap is 1-2 % ahead of it, and two or four chunks per wave were 20-40 % slower: profiles/r02/pad_lab*.txt, expand_lab3.txt;
+    // its source is csrc/labs/bsq_expand_small.inc.)
     const int padv = bsq_internal::tuning().expand_pad;
     const bool big_rows = e.C * int64_t(sizeof(ST)) >= 64;
     // (nibble ids, rows below 64 bytes: 12 KiB = FIVE workgroups per CU -- 16 KiB + the 16-KiB image + the kernel's few bytes of static LDS
     //  round up to four; cfg4 f32 with nibbles 714 us at four, 648 at five, 662 at six; byte ids 673 / 690 / 703: profiles/r05/nibble_ids_lab.txt)
     const size_t pad = padv > 0 ? size_t(padv) : (padv < 0 ? size_t(0) : (big_rows ? size_t(36864) : (e.nib ? size_t(12288) : size_t(16384))));
-#ifdef BSQ_LABS
-    if (bsq_internal::tuning().xcd_claim == 1) {  // measurement only: placement-independent chunk classes (see the kernel)
-        static unsigned int *counters[16] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return bsq_internal::set_error(BSQ_ERR_HIP, "hipGetDevice");
-        if (!counters[dev] && hipMalloc(reinterpret_cast<void **>(&counters[dev]), 8 * 128) != hipSuccess)
-            return bsq_internal::set_error(BSQ_ERR_ALLOC, "claim counters");
-        if (hipMemsetAsync(counters[dev], 0, 8 * 128, s) != hipSuccess) return bsq_internal::set_error(BSQ_ERR_HIP, "hipMemsetAsync");
-        EParams ec = e;
-        ec.claim = counters[dev];
-        ec.groups_per_class = groups;
-        if (bsq_internal::nontemporal_stores())
-            hipLaunchKernelGGL((k_expand_chunks<ST, true, 0, false, 1>), grid, dim3(kThreads), pad, s, ec);
-        else
-            hipLaunchKernelGGL((k_expand_chunks<ST, false, 0, false, 1>), grid, dim3(kThreads), pad, s, ec);
-        return check_launch("k_expand_chunks<claim>");
-    }
-#endif
-    // knob "chunk_math": 2 = scalar 64-bit reciprocal multiplies (div64) instead of the double reciprocals (div_by).
-    // Measured (profiles/r02/math_lab1.txt): the scalar prologue is ~90 SALU instructions instead of ~130 VALU ones
-    // (22 of them FP64) and wins where a wave's latency is exposed (2 workgroups per CU: 0.938 vs 0.969 ms on cfg3),
-    // but at the bandwidth optimum (3 per CU) the double form is 1 % FASTER (0.734 vs 0.741 ms): the stream is paced by
-    // the memory system there, not by the prologue.  So the double form stays the default.
-#ifdef BSQ_LABS
-    if (bsq_internal::tuning().chunk_math == 2) {
-        if (bsq_internal::nontemporal_stores())
-            hipLaunchKernelGGL((k_expand_chunks<ST, true, 1>), grid, dim3(kThreads), pad, s, e);
-        else
-            hipLaunchKernelGGL((k_expand_chunks<ST, false, 1>), grid, dim3(kThreads), pad, s, e);
-        return check_launch("k_expand_chunks<div64>");
-    }
-#endif
+    // (Scalar 64-bit reciprocal multiplies instead of the double reciprocals for the chunk arithmetic: ~90 SALU instructions instead of
+    // ~130 VALU ones, ahead where a wave's latency is exposed (2 workgroups per CU: 0.938 vs 0.969 ms on cfg3) and 1 % BEHIND at the
+    // bandwidth optimum (3 per CU: 0.741 vs 0.734 ms) -- profiles/r02/math_lab1.txt; not built any more.)
     // one-byte elements, rows of 3 ... 15 bytes: the LDS-free form (knob "expand_rows1": 0 automatic, 1 never, 2 whenever it applies)
     if constexpr (sizeof(ST) == 1) {
         const int rk = bsq_internal::tuning().expand_rows1;
@@ -881,11 +824,7 @@ bsq_status launch_expand(const EParams &e, hipStream_t s) {
     const bool gated = (gk == 2 || (gk == 0 && rowb >= 24 && rowb < 64)) && e.Bp >= 256;
     if constexpr (sizeof(ST) >= 2) {
         if (e.nib) {  // ids as nibbles (two_pass_nibbles)
-#ifdef BSQ_LABS
-#define BSQ_EXPN(NTV, GV) hipLaunchKernelGGL((k_expand_chunks<ST, NTV, 0, GV, 0, true>), grid, dim3(kThreads), pad, s, e)
-#else
 #define BSQ_EXPN(NTV, GV) hipLaunchKernelGGL((k_expand_chunks<ST, NTV, 0, GV, true>), grid, dim3(kThreads), pad, s, e)
-#endif
             if (bsq_internal::nontemporal_stores()) { if (gated) BSQ_EXPN(true, true); else BSQ_EXPN(true, false); }
             else { if (gated) BSQ_EXPN(false, true); else BSQ_EXPN(false, false); }
 #undef BSQ_EXPN
@@ -919,10 +858,8 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
         return bsq_internal::launch_tokens_pb8(k.desc, k.chars, k.offsets, k.B, k.P, tokens, pitch, s, true, BSQ_I8, nib, tt0, ntt_count);
     if (nib || tt0 != 0 || ntt_count != 0) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "nibble ids / slices need the register-transposed raw pass");
     const dim3 grid(unsigned(tile_grid(k, k.ntt)));
-    // knob "raw_mode": 0 / 1 k_tokens_raw; 2 k_tokens_raw2 (register transpose) with the LDS byte table, 3 with the
-    // register table.  k_tokens_raw2 is an experiment that LOST (profiles/r02/raw_lab.txt: cfg2 as (P,B) int8 tokens
-    // 24.0 us -> 25.8 (2) / 27.4 (3); cfg3 / cfg4 f32 steps +0.1 / +0.3 %): the tile is bound by vector instructions at
-    // least as much as by LDS traffic, and the transpose trades 3 LDS writes for 6 vector instructions per word.
+    // knob "raw_mode": 0 / 1 k_tokens_raw.  (k_tokens_raw2 -- a register transpose through v_permlane swaps -- LOST: profiles/r02/raw_lab.txt,
+    // cfg2 as (P,B) int8 tokens 24.0 us -> 25.8 / 27.4; its source is csrc/labs/bsq_tokens_raw2.inc.)
     const int rm = bsq_internal::tuning().raw_mode;
     if (!k.mask && rm == 4 && k.P <= (int64_t(1) << 20)) {  // measurement: the wide tile of the (P,B) int8 token matrix
         k.ntb = int32_t((k.B + kWideTB - 1) / kWideTB);
@@ -932,13 +869,6 @@ bsq_status launch_tokens_raw(KParams &k, void *tokens, int64_t pitch, hipStream_
                            dim3(kThreads), 0, s, k);
         return check_launch("k_tokens_raw<wide>");
     }
-#ifdef BSQ_LABS
-    if (!k.mask && (rm == 2 || rm == 3)) {
-        if (rm == 3 && k.foldable) hipLaunchKernelGGL((k_tokens_raw2<true, true>), grid, dim3(kThreads), 0, s, k);
-        else hipLaunchKernelGGL((k_tokens_raw2<true, false>), grid, dim3(kThreads), 0, s, k);
-        return check_launch("k_tokens_raw2");
-    }
-#endif
     if (k.mask) hipLaunchKernelGGL(k_tokens_raw<true>, grid, dim3(kThreads), 0, s, k);
     else hipLaunchKernelGGL(k_tokens_raw<false>, grid, dim3(kThreads), 0, s, k);
     return check_launch("k_tokens_raw");
@@ -959,15 +889,12 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
     e.nchunks = (e.head + e.total + kChunk - 1) / kChunk;
     // a column block whose rows do not all start on chunk boundaries of memory: the ragged form (see EParams)
     const int64_t block_row = B * C * int64_t(sz);
-    e.ragged = (row_gap != 0 && (e.head != 0 || block_row % kChunk != 0 || (block_row + row_gap) % kChunk != 0) && bsq_internal::tuning().expand_mode == 0 &&
-                bsq_internal::tuning().chunk_math == 0 && bsq_internal::tuning().xcd_claim == 0) ? 1 : 0;
+    e.ragged = (row_gap != 0 && (e.head != 0 || block_row % kChunk != 0 || (block_row + row_gap) % kChunk != 0)) ? 1 : 0;
     e.npr8 = ((block_row + 2 * int64_t(kChunk) - 2) / kChunk + 7) / 8 * 8;
     e.inv_npr8 = 1.0 / double(e.npr8);
     if (e.ragged) {
         e.head = 0;
         e.nchunks = P * e.npr8;
-    } else if (row_gap != 0 && (e.head != 0 || block_row % kChunk != 0)) {
-        return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "column block: its rows must be whole chunks under this knob");
     }
     e.C = C;
     e.one_bits = one_bits;
@@ -976,11 +903,8 @@ bsq_status launch_expansion(const uint8_t *tokens, int64_t pitch, int64_t B, int
     e.pitch = B * C * int64_t(sz);
     e.dv_pitch = div64_constants(uint64_t(e.pitch));
     e.dv_rb = div64_constants(uint64_t(C * int64_t(sz)));
-    e.claim = nullptr;
-    e.groups_per_class = 0;
     div_constants(uint32_t(C * int64_t(sz)), &e.rb_magic, &e.rb_shift, &e.rb_pow2);
     e.force4 = bsq_internal::tuning().expand_slots == 4;
-    e.mode = bsq_internal::tuning().expand_mode;
     switch (sz) {
     case 1: return launch_expand<uint8_t>(e, s);
     case 2: return launch_expand<uint16_t>(e, s);
@@ -1016,7 +940,7 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz) {
     const bool pb8 = !k.mask && k.desc && tn.raw_mode == 0 &&
                      bsq_internal::tokens_pb8_applicable(k.desc, k.B, k.P, reinterpret_cast<const void *>(uintptr_t(256)), pl.pitch);
     const bool rows1 = sz == 1 && rb >= 3 && rb <= 15 && tn.expand_rows1 != 1;  // (launch_expand: one-byte rows expand through k_expand_rows1)
-    const bool nib_ok = pb8 && k.C <= 15 && (sz >= 2 || rows1) && tn.expand_mode == 0 && tn.xcd_claim == 0 && tn.chunk_math == 0;
+    const bool nib_ok = pb8 && k.C <= 15 && (sz >= 2 || rows1);
     // (automatic: rows of 24 ... 31 bytes, and every id matrix beyond 128 MB as bytes -- half the scratch to keep resident, slices of twice the rows)
     pl.nib_ok = nib_ok && tn.raw_nibbles != 1;
     // (one-byte rows through k_expand_rows1<nibbles>: ahead of byte ids on every shape tried, 2-9 % -- profiles/r05/rows1_nib_sweep.txt)
@@ -1026,7 +950,7 @@ TwoPassPlan two_pass_plan(const KParams &k, size_t sz) {
     pl.wants_slices = false;
     const int64_t mb = tn.two_pass_slice_mb;
     // (slices of a column block that do not start on a chunk boundary take the ragged form, see EParams: no condition on the gap)
-    if (pb8 && mb >= 0 && tn.expand_mode == 0) {
+    if (pb8 && mb >= 0) {
         const int64_t slice_bytes = (mb > 0 ? mb : 96) << 20;
         if ((mb > 0 && all_bytes > slice_bytes) || all_bytes > (int64_t(128) << 20)) {
             pl.wants_slices = true;
@@ -1194,10 +1118,6 @@ const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_
     case 1: return "k_onehot_tile";
     case 2: {
         const int64_t rb = bsq_alphabet_size(d) * int64_t(bsq_dtype_size(t));
-#ifdef BSQ_LABS
-        const int mode = bsq_internal::tuning().expand_mode;
-        if (rb >= 4 && (mode == 2 || mode == 9)) return "k_tokens_raw+k_expand_small";
-#endif
         // (unmasked: the raw-id pass runs in k_tokens_pb8_fast unless a knob keeps it in k_tokens_raw -- see launch_tokens_raw)
         const bool rows1 = bsq_dtype_size(t) == 1 && rb >= 3 && rb <= 15 && bsq_internal::tuning().expand_rows1 != 1;
         if (bsq_internal::tuning().raw_mode == 0 && bsq_internal::tuning().tokens_pb8 != 1) {

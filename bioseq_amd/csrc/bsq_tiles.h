@@ -222,9 +222,6 @@ __device__ __forceinline__ uint32_t finish4(const TokenRule p, const uint8_t *s_
     return w;
 }
 
-#ifdef BSQ_LABS
-#include "labs/bsq_tokens_raw2_helpers.inc"  // helpers of k_tokens_raw2 (4 x 4 byte transposes in registers
-#endif
 
 __device__ __forceinline__ uint32_t resolve4(const TokenRule p, const uint8_t *s_lut, uint32_t start, int32_t L,
                                              int32_t tpos) {
@@ -464,9 +461,6 @@ __global__ __launch_bounds__(kThreads) void k_tokens_raw(const KParams p) {
     }
 }
 
-#ifdef BSQ_LABS
-#include "labs/bsq_tokens_raw2.inc"  // k_tokens_raw2
-#endif
 
 // ------------------------------------------------------------------------------------------
 // Launch helpers

@@ -502,14 +502,10 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     div_constants(uint32_t(k.C > 0 ? k.C : 1), &c.magic_c, &c.shift_c, &c.pow2_c);
     c.step_q = 64u / c.ppr;
     c.step_r = 64u % c.ppr;
-    // Chunks per wave: 1.  The software-pipelined 4-chunk form (knob "tokenize_nch" = 4) is 15-20 % SLOWER on cfg2 /
+    // Chunks per wave: 1.  The software-pipelined 4-chunk form (round 2; not built any more) was 15-20 % SLOWER on cfg2 /
     // cfg5: the kernel is bound by its ~550 VALU instructions per chunk, not by memory latency, and four chunks
     // per wave cost occupancy (102 VGPRs).
-#ifdef BSQ_LABS
-    const int nch = bsq_internal::tuning().tokenize_nch == 4 && !ragged ? 4 : 1;
-#else
     const int nch = 1;
-#endif
     const int64_t groups = ((c.nchunks + 7) / 8 + int64_t(4) * nch - 1) / (int64_t(4) * nch);
     if (groups * 8 >= (int64_t(1) << 31)) return bsq_internal::set_error(BSQ_ERR_INVALID_ARG, "output too large");
     const dim3 grid(unsigned(groups * 8));
@@ -519,11 +515,6 @@ bsq_status launch_tokenize_chunks(const KParams &k, hipStream_t s) {
     if (ragged) {
         if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 1, true>), grid, dim3(kThreads), pad, s, c);
         else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 1, true>), grid, dim3(kThreads), pad, s, c);
-#ifdef BSQ_LABS
-    } else if (nch == 4) {
-        if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 4>), grid, dim3(kThreads), pad, s, c);
-        else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 4>), grid, dim3(kThreads), pad, s, c);
-#endif
     } else {
         if (nt) hipLaunchKernelGGL((k_tokenize_chunks<T, true, HOT, 1>), grid, dim3(kThreads), pad, s, c);
         else hipLaunchKernelGGL((k_tokenize_chunks<T, false, HOT, 1>), grid, dim3(kThreads), pad, s, c);
@@ -613,7 +604,7 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         // 65000 x 1001 29.1 -> 27.3, cfg2 24.7 -> 24.0 (profiles/r02/seqfirst_orders2.txt)
         if (bsq_internal::tuning().tile_order == 0) k.order = 5;
         const int rm = bsq_internal::tuning().raw_mode;
-        // knob "raw_mode": 0 automatic, 1 the 256 x 64 tile, 4 the wide 1024 x 16 tile, 2 / 3 the round-2 experiments
+        // knob "raw_mode": 0 automatic, 1 the 256 x 64 tile, 4 the wide 1024 x 16 tile
         const bool wide_ok = P <= (int64_t(1) << 20);  // 1024 sequences x padlen in 32-bit window offsets
         if (wide_ok && rm == 4) {  // measurement only: 35 vs 24 us on cfg2 (profiles/r02/seqfirst_lab1.txt)
             k.ntb = int32_t((k.B + kWideTB - 1) / kWideTB);
@@ -625,13 +616,6 @@ bsq_status bsq_tokenize_device(const bsq_desc *d, const uint8_t *chars, const in
         }
         k.ntb = int32_t((k.B + kRawTB - 1) / kRawTB);
         const dim3 vgrid(unsigned(tile_grid(k, k.ntt)));
-#ifdef BSQ_LABS
-        if (rm == 2 || rm == 3) {
-            if (rm == 3 && k.foldable) hipLaunchKernelGGL((k_tokens_raw2<false, true>), vgrid, dim3(kThreads), 0, s, k);
-            else hipLaunchKernelGGL((k_tokens_raw2<false, false>), vgrid, dim3(kThreads), 0, s, k);
-            return check_launch("k_tokens_raw2<value>");
-        }
-#endif
         if (vgrid.x <= 2048u)  // about one round of workgroups: the latency form
             hipLaunchKernelGGL((k_tokens_raw<false, false, kRawTB, kTT, true>), vgrid, dim3(kThreads), 0, s, k);
         else

@@ -666,9 +666,6 @@ __global__ __launch_bounds__(kThreads) void k_tokens_bp8_fast_multi(uint32_t PPR
                                   tab, rules, FusedWait{});
 }
 
-#ifdef BSQ_LABS
-#include "labs/bsq_tokens8_pipe.inc"  // k_tokens_bp8_pipe: the per-wave LDS-DMA pipeline (round 5; lost: profiles/r05/tokens8_pipeline_lost.txt)
-#endif
 
 // BASELINE config 5 as ONE launch (round 3): BLOSUM62 augmentation (bsq_augment.hip) and the (B,P) int8 token matrix.  The first
 // `aug_blocks` workgroups (a multiple of 8, so that the token role's chunk classes stay pinned to their XCDs) are k_augment_groups
@@ -1077,16 +1074,6 @@ __global__ __launch_bounds__(kThreads) void k_tokens_pb8_fast_multi(uint32_t P, 
 
 template <bool NT, int LK>
 void launch_variant(const T8Params &c, dim3 grid, size_t pad, hipStream_t s) {
-#ifdef BSQ_LABS  // ablations: their output is WRONG on purpose; they exist in diagnostic builds only
-    switch (c.abl) {
-    case 1: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 1>), grid, dim3(kThreads), pad, s, c); return;
-    case 2: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 2>), grid, dim3(kThreads), pad, s, c); return;
-    case 3: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 3>), grid, dim3(kThreads), pad, s, c); return;
-    case 4: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 4>), grid, dim3(kThreads), pad, s, c); return;
-    case 5: hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 5>), grid, dim3(kThreads), pad, s, c); return;
-    default: break;
-    }
-#endif
     if (c.mask)  // raw ids for the masked channels-first one-hot (aligned shapes only: see launch_tokens_bp8)
         hipLaunchKernelGGL((k_tokens_bp8<NT, LK, 0, false, true>), grid, dim3(kThreads), pad, s, c);
     else if (c.P % 16 != 0 || reinterpret_cast<uintptr_t>(c.out) % 16 != 0)
@@ -1269,7 +1256,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
     const uint32_t fill = d->padchar ? uint32_t(bsq_pad_id(d)) : c.none_v;  // no padchar: the memset 0 of tokenize.h:427 stays
     c.fill_v = fill;
     c.at_len_v = d->eos ? uint32_t(bsq_eos_id(d)) : fill;
-    c.abl = tuning().tokens8_abl;
+    c.abl = 0;
     c.wide_index = tuning().wide_index;
     int lk = tuning().tokens8_lookup;  // 0 automatic (registers when the table folds), 1 LDS byte table, 2 registers
     if (lk == 0) lk = foldable ? 2 : 1;
@@ -1398,24 +1385,6 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
         }
         if (fuse) return BSQ_OK;  // the caller runs the two launches (fused_taken stays false; nothing was launched)
         const bool eosv = (c.at_len_v & 0xFFu) != (c.fill_v & 0xFFu);
-#ifdef BSQ_LABS
-        // knob "tokens8_ring" = N > 0: the per-wave LDS-DMA pipeline, N chunks per wave (round 5 experiment; 0: the fast kernel)
-        if (tuning().tokens8_ring > 0 && !raw) {
-            const int32_t nsteps = tuning().tokens8_ring;
-            const int64_t per_class = (c.nchunks + 7) / 8;
-            const int64_t wgs = (per_class + 4 * int64_t(nsteps) - 1) / (4 * int64_t(nsteps));
-            const dim3 rgrid(unsigned(wgs * 8));
-#define BSQ_T8R(NTV, EV)                                                                                                                  \
-    hipLaunchKernelGGL((k_tokens_bp8_pipe<NTV, EV>), rgrid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks), uint32_t(B), \
-                       c.ppr, magic, shift, c.room, packed, tab, rules, nsteps)
-            if (nt) { if (eosv) BSQ_T8R(true, true); else BSQ_T8R(true, false); }
-            else { if (eosv) BSQ_T8R(false, true); else BSQ_T8R(false, false); }
-#undef BSQ_T8R
-            const hipError_t er = hipGetLastError();
-            if (er != hipSuccess) return set_hip_error("k_tokens_bp8_pipe", er);
-            return BSQ_OK;
-        }
-#endif
 #define BSQ_T8F(NTV, EV)                                                                                                                 \
     hipLaunchKernelGGL((k_tokens_bp8_fast<NTV, EV>), grid, dim3(kThreads), pad, s, offsets, chars, c.out, uint32_t(c.nchunks), uint32_t(B), \
                        c.ppr, magic, shift, c.room, packed, tab, rules)
@@ -1563,7 +1532,7 @@ struct Bp8Shared {
 static bool bp8_shared_setup(const bsq_desc *d, int64_t P, Bp8Shared &c) {
     const Tuning &tn = tuning();
     if (bsq_alphabet_size(d) > 250 || P < 128 || P % 16 != 0 || P > (int64_t(1) << 30)) return false;
-    if (tn.tokenize_path == 1 || tn.tokens8_abl != 0 || tn.wide_index || tn.tokens8_pad > 0 || tn.tokens8 == 1 || tn.tokens8_fast == 1) return false;
+    if (tn.tokenize_path == 1 || tn.wide_index || tn.tokens8_pad > 0 || tn.tokens8 == 1 || tn.tokens8_fast == 1) return false;
     const bool foldable = fold_table(d->lut, c.tab.t, 0u);
     if (!foldable || tn.tokens8_lookup == 1) return false;  // (the LDS byte-table form has no fast kernel)
     const uint32_t fill = d->padchar ? uint32_t(bsq_pad_id(d)) : 0u;
@@ -1625,7 +1594,7 @@ bsq_status launch_tokens_multi(const bsq_desc *d, int32_t n, const bsq_batch *bt
     *taken = false;
     if (n < 1 || n > kMultiMax || bsq_alphabet_size(d) > 250 || P <= 0 || P > (int64_t(1) << 30)) return BSQ_OK;
     const Tuning &tn = tuning();
-    if (tn.tokenize_path == 1 || tn.tokens8_abl != 0 || tn.wide_index || tn.tokens8_pad > 0) return BSQ_OK;
+    if (tn.tokenize_path == 1 || tn.wide_index || tn.tokens8_pad > 0) return BSQ_OK;
     const size_t sz = bsq_dtype_size(t);
     if (batch_first) {
         Bp8Shared c;

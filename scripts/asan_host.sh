@@ -2,7 +2,7 @@
 # CPU-only sanitizer run of ALL host code of the product (GPU ASan is not available on this pool):
 #   * bsq_host.cpp (staging ring, host entry points), bsq_alphabet.cpp (LUT builder, descriptors), bsq_fastx.cpp (the streaming
 #     FASTA / FASTQ / gzip parser -- untrusted text) are rebuilt with g++ -fsanitize=address,undefined and linked with the hipcc-built
-#     kernel objects (csrc/_obj/*.hip.o, uninstrumented) into a scratch libbsq_hip.so;
+#     kernel objects (exactly build.py's LIB_SRCS, uninstrumented) into a scratch libbsq_hip.so;
 #   * cbioseq_module.cpp (pybind11 layer) is rebuilt the same way against it;
 #   * the host-only test modules run against the scratch copy: surface + error paths, FlatFile / FASTX differentials against the
 #     compiled reference (400 adversarial texts, 16 383 ... 131 072-byte lines, truncated gzip members), ABI + alphabets.
@@ -14,14 +14,16 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 W=$(mktemp -d)
 trap 'rm -rf "$W"' EXIT
 cp -r "$REPO/bioseq_amd" "$REPO/tests" "$REPO/oracle" "$REPO/include" "$REPO/bench.py" "$REPO/__graft_entry__.py" "$W/"
-[ -d "$REPO/bioseq_amd/csrc/_obj" ] || python3 "$REPO/bioseq_amd/build.py"
+# always: the build is incremental, and objects of an older tree must never be linked against fresh host code
+python3 "$REPO/bioseq_amd/build.py" > /dev/null
+KOBJS=$(python3 "$REPO/bioseq_amd/build.py" --kernel-objects)
 SAN="-O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer"
 for f in bsq_host bsq_alphabet bsq_fastx; do
   g++ $SAN -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$REPO/include" -I"$REPO/bioseq_amd/csrc" -c "$REPO/bioseq_amd/csrc/$f.cpp" -o "$W/$f.o" &
 done
 wait
 g++ -shared -fPIC -fsanitize=address,undefined -pthread -o "$W/bioseq_amd/libbsq_hip.so" "$W"/bsq_host.o "$W"/bsq_alphabet.o "$W"/bsq_fastx.o \
-    "$REPO"/bioseq_amd/csrc/_obj/*.hip.o -L/opt/rocm/lib -lamdhip64 -lz -Wl,-rpath,/opt/rocm/lib
+    $KOBJS -L/opt/rocm/lib -lamdhip64 -lz -Wl,-rpath,/opt/rocm/lib
 g++ $SAN -shared -fvisibility=hidden \
     -I"$REPO/include" -I"$(python3 -c 'import pybind11;print(pybind11.get_include())')" \
     -I"$(python3 -c 'import sysconfig;print(sysconfig.get_paths()["include"])')" \

@@ -47,8 +47,8 @@ def test_host_only_abi_calls(alphabets_golden):
     assert lib.bsq_validate_lengths(offs.ctypes.data, 3, 6, 1, 1, ctypes.byref(bad)) == capi.ERR_SEQ_TOO_LONG and bad.value == 1
     assert lib.bsq_strerror(capi.ERR_SEQ_TOO_LONG) == b"seq len + bos + eos > padlen"
     assert lib.bsq_tuning_set(b"no_such_knob", 1) == capi.ERR_INVALID_ARG
-    # result-changing ablations and the experiment kernels that lost exist only in -DBSQ_LABS builds: the product
-    # library refuses their knobs, and no environment variable reaches them
+    # result-changing ablations and the experiment kernels that lost are not in the library at all (round 6: csrc/labs/README.md): their
+    # knob names are unknown to it, and no environment variable reaches anything
     for labs_knob in (b"tokens8_abl", b"expand_mode", b"xcd_claim", b"chunk_math", b"tokenize_nch", b"chunks_cpw", b"augment_mode"):
         assert lib.bsq_tuning_set(labs_knob, 1) == capi.ERR_INVALID_ARG, labs_knob
         assert lib.bsq_tuning_get(labs_knob) == 0

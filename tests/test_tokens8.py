@@ -30,25 +30,21 @@ def nasty_batch(seed, n, lo, hi):
     return chars, offs
 
 
-@pytest.fixture(params=[(0, 0, 0, 0), (0, 1, 0, 0), (0, 2, 0, 0), (0, 2, 1, 0), (1, 0, 0, 0), (0, 0, 0, 1), (0, 0, 0, 2), (0, 0, 0, 3), (0, 0, 0, 8)],
-                ids=["auto", "lds-table", "register-table", "register-table-round2-form", "round1-kernel", "ring-1-step", "ring-2-steps",
-                     "ring-3-steps", "ring-8-steps"])
+@pytest.fixture(params=[(0, 0, 0), (0, 1, 0), (0, 2, 0), (0, 2, 1), (1, 0, 0)],
+                ids=["auto", "lds-table", "register-table", "register-table-round2-form", "round1-kernel"])
 def variant(request):
-    """auto / register-table take k_tokens_bp8_fast (round 3) on aligned shapes; tokens8_fast = 1 keeps the round-2 form; ring-N: the
-    loader / consumer form k_tokens_bp8_ring (round 5), N steps per workgroup (1, 2: the prologue-only schedules of its DMA counts)."""
+    """auto / register-table take k_tokens_bp8_fast (round 3) on aligned shapes; tokens8_fast = 1 keeps the round-2 form.  (The LDS-DMA
+    pipeline variants of round 5 left the library with their kernel: csrc/labs/README.md.)"""
     from bioseq_amd import capi
     lib = capi.load()
-    off, lookup, nofast, ring = request.param
+    off, lookup, nofast = request.param
     capi.check(lib.bsq_tuning_set(b"tokens8", off))
     capi.check(lib.bsq_tuning_set(b"tokens8_lookup", lookup))
     capi.check(lib.bsq_tuning_set(b"tokens8_fast", nofast))
-    if ring and lib.bsq_tuning_set(b"tokens8_ring", ring) != capi.OK:
-        pytest.skip("k_tokens_bp8_pipe exists in -DBSQ_LABS builds only (an experiment that lost: profiles/r05/tokens8_pipeline_lost.txt)")
     yield request.param[:2]
     capi.check(lib.bsq_tuning_set(b"tokens8", 0))
     capi.check(lib.bsq_tuning_set(b"tokens8_lookup", 0))
     capi.check(lib.bsq_tuning_set(b"tokens8_fast", 0))
-    lib.bsq_tuning_set(b"tokens8_ring", 0)
 
 
 def dev_tokens(lib, capi, desc, chars, offs, P, gpu, out_shift=0):
