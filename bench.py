@@ -467,17 +467,8 @@ class Batch:
             return self.lib.bsq_onehot_kernel_name(ctypes.byref(self.desc), n, P, self.dt_code).decode()
         if op == "onehot_bcl":
             return "k_tokens_bp8<raw>+k_expand_bcl" if (P >= 128 and P % 16 == 0 and self.out_bytes >= (256 << 20)) else "k_tokenize_chunks<onehot bcl>"
-        if self.batch_first:
-            name = "k_tokens_bp8_fast" if sz == 1 and P >= 128 and P % 16 == 0 else "k_tokenize_chunks"
-        else:
-            name = "k_tokens_pb8_fast" if sz <= 2 and (n * sz) % 16 == 0 else ("k_tokens_raw<value>" if sz == 1 else "k_tokenize_tile")
-        if op == "augment+tokenize":
-            if name != "k_tokens_bp8_fast":
-                return "k_augment_groups+" + name
-            # one launch either way: up to 16 384 chunks nobody waits and a patch launch follows; beyond that the token waves wait for flags
-            return ("k_augment_tokens_nowait(k_augment_groups || k_tokens_bp8_fast)+k_patch_tokens" if n * P <= 16384 * 4096
-                    else "k_augment_tokens_fused(k_augment_groups -> k_tokens_bp8_fast)")
-        return name
+        # (the library's own dispatch as a function of the shape: bsq_tokenize_kernel_name -- ADVICE round 5: this used to be re-implemented here)
+        return self.lib.bsq_tokenize_kernel_name(ctypes.byref(self.desc), n, P, int(self.batch_first), self.dt_code, 1 if op == "augment+tokenize" else 0).decode()
 
     def describe(self):
         cfg = self.cfg

@@ -85,6 +85,7 @@ def load():
         "bsq_onehot_block_device": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, i64, vp]),
         "bsq_tokenize_block_device": (i32, [dp, vp, vp, i64, i64, c_int, vp, i64, vp]),
         "bsq_onehot_kernel_name": (ctypes.c_char_p, [dp, i64, i64, c_int]),
+        "bsq_tokenize_kernel_name": (ctypes.c_char_p, [dp, i64, i64, i32, c_int, i32]),
         "bsq_tokenize_device_generic": (i32, [dp, vp, vp, i64, i64, i32, c_int, vp, vp]),
         "bsq_onehot_device_generic": (i32, [dp, vp, vp, vp, i64, i64, c_int, vp, vp]),
         "bsq_fill_device": (i32, [vp, sz, ctypes.c_uint32, vp]),

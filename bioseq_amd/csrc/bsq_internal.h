@@ -91,6 +91,9 @@ std::mutex &workspace_mutex();
 
 // bsq_tokens8.hip: the (B,P) int8 token matrix (register-table lookups, LDS rule tables).
 bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out);
+int64_t tokens_bp8_chunks(int64_t B, int64_t P);                                              // 4-KiB chunks of the (B,P) int8 matrix
+bool tokens_bp8_fast_form(const bsq_desc *d, int64_t B, int64_t P, bool aligned_out);         // k_tokens_bp8_fast (else k_tokens_bp8)
+bool tokens_bp8_nowait_form(int64_t nchunks);                                                 // fused augmentation: no-wait form (else the flag form)
 // raw = false: token VALUES (batch_tokenize); raw = true: ids with BSQ_NO_TOKEN (255) where a one-hot row is all zero
 // fuse != nullptr: the BLOSUM62 augmentation of `fuse->chars` (the same buffer as `chars`) in the SAME launch when the fast form applies
 // (*fused_taken = true); otherwise NOTHING is launched and the caller runs the two launches itself.

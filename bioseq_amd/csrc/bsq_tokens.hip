@@ -727,6 +727,41 @@ bsq_status bsq_augment_tokenize_device_multi(const bsq_desc *d, int32_t n, const
     return bsq_tokenize_device_multi(d, n, batches, P, batch_first, t, hip_stream);
 }
 
+// Name of the kernel(s) bsq_tokenize_device (augment = 0) / bsq_augment_tokenize_device (augment = chain_len > 0) launch for this shape, for a
+// 16-byte aligned contiguous output: the dispatch above, as a function of the shape alone (profiling / bench labels).
+const char *bsq_tokenize_kernel_name(const bsq_desc *d, int64_t B, int64_t P, int32_t batch_first, bsq_dtype t, int32_t augment) {
+    if (!d || B <= 0 || P <= 0) return "";
+    const size_t sz = bsq_dtype_size(t);
+    if (sz == 0) return "";
+    const int C = bsq_alphabet_size(d);
+    const auto &tn = bsq_internal::tuning();
+    if (C > 250 || B >= (int64_t(1) << 31) - 1024 || (!batch_first && P > kMaxTiledP)) return augment ? "k_augment_groups+k_tokenize_generic" : "k_tokenize_generic";
+    if (batch_first) {
+        const bool bp8 = t == BSQ_I8 && tn.tokenize_path != 1 && tn.tokens8 != 1 && bsq_internal::tokens_bp8_applicable(d, B, P, nullptr) &&
+                         (P % 16 == 0 || tn.tokens8 != 2);
+        if (bp8) {
+            const bool fast = bsq_internal::tokens_bp8_fast_form(d, B, P, true);
+            if (augment && fast && tn.augment_fused != 1)
+                return bsq_internal::tokens_bp8_nowait_form(bsq_internal::tokens_bp8_chunks(B, P))
+                           ? "k_augment_tokens_nowait(k_augment_groups || k_tokens_bp8_fast)+k_patch_tokens"
+                           : "k_augment_tokens_fused(k_augment_groups -> k_tokens_bp8_fast)";
+            if (augment) return fast ? "k_augment_groups+k_tokens_bp8_fast" : "k_augment_groups+k_tokens_bp8";
+            return fast ? "k_tokens_bp8_fast" : "k_tokens_bp8";
+        }
+        const bool chunks = tn.tokenize_path != 1 && (P % int64_t(16 / sz) == 0 || tn.tokenize_path != 2);
+        if (augment) return chunks ? "k_augment_groups+k_tokenize_chunks" : "k_augment_groups+k_tokenize_rows";
+        return chunks ? "k_tokenize_chunks" : "k_tokenize_rows";
+    }
+    const char *name;
+    alignas(64) static const char aligned_dummy[64] = {};
+    if (tn.tokenize_path != 1 && bsq_internal::tokens_pb8_applicable(d, B, P, aligned_dummy, B, t)) name = "k_tokens_pb8_fast";
+    else if (t == BSQ_I8 && tn.tokenize_path != 1) name = "k_tokens_raw<value>";
+    else name = "k_tokenize_tile";
+    if (!augment) return name;
+    return name == std::string("k_tokens_pb8_fast") ? "k_augment_groups+k_tokens_pb8_fast"
+           : (name == std::string("k_tokens_raw<value>") ? "k_augment_groups+k_tokens_raw<value>" : "k_augment_groups+k_tokenize_tile");
+}
+
 bsq_status bsq_fused_status(uint32_t *failures) {
     const uint32_t n = bsq_internal::fused_failures();
     if (failures) *failures = n;

@@ -724,13 +724,18 @@ __global__ __launch_bounds__(kThreads) void k_augment_tokens_fused(const int64_t
 }
 
 // The NO-WAIT form (round 5) -- cfg5's default entry since then.  Nobody waits for anybody inside the launch: the augmentation role mutates the
-// characters in place (plain stores) and writes every mutation down (position, new byte); the token role is k_tokens_bp8_fast as it is, at
+// characters in place (single BYTE stores at agent scope -- augment_groups_body<K, COHERENT = true>, as compiled: a one-byte store is atomic
+// whatever its scope, the scope only says where it becomes visible) and writes every mutation down (position, new byte); the token role is k_tokens_bp8_fast as it is, at
 // once, on whatever it finds -- for a mutated position that is the old residue or the new one, depending on who came first.  A second, tiny
 // launch (k_patch_tokens, one thread per sequence, in chain order) then stores the token of every recorded new residue at its place in the
 // matrix: whichever version the token role saw, the matrix ends up as the tokens of the mutated batch, bit for bit (a mutation never
 // changes a length, so BOS / EOS / PAD are where they were).  Against the flag form (above; still there under knob augment_fused = 2):
-// the ~9 us the token stream used to wait for the augmentation are gone, so are the written-through stores, the second fetch of the
-// characters through sc1 loads, the polling, the epoch bookkeeping -- and the failure mode (a wait that could expire).  What it costs is
+// the ~9 us the token stream used to wait for the augmentation are gone, so are the second fetch of the characters through sc1 loads, the
+// polling, the epoch bookkeeping -- and the failure mode (a wait that could expire).  The token role READS `chars` through ordinary (restrict-
+// qualified, cacheable) loads while other workgroups of the same launch store single bytes into it: by the letter of the language that is a
+// data race; what the hardware does with it is read either the old or the new BYTE of a position (never a torn one), and the patch launch
+// overwrites exactly those positions -- the tolerated race is the design, stated here so that nobody takes the qualifier for a proof
+// (ADVICE round 5).  What it costs is
 // the patch launch: 1 MB of records read, one byte store per mutation.  Round 4 had tried the side list with the wait kept INSIDE the
 // launch (46.5 us: the late waits stalled the stream); profiles/r05/aug_nowait_patch_ab.txt.
 template <bool NT, int K, bool EOSV>
@@ -1124,6 +1129,22 @@ static void build_rules(uint32_t fill_v, uint32_t at_len_v, T8Rules &rules) {
     }
 }
 
+// The decisions of launch_tokens_bp8 as functions of the shape alone -- shared by the launcher and by bsq_tokenize_kernel_name (ADVICE round 5:
+// bench.py used to re-implement them and could report a kernel that was not the one launched).
+int64_t tokens_bp8_chunks(int64_t B, int64_t P) { return (B * ((P + 15) / 16) + kChunk / 16 - 1) / (kChunk / 16); }
+bool tokens_bp8_fast_form(const bsq_desc *d, int64_t B, int64_t P, bool aligned_out) {
+    uint32_t tab[8];
+    const Tuning &tn = tuning();
+    int lk = tn.tokens8_lookup;
+    const bool foldable = fold_table(d->lut, tab, 0u);
+    if (lk == 0) lk = foldable ? 2 : 1;
+    if (lk == 2 && !foldable) lk = 1;
+    return lk == 2 && P % 16 == 0 && aligned_out && !tn.wide_index && tokens_bp8_chunks(B, P) < (int64_t(1) << 23) && B < (int64_t(1) << 31) &&
+           tn.tokens8_fast != 1;
+}
+// fused augmentation + tokens: the no-wait form (k_augment_tokens_nowait + k_patch_tokens) or the flag form (k_augment_tokens_fused)
+bool tokens_bp8_nowait_form(int64_t nchunks) { return (tuning().augment_fused == 0 && nchunks <= 16384) || tuning().augment_fused == 4; }
+
 bool tokens_bp8_applicable(const bsq_desc *d, int64_t B, int64_t P, const void *out) {
     (void)d;
     (void)out;  // any alignment: P % 16 != 0 or a misaligned output take the kernel's row-piece form (RG)
@@ -1293,7 +1314,7 @@ bsq_status launch_tokens_bp8(const bsq_desc *d, const uint8_t *chars, const int6
                 // loader batch of 4096: 12.5 vs 14.1) -- beyond that the mutations' own work no longer hides beside the stream and the patch
                 // launch comes on top (262 144 sequences: 40.5 + 6.4 us against 41 for the flag form, which cfg5 itself therefore keeps).
                 // Knob 4: whatever the size.
-                if ((tuning().augment_fused == 0 && c.nchunks <= 16384) || tuning().augment_fused == 4) {
+                if (tokens_bp8_nowait_form(c.nchunks)) {
                     std::lock_guard<std::mutex> scratch_turn(workspace_mutex());  // (the scratch is shared by the calls of a stream: both launches back to back)
                     void *ws = nullptr;
                     const int32_t chain = fuse->chain_len > 0 ? fuse->chain_len : 1;

@@ -1371,10 +1371,22 @@ PYBIND11_MODULE(cbioseq, m) {
              py::arg("bos") = false, py::arg("padchar") = false)
         .def("batch_tokenize", &Tokenizer::batch_tokenize, py::arg("batch"), py::arg("padlen") = -1,
              py::arg("destchar") = "B", py::arg("batch_first") = false, py::arg("nthreads") = 1, py::kw_only(),
-             py::arg("device") = py::none())
+             py::arg("device") = py::none(),
+             "Token matrix of a list of sequences -- (padlen, B), or (B, padlen) with batch_first -- as the reference's\n"
+             "Tokenizer.batch_tokenize (src/tokenize.cpp:82-98, tokenize.h:381-485); device= keeps the result on the GPU.\n\n"
+             "nthreads: in the reference the OpenMP team of the encode loop; here the encode runs on the GPU and the value governs the\n"
+             "host scan + pack only.  nthreads > 1 is honoured as given.  The signature default 1 CANNOT be told from an explicit 1:\n"
+             "both defer to the module policy -- set_host_threads(n) / BSQ_HOST_THREADS, where 0 (the initial value) means one thread\n"
+             "below 8192 items and up to 16 above.  A caller that needs a strictly serial host path whatever the batch size\n"
+             "(DataLoader workers, cgroup-limited jobs) calls set_host_threads(1) once.")
         .def("batch_onehot_encode", &Tokenizer::batch_onehot_encode, py::arg("batch"), py::arg("padlen") = -1,
              py::arg("destchar") = "B", py::arg("nthreads") = 1, py::arg("mask") = py::none(), py::kw_only(),
-             py::arg("device") = py::none(), py::arg("layout") = "tbc")
+             py::arg("device") = py::none(), py::arg("layout") = "tbc",
+             "One-hot tensor (padlen, B, C) of a list of sequences, as the reference's Tokenizer.batch_onehot_encode\n"
+             "(src/tokenize.cpp:65-81, tokenize.h:283-371); device= keeps the result on the GPU, layout='bcl' writes (B, C, padlen).\n\n"
+             "nthreads: the host scan + pack only (the encode runs on the GPU).  nthreads > 1 is honoured as given; the signature\n"
+             "default 1 cannot be told from an explicit 1 and defers to the module policy (set_host_threads / BSQ_HOST_THREADS; 0 =\n"
+             "one thread below 8192 items, up to 16 above).  For a strictly serial host path call set_host_threads(1).")
         .def("tokenize_packed",
              [](const Tokenizer &t, const py::object &chars, const py::object &offsets, py::ssize_t padlen,
                 const std::string &dt, bool batch_first, const py::object &device, bool validate) {

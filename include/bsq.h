@@ -154,6 +154,9 @@ bsq_status bsq_tokenize_device_multi(const bsq_desc *d, int32_t n, const bsq_bat
                                      bsq_dtype t, void *hip_stream);
 /* Name of the kernel(s) bsq_onehot_device would launch for this shape (profiling / bench labels). */
 const char *bsq_onehot_kernel_name(const bsq_desc *d, int64_t B, int64_t P, bsq_dtype t);
+/* The same for bsq_tokenize_device (augment = 0) and bsq_augment_tokenize_device (augment = its chain_len > 0), for a 16-byte aligned
+ * contiguous output: which token kernel, and for the fused augmentation which of its two one-launch forms. */
+const char *bsq_tokenize_kernel_name(const bsq_desc *d, int64_t B, int64_t P, int32_t batch_first, bsq_dtype t, int32_t augment);
 /* Same results through the simple one-thread-per-element kernels (any shape/alignment/alphabet).
  * Used as the in-library cross-check of the tiled kernels and as their fallback. */
 bsq_status bsq_tokenize_device_generic(const bsq_desc *d, const uint8_t *chars, const int64_t *offsets,

@@ -62,6 +62,14 @@ def test_host_only_abi_calls(alphabets_golden):
     # (28-byte rows: ids as nibbles, round 5)
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("DNA4", 1, 1, 1)), 1000000, 160, capi.F32) == b"k_tokens_pb8_fast<raw, nibbles>+k_expand_chunks<nibbles>"
     assert lib.bsq_onehot_kernel_name(ctypes.byref(capi.make_desc("BYTES", 1, 1, 1)), 1000, 160, capi.I16) == b"k_onehot_generic"
+    # the token entry points' dispatch, from the library itself (bench.py labels its lines with it)
+    tk = lambda key, flags, B, P, bf, t, aug: lib.bsq_tokenize_kernel_name(ctypes.byref(capi.make_desc(key, *flags)), B, P, bf, t, aug)
+    assert tk("AMINO20", (0, 0, 0), 65536, 1024, 1, capi.I8, 0) == b"k_tokens_bp8_fast" and tk("AMINO20", (0, 0, 0), 65536, 1024, 0, capi.I8, 0) == b"k_tokens_pb8_fast"
+    assert tk("SEB8", (0, 0, 0), 262144, 512, 1, capi.I8, 1) == b"k_augment_tokens_fused(k_augment_groups -> k_tokens_bp8_fast)"      # 32 768 chunks: the flag form
+    assert tk("SEB8", (0, 0, 0), 131072, 512, 1, capi.I8, 1) == b"k_augment_tokens_nowait(k_augment_groups || k_tokens_bp8_fast)+k_patch_tokens"  # 16 384 chunks
+    assert tk("SEB8", (0, 0, 0), 131073, 512, 1, capi.I8, 1).startswith(b"k_augment_tokens_fused")
+    assert tk("SEB8", (0, 0, 0), 4096, 500, 1, capi.I8, 1) == b"k_augment_groups+k_tokens_bp8" and tk("SEB8", (0, 0, 0), 4096, 100, 1, capi.I8, 0) == b"k_tokenize_chunks"
+    assert tk("BYTES", (1, 1, 1), 1000, 160, 1, capi.I8, 0) == b"k_tokenize_generic"
 
 
 def test_compute_entry_points_refuse_without_a_device():
