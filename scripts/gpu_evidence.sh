@@ -8,7 +8,9 @@
 #                                                       --pmc FETCH_SIZE passes of `bench.py --workload W --no-configs`, condensed by
 #                                                       summarize_prof.py -> gpurun_out/<TAG>_<W>/summary.{txt,json}
 #   scripts/gpu_evidence.sh sq [workloads...]           SQ / TCC counter passes -> gpurun_out/<TAG>_sq_<W>/summary.txt
-#   scripts/gpu_evidence.sh all                         tests, fuzz 300, bench, profile + sq of every workload
+#   scripts/gpu_evidence.sh dispatch                    scripts/check_dispatch.py over scripts/dispatch_shapes.json (the automatic one-hot path against every
+#                                                       forced path, 5 % gate) -> gpurun_out/<TAG>/dispatch_check.txt
+#   scripts/gpu_evidence.sh all                         tests, fuzz 300, bench, dispatch, profile + sq of every workload
 #
 # TAG (environment, default r04) names the output directories.  Back in the build container:
 #   python scripts/make_traffic.py <TAG>   copies the summaries into profiles/<TAG>/ and rebuilds profiles/traffic.json.
@@ -97,12 +99,14 @@ PY
     echo "sq $w: $(wc -l < "$P/summary.txt") lines"
   done
 }
+do_dispatch() { ( cd "$REPO" && timeout 1500 python3 scripts/check_dispatch.py --json "$OUT/dispatch_check.json" ) > "$OUT/dispatch_check.txt" 2>> "$OUT/dispatch_check.err"; grep -E "^#|^FAIL" "$OUT/dispatch_check.txt"; }
 case "$MODE" in
+  dispatch) do_dispatch ;;
   tests) do_tests "$@" ;;
   fuzz) do_fuzz "$@" ;;
   bench) do_bench ;;
   profile) do_profile ${@:-$ALL} ;;
   sq) do_sq ${@:-cfg2 cfg2sf cfg3b cfg5 cfg5aug cfg4b} ;;
-  all) do_tests; do_fuzz 300; do_bench; do_profile $ALL; do_sq cfg2 cfg2sf cfg3b cfg5 cfg5aug cfg4b ;;
+  all) do_tests; do_fuzz 300; do_bench; do_dispatch; do_profile $ALL; do_sq cfg2 cfg2sf cfg3b cfg5 cfg5aug cfg4b ;;
   *) echo "unknown mode $MODE"; exit 2 ;;
 esac
