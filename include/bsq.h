@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BSQ_ABI_VERSION 6
+#define BSQ_ABI_VERSION 7 /* 7 (round 6): bsq_tokenize_device_multi, bsq_augment_device_multi, bsq_augment_tokenize_device_multi, bsq_enable_peer_access, bsq_tokenize_kernel_name; nothing removed */
 
 typedef int32_t bsq_status;
 enum {

@@ -46,7 +46,7 @@ for w in sys.argv[2:]:
         w, r["kernel_avg_ms"], r["frac"], s.get("kernel_avg_ms", 0), s.get("frac", 0),
         ("%.4f ms frac %.3f (sustained %.3f, of_mix %.3f)" % (c["ms_per_step"], c["frac"], c["frac_sustained"], c.get("frac_of_copy_mix") or 0)) if c else "-",
         r["frac_of_fill"], r["frac_of_copy_mix"] and round(r["frac_of_copy_mix"], 3), j["check"].get("ok")))
-d = json.loads(open(out + "/bench_default.json").read().strip().splitlines()[-1])
+d = json.load(open(out + "/bench_default.json"))  # (bench_full.json: the whole object, indented)
 print("driver line: cfg3 ms/step %.4f frac %.3f; configs:" % (d["ms_per_step"], d["roofline"]["frac"]))
 for w, c in (d.get("configs") or {}).items():
     print("   %-8s %.4f ms frac %.3f sustained %.3f cold %s check %s (%.1f s)" % (w, c["ms_per_step"], c["frac"], c["frac_sustained"],

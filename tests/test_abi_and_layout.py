@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25 and "bsq_onehot_device" in names and "bsq_tokenize_host" in names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.bsq_abi_version() == 6
+    assert lib.bsq_abi_version() == 7
     product = capi.declared_symbols(capi.HEADER_PATH)  # the drop-in surface holds no knobs / yardsticks / probes
     assert not [n for n in product if 'tuning' in n or 'fill' in n or 'selftest' in n or 'xcd' in n]
 
