@@ -31,7 +31,7 @@ except ImportError as _e:  # fail loudly: the HIP extension IS the product
 
 from .cbioseq import Threading, Tokenizer, get_host_threads, get_num_threads, set_host_threads, set_num_threads  # noqa: F401
 from . import synth  # noqa: F401
-from . import blosum, sharding  # noqa: F401
+from . import blosum, multi, sharding  # noqa: F401
 from .flatfile import FlatFile, FlatFileIterator, getstats  # noqa: F401  (bioseq.FlatFile / getstats, /root/reference/src/fxstats.cpp:166-219)
 
 __version__ = "0.1.0"
@@ -170,4 +170,4 @@ __all__ = ["onehot_encode", "cbioseq", "f_encode", "Tokenizer", "make_embedding"
            "pos_tokenizers", "default_tokenizers", "total_tokenizer_dict", "get_tokenizer_dict", "DNATokenizer",
            "AmineTokenizer", "Reduced6Tokenizer", "Reduced8Tokenizer", "Reduced10Tokenizer", "Reduced14Tokenizer",
            "DayhoffTokenizer", "LIATokenizer", "LIBTokenizer", "torchify", "set_num_threads", "get_num_threads",
-           "Threading", "device_count", "synth", "blosum", "sharding", "FlatFile", "FlatFileIterator", "getstats", "loaders", "set_host_threads", "get_host_threads"]
+           "Threading", "device_count", "synth", "blosum", "multi", "sharding", "FlatFile", "FlatFileIterator", "getstats", "loaders", "set_host_threads", "get_host_threads"]

@@ -1270,6 +1270,16 @@ struct Threading {
 
 }  // namespace
 
+// "Host packs once; GPU g receives its slice" (sharding.encode_on_devices): ONE scan of the list under the GIL -- pointer + length
+// of every item, the offsets, the first item that is too long -- kept alive (it holds the list's items) while the caller packs RANGES of it
+// into memory it allocated once the total was known: device g's slice is packed and sent on its way while device g + 1's is being packed.
+struct ListScan {
+    Gathered g;
+    py::array_t<int64_t> offsets;
+    int64_t n = 0, bad = -1;
+    int nthreads = 1;
+};
+
 PYBIND11_MODULE(cbioseq, m) {
     m.doc() = "bioseq_amd.cbioseq: MI355X-native drop-in for the reference's cbioseq tokenizer module";
     m.attr("abi_version") = bsq_abi_version();
@@ -1346,6 +1356,42 @@ PYBIND11_MODULE(cbioseq, m) {
         pack_range(g, p, 0, sc.n, nthreads);
         return py::make_tuple(offsets, buf, bad);
     }, py::arg("batch"), py::arg("maxlen"), py::arg("nthreads"), py::arg("alloc"));
+    py::class_<ListScan>(m, "_ListScan")
+        .def(py::init([](py::sequence batch, int64_t maxlen, int nthreads) {
+                 auto sc = std::make_unique<ListScan>();
+                 const Scan scan = scan_begin(batch, py::none(), sc->g, nthreads);
+                 scan_range(scan, sc->g, 0, scan.n, nthreads);
+                 sc->n = scan.n;
+                 sc->nthreads = nthreads;
+                 sc->offsets = py::array_t<int64_t>(scan.n + 1);
+                 int64_t *o = sc->offsets.mutable_data();
+                 int64_t acc = 0;
+                 o[0] = 0;
+                 for (Py_ssize_t i = 0; i < scan.n; ++i) {
+                     const int64_t len = int64_t(sc->g.items[size_t(i)].len);
+                     if (len > maxlen && sc->bad < 0) sc->bad = i;
+                     acc += len;
+                     o[i + 1] = acc;
+                 }
+                 return sc;
+             }),
+             py::arg("batch"), py::arg("maxlen"), py::arg("nthreads") = 0)
+        .def_readonly("offsets", &ListScan::offsets)
+        .def_readonly("bad", &ListScan::bad)
+        .def_readonly("n", &ListScan::n)
+        .def("pack", [](ListScan &sc, int64_t lo, int64_t hi, py::buffer dst) {
+            // items [lo, hi) -> dst[offsets[lo] : offsets[hi]] (dst = the whole batch's buffer: writable, contiguous bytes)
+            if (lo < 0 || hi < lo || hi > sc.n) throw py::index_error("_ListScan.pack: range outside the list");
+            py::buffer_info info = dst.request(true);
+            const int64_t *o = sc.offsets.data();
+            if (info.itemsize != 1 || info.ndim != 1 || int64_t(info.shape[0]) < o[hi] || (info.strides[0] != 1 && info.shape[0] > 1))
+                throw std::invalid_argument("_ListScan.pack: dst must be a writable, contiguous buffer of at least offsets[hi] bytes");
+            Packed p;
+            p.B = sc.n;
+            p.offsets = const_cast<int64_t *>(o);
+            p.chars = static_cast<uint8_t *>(info.ptr);
+            pack_range(sc.g, p, lo, hi, sc.nthreads);
+        }, py::arg("lo"), py::arg("hi"), py::arg("dst"));
     m.def("alphabet_keys", [] {
         std::vector<std::string> k;
         for (int i = 0; i < bsq_num_keys(); ++i) k.emplace_back(bsq_key_name(i));

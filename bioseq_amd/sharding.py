@@ -527,12 +527,38 @@ class _DeviceSlot:
 _slots = {}
 
 
+class _PinnedRing:
+    """Pinned host buffers of `encode_on_devices`, kept between calls (a fresh 35-MB hipHostMalloc per call costs ~0.4 ms): two of each kind
+    take turns, and a buffer is reused only after the uploads that last read it have completed (events; normally long past)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, kind, nbytes, dtype):
+        import torch
+        turn = self.bufs.setdefault(kind, {"i": 0, "slots": [None, None]})
+        turn["i"] ^= 1
+        slot = turn["slots"][turn["i"]]
+        item = torch.empty(0, dtype=dtype).element_size()
+        if slot is None or slot["t"].numel() * item < nbytes:
+            cap = max(int(nbytes * 1.25) + 4096, 1 << 16)
+            slot = turn["slots"][turn["i"]] = {"t": torch.empty((cap + item - 1) // item, dtype=dtype, pin_memory=True), "events": []}
+        for ev in slot["events"]:
+            ev.synchronize()
+        slot["events"] = []
+        return slot["t"], slot["events"]
+
+
+_pinned = _PinnedRing()
+
+
 def encode_on_devices(tokenizer, batch, padlen: int, destchar: str = "B", devices=None, op: str = "onehot", batch_first: bool = False,
                       layout: str = "tbc", root=None, nthreads: int = 0):
-    """Sharded encode from ONE process: the host packs `batch` once (`pack_once`: one scan under the GIL, one pack into pinned
-    memory); device g of `devices` gets sequences `shard_bounds(B, len(devices), g)` -- its slice of the characters and its rebased
-    offsets uploaded on ITS copy stream, encoded on ITS encode stream by the ordinary kernels -- with all devices in flight together
-    (N PCIe links, N GPUs); no collective, nothing synchronises.
+    """Sharded encode from ONE process: the host scans `batch` once under the GIL (`cbioseq._ListScan`: pointer + length of every item, the
+    offsets) and packs it once into pinned memory, slice by slice; device g of `devices` gets sequences `shard_bounds(B, len(devices), g)` --
+    its slice of the characters and its rebased offsets uploaded on ITS copy stream as soon as that slice is packed (while the next device's
+    is being packed), encoded on ITS encode stream by the ordinary kernels -- with all devices in flight together (N PCIe links, N GPUs);
+    no collective, nothing synchronises.
 
     op 'tokenize' (batch_first as in `batch_tokenize`) or 'onehot' (layout 'tbc' = the reference's (padlen, B, C), or 'bcl' = (B, C, padlen)).
     devices: list of devices; an entry may repeat (`['cuda:0', 'cuda:0']`: two stream pairs of one GPU -- how this pool tests it).
@@ -552,7 +578,20 @@ def encode_on_devices(tokenizer, batch, padlen: int, destchar: str = "B", device
     if not devs or any(d.type != "cuda" for d in devs):
         raise ValueError("encode_on_devices needs a non-empty list of HIP devices")
     devs = [torch.device("cuda", torch.cuda.current_device() if d.index is None else d.index) for d in devs]
-    chars, offsets = pack_once(tokenizer, batch, padlen, nthreads, onehot=(op == "onehot"))
+    scan = None
+    if isinstance(batch, tuple) and len(batch) == 2 and not isinstance(batch[0], (str, bytes, bytearray)):
+        chars, offsets = pack_once(tokenizer, batch, padlen, nthreads, onehot=(op == "onehot"))  # already packed: pinned as it is / after one copy
+    else:
+        # ONE scan under the GIL (pointer + length of every item, the offsets); the bytes are packed into pinned memory SLICE BY SLICE below,
+        # device g's slice on its way over PCIe while device g + 1's is being packed
+        from . import cbioseq
+        room = int(padlen) - int(tokenizer.includes_bos()) - int(tokenizer.includes_eos())
+        scan = cbioseq._ListScan(batch, max(room, 0), int(nthreads))
+        offsets = torch.from_numpy(scan.offsets)
+        if scan.bad >= 0:
+            _raise_too_long(tokenizer, int(offsets[scan.bad + 1] - offsets[scan.bad]), padlen, op == "onehot")
+        chars, chars_events = _pinned.get("chars", int(offsets[-1]) + 16, torch.uint8)
+        chars_np = chars.numpy()
     B = int(offsets.shape[0]) - 1
     G = len(devs)
     lib = capi.load()
@@ -570,7 +609,7 @@ def encode_on_devices(tokenizer, batch, padlen: int, destchar: str = "B", device
 
     # every device's rebased offsets in ONE pinned buffer (device g: entries [b0 + g, b1 + g + 1))
     bounds = [shard_bounds(B, G, g) for g in range(G)]
-    reb = torch.empty(B + G, dtype=torch.int64, pin_memory=True)
+    reb, reb_events = _pinned.get("offsets", (B + G) * 8, torch.int64)
     o_np, r_np = offsets.numpy(), reb.numpy()
     for g, (b0, b1) in enumerate(bounds):
         np.subtract(o_np[b0:b1 + 1], o_np[b0], out=r_np[b0 + g:b1 + g + 1])
@@ -594,12 +633,19 @@ def encode_on_devices(tokenizer, batch, padlen: int, destchar: str = "B", device
         if slot is None:
             slot = _slots[(g, dev.index)] = _DeviceSlot(dev)
         slots.append(slot)
+        if scan is not None and nb > 0:
+            scan.pack(b0, b1, chars_np)  # this device's characters (the pool's threads copy; the GIL stays held: the items must not change)
         with torch.cuda.device(dev):
             with torch.cuda.stream(slot.copy):
                 # (+16 spare bytes ride along when the buffer has them: the kernels' unaligned 16-byte loads stay inside the allocation)
                 d_chars = chars[c0:min(c1 + 16, chars.numel())].to(dev, non_blocking=True)
                 d_offs = reb[b0 + g:b1 + g + 1].to(dev, non_blocking=True)
                 slot.uploaded.record(slot.copy)
+                done = torch.cuda.Event()
+                done.record(slot.copy)  # (a per-call event: the pinned buffers may be refilled once these copies have completed)
+                reb_events.append(done)
+                if scan is not None:
+                    chars_events.append(done)
             with torch.cuda.stream(slot.encode):
                 slot.encode.wait_event(slot.uploaded)
                 d_chars.record_stream(slot.encode), d_offs.record_stream(slot.encode)

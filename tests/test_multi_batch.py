@@ -223,3 +223,41 @@ def test_augment_multi_equals_single_calls(gpu):
     for dof, c1, c2 in keep:
         assert torch.equal(c1, c2)
     assert lib.bsq_augment_device_multi(2, arr, 1, 0.5, None, None) == capi.ERR_INVALID_ARG
+
+
+def test_python_surface_of_the_multi_batch_calls(gpu, bsq, oracle):
+    """bioseq_amd.multi.tokenize_packed_multi / augment_tokenize_packed_multi == the per-batch Python calls (and the oracle), on the caller's
+    current stream; outs=; the reference's error for an over-long sequence."""
+    import torch
+    from bioseq_amd import blosum, multi
+    tok, ora = bsq.Tokenizer("SEB8", 0, 1, 1), oracle.OracleTokenizer("SEB8", 0, 1, 1)
+    P = 256
+    host = [_batch(1300 + i, b, 1, P - 2) for i, b in enumerate([640, 64, 2048, 128, 960])]
+    dev = [(torch.from_numpy(np.concatenate([c, np.full(16, 0x41, np.uint8)])).to(gpu)[:len(c)], torch.from_numpy(o).to(gpu)) for c, o in host]
+    side = torch.cuda.Stream(device=gpu)
+    for bf in (True, False):
+        with torch.cuda.stream(side):
+            got = multi.tokenize_packed_multi(tok, dev, P, "B", bf)
+        side.synchronize()
+        for (c, o), g in zip(host, got):
+            assert g.cpu().numpy().tobytes() == ora.tokenize_packed(c, o, P, "B", bf).tobytes()
+    outs = [torch.full((len(o) - 1, P), 9, dtype=torch.int8, device=gpu) for _, o in host]
+    got = multi.tokenize_packed_multi(tok, dev, P, "b", True, outs=outs)
+    assert all(a is b for a, b in zip(got, outs))
+    # augmentation: the same seeds through the one-batch entry
+    a1 = [(c.clone(), o) for c, o in dev]
+    a2 = [(c.clone(), o) for c, o in dev]
+    seeds = [11, 22, 33, 44, 55]
+    want = [blosum.augment_tokenize_packed(tok, c, o, P, "b", True, chain_len=2, augment_frac=0.7, seed=s) for (c, o), s in zip(a1, seeds)]
+    got = multi.augment_tokenize_packed_multi(tok, a2, P, "b", True, chain_len=2, augment_frac=0.7, seeds=seeds)
+    torch.cuda.synchronize()
+    for (c1, _), (c2, _), w, g in zip(a1, a2, want, got):
+        assert torch.equal(c1, c2) and torch.equal(w, g)
+    blosum.check_fused()
+    bad_o = host[1][1].copy()
+    bad_o[-1] += 0  # (lengths as they are) ...
+    long_c = np.concatenate([host[1][0], np.full(300, 0x41, np.uint8)])
+    long_o = host[1][1].copy()
+    long_o[-1] += 300   # ... and one sequence that no longer fits
+    with pytest.raises(RuntimeError, match="seq len \\+ bos \\+ eos > padlen"):
+        multi.tokenize_packed_multi(tok, [dev[0], (torch.from_numpy(long_c).to(gpu), torch.from_numpy(long_o).to(gpu))], P, "B", True)
