@@ -98,6 +98,62 @@ def run(budget=120.0, seed=1):
                 t1 = tok.tokenize_packed(a1, dof, P, d, bf, validate=False)
                 t2 = blosum.augment_tokenize_packed(tok, a2, dof, P, d, bf, chain_len=cl, augment_frac=fr, seed=sd)
                 assert torch.equal(a1, a2) and u64(t1.cpu().numpy()).tobytes() == u64(t2.cpu().numpy()).tobytes(), ("augment+tokenize", cl, fr, bf)
+            if d in "bh" and rng.random() < 0.3:  # round 6: the batch cut into 1 ... 10 pieces, all of them in ONE multi-batch call (multi kernels
+                from bioseq_amd import multi            # where every piece qualifies, single launches otherwise; empty pieces allowed)
+                cuts = sorted([0, B] + [int(x) for x in rng.integers(0, B + 1, int(rng.integers(0, 10)))])
+                if rng.random() < 0.5:  # multiples of 64 sequences: what the (P,B) multi kernel takes
+                    cuts = sorted(set([0, B] + [c // 64 * 64 for c in cuts]))
+                parts = [(dch[int(offs[b0]):int(offs[b1])] if offs[b1] > offs[b0] else dch[:0], (dof[b0:b1 + 1] - dof[b0]).contiguous())
+                         for b0, b1 in zip(cuts[:-1], cuts[1:])]
+                got = multi.tokenize_packed_multi(tok, parts, P, d, bf)
+                whole = ora.tokenize_packed(chars, offs, P, d, bf)
+                for (b0, b1), g in zip(zip(cuts[:-1], cuts[1:]), got):
+                    w = whole[b0:b1] if bf else whole[:, b0:b1]
+                    assert g.cpu().numpy().tobytes() == np.ascontiguousarray(w).tobytes(), ("multi tokens", bf, cuts, b0, b1)
+                if d == "b" and bf and rng.random() < 0.5:  # ... and with augmentation: == the per-piece calls with the same seeds
+                    from bioseq_amd import blosum
+                    seeds = [int(x) for x in rng.integers(1 << 30, size=len(parts))]
+                    p1 = [(c.clone(), o) for c, o in parts]
+                    p2 = [(c.clone(), o) for c, o in parts]
+                    want = [blosum.augment_tokenize_packed(tok, c, o, P, "b", True, chain_len=1, augment_frac=0.5, seed=sd_) if o.numel() > 1 else None
+                            for (c, o), sd_ in zip(p1, seeds)]
+                    got = multi.augment_tokenize_packed_multi(tok, p2, P, "b", True, chain_len=1, augment_frac=0.5, seeds=seeds, validate=False)
+                    for (c1, _), (c2, _), w, g in zip(p1, p2, want, got):
+                        assert torch.equal(c1, c2) and (w is None or torch.equal(w, g)), ("multi augment + tokens", cuts)
+            if rng.random() < 0.15:  # round 6: index batches of every size class of the gather (one launch <= 4096, two beyond, three under the knob)
+                nidx = int(rng.choice([1, 100, 4096, 4097, 9000, 20000, 66000]))
+                idx = rng.integers(0, B, size=nidx).astype(np.int64)
+                capi.check(lib.bsq_tuning_set(b"gather_small", int(rng.choice([0, 0, 1]))))
+                lens_ = np.diff(offs)
+                woffs = np.concatenate([[0], np.cumsum(lens_[idx])]).astype(np.int64)
+                cap = int(woffs[-1])
+                oc = torch.full((cap + 64,), 0xEE, dtype=torch.uint8, device=dev)
+                oo = torch.empty(nidx + 1, dtype=torch.int64, device=dev)
+                stt = torch.empty(1, dtype=torch.int64, device=dev)
+                capi.check(lib.bsq_gather_packed_device(dch.data_ptr(), dof.data_ptr(), B, torch.from_numpy(idx).to(dev).data_ptr(), nidx, oc.data_ptr(), cap,
+                                                        oo.data_ptr(), stt.data_ptr(), None))
+                capi.check(lib.bsq_tuning_set(b"gather_small", 0))
+                assert int(stt.item()) == -1 and (oo.cpu().numpy() == woffs).all(), ("gather offsets", nidx)
+                pos = np.repeat(offs[:-1][idx] - woffs[:-1], lens_[idx]) + np.arange(cap)
+                hc = oc.cpu().numpy()
+                assert (hc[:cap] == chars[pos]).all() and (hc[cap:] == 0xEE).all(), ("gather characters", nidx)
+            if B <= 20001 and rng.random() < 0.12:  # round 6: ONE process, several device entries (stream pairs of this GPU): shards and a root tensor
+                from bioseq_amd import sharding
+                seqs = synth.unpack(chars, offs)
+                G = int(rng.integers(1, 6))
+                devs = ["cuda:0"] * G
+                op = "tokenize" if rng.random() < 0.5 else "onehot"
+                lay = "bcl" if rng.random() < 0.5 else "tbc"
+                e0 = e if mask is None else ora.onehot_packed(chars, offs, P, d)  # (no mask on this path)
+                want = ora.tokenize_packed(chars, offs, P, d, bf) if op == "tokenize" else (np.ascontiguousarray(e0.transpose(1, 2, 0)) if lay == "bcl" else e0)
+                full = sharding.encode_on_devices(tok, seqs, P, d, devices=devs, op=op, batch_first=bf, layout=lay, root="cuda:0")
+                torch.cuda.synchronize()
+                assert u64(full.cpu().numpy()).tobytes() == want.tobytes(), ("encode_on_devices root", op, lay, bf, G)
+                shards = sharding.encode_on_devices(tok, seqs, P, d, devices=devs, op=op, batch_first=bf, layout=lay)
+                torch.cuda.synchronize()
+                ax = (0 if bf else 1) if op == "tokenize" else (0 if lay == "bcl" else 1)
+                cat = np.concatenate([u64(x.cpu().numpy()) for x in shards], axis=ax)
+                assert np.ascontiguousarray(cat).tobytes() == want.tobytes(), ("encode_on_devices shards", op, lay, bf, G)
             if B * P < 400_000:  # host entry points (list of bytes -> numpy)
                 seqs = synth.unpack(chars, offs)
                 ml = None if mask is None else [mask[offs[i]:offs[i + 1]].copy() for i in range(B)]
@@ -126,7 +182,7 @@ def run(budget=120.0, seed=1):
         n += 1
     torch.cuda.synchronize()
     capi.check(lib.bsq_fused_status(None))  # no token wave of a fused augmentation launch gave up waiting
-    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"augment_fused", b"bcl_path", b"tokenize_tb", b"host_pieces", b"expand_rows1", b"raw_nibbles", b"two_pass_slice_mb"):
+    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"augment_fused", b"bcl_path", b"tokenize_tb", b"host_pieces", b"expand_rows1", b"raw_nibbles", b"two_pass_slice_mb", b"gather_small"):
         capi.check(lib.bsq_tuning_set(name, 0))
     return n
 
