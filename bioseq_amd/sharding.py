@@ -550,6 +550,7 @@ class _PinnedRing:
 
 
 _pinned = _PinnedRing()
+_encode_lock = None  # serialises the ISSUE phase of encode_on_devices between Python threads (stream pairs and pinned buffers are shared)
 
 
 def encode_on_devices(tokenizer, batch, padlen: int, destchar: str = "B", devices=None, op: str = "onehot", batch_first: bool = False,
@@ -565,6 +566,19 @@ def encode_on_devices(tokenizer, batch, padlen: int, destchar: str = "B", device
     Returns the list of per-device shards (what `nn.parallel.parallel_apply` consumes), each safe to use on its device's current stream.
     root = a device: the whole-batch tensor is allocated THERE and every device stores its shard straight into it (column blocks through
     `bsq_onehot_block_device` / `bsq_tokenize_block_device`, row slabs for batch-first layouts) over peer access; returns that one tensor."""
+    import threading
+    global _encode_lock
+    if op not in ("tokenize", "onehot"):
+        raise ValueError("op must be 'tokenize' or 'onehot'")
+    if op == "onehot" and layout not in ("tbc", "bcl"):
+        raise ValueError("layout must be 'tbc' or 'bcl'")
+    if _encode_lock is None:
+        _encode_lock = threading.Lock()
+    with _encode_lock:  # (the call only ENQUEUES work: held for about a millisecond)
+        return _encode_on_devices(tokenizer, batch, padlen, destchar, devices, op, batch_first, layout, root, nthreads)
+
+
+def _encode_on_devices(tokenizer, batch, padlen, destchar, devices, op, batch_first, layout, root, nthreads):
     import ctypes
 
     import torch

@@ -143,7 +143,8 @@ bsq_status bsq_tokenize_block_device(const bsq_desc *d, const uint8_t *chars, co
  * own characters, offsets and output matrix ((B_i, P) or (P, B_i), contiguous) -- with results identical to n calls of
  * bsq_tokenize_device on the same stream, in ceil(n / 8) launches when every batch qualifies for the fast kernel of its layout
  * (int8 (B,P) with padlen % 16 == 0 and >= 128; 1- / 2-byte (P,B) with 64-byte aligned rows; ids < 251), and as n launches otherwise.
- * Batches with B == 0 are skipped.  n < 0 or a null table: BSQ_ERR_INVALID_ARG. */
+ * Batches with B == 0 are skipped.  n < 0 or a null table: BSQ_ERR_INVALID_ARG.  The batches' buffers must not overlap one another
+ * (they are independent: nothing orders one batch's stores against another's loads inside the launch). */
 typedef struct bsq_batch {
     const uint8_t *chars;   /* device: packed characters of this batch */
     const int64_t *offsets; /* device: B + 1 offsets into chars */
