@@ -55,6 +55,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
 //                         k_expand_rows1<nibbles> for one-byte rows): 0 automatic (rows of 24 ... 31 bytes, id matrices beyond 128 MB, every one-byte row), 1 never, 2 whenever they apply
 //   two_pass_slice_mb     the two-pass one-hot in SLICES of position rows whose id scratch stays cache-resident: 0 automatic (slices of <= 96 MB once the
 //                         id matrix exceeds 128 MB), > 0 that many MB per slice (whatever the size), < 0 never
+//   tokens_pb8_pair       k_tokens_pb8_fast: the last position tile of a matrix whose padlen % 64 is 1 ... 32 shared by two sequence tiles (0 automatic, 1 never)
 //   expand_rows1          the LDS-free expansion k_expand_rows1 (one-byte elements, rows of 3 ... 15 bytes): 0 automatic, 1 never, 2 whenever it applies
 //   gather_small          bsq_gather_packed_device: 0 one launch up to 4096 indices (k_gather_small), two beyond (k_gather_lengths2 + k_gather_place); 1 the three launches of rounds 2-5
 //   host_pieces           list / host batch -> seq-first one-hot on the device: upload + encode in pieces (0 automatic: 4 pieces when the
@@ -69,7 +70,7 @@ bsq_status set_hip_error(const char *what, hipError_t e);
     X(nt_stores, 1) X(onehot_tb, 0) X(tile_order, 0) X(fill_mode, 0) X(onehot_path, 0) X(expand_pad, 0) X(tokenize_path, 0)   \
     X(fill_pad, 0) X(chunks_pad, 0) X(host_copy_threads, 0) X(tokenize_pad, 0) X(expand_slots, 0) X(tile_group, 0)             \
     X(bcl_path, 0) X(bcl_pad, 0) X(raw_mode, 0) X(workspace_cache, 0) X(tokens8, 0) X(tokens8_fast, 0) X(tokens8_lookup, 0)    \
-    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0) X(expand_gate, 0) X(host_pieces, 0) X(gather_small, 0) X(expand_rows1, 0) X(raw_nibbles, 0) X(two_pass_slice_mb, 0)
+    X(tokens8_pad, 0) X(pattern_wait, 0) X(tokenize_tb, 0) X(wide_index, 0) X(augment_k, 0) X(tokens_pb8, 0) X(augment_fused, 0) X(fused_spins, 0) X(expand_gate, 0) X(host_pieces, 0) X(gather_small, 0) X(expand_rows1, 0) X(raw_nibbles, 0) X(two_pass_slice_mb, 0) X(tokens_pb8_pair, 0)
 struct Tuning {
 #define BSQ_KNOB_FIELD(name, def) int32_t name = def;
     BSQ_KNOB_LIST(BSQ_KNOB_FIELD)

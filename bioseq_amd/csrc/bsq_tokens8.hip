@@ -852,16 +852,28 @@ __device__ __forceinline__ void tokens_pb8_body(const uint32_t vblock, const int
         if (tt >= ntt) return;
     }
     if (tb >= ntb) return;
+    // PAIRED TAIL (round 6; packed bit 3, aligned class-pinned form only): the matrix's last position tile holds at most 32 positions (padlen 160 =
+    // 2.5 tiles: BASELINE config 4), so half of the tile's pieces -- and of its lookups, transposes and LDS traffic -- would belong to positions that
+    // do not exist; the kernel is bound by vector issue (569 vector instructions per wave at ~90 % VALU activity: profiles/r06/cfg4b_sq_tcc_counters.txt).
+    // The tail tile of sequence tile tb (group quo even) takes the tail of tb + 8 as well (the same chunk class = the same XCD): lanes whose piece
+    // would be 2 or 3 work on pieces 0 / 1 of the PARTNER's sequences, the partner's own tail workgroup returns at once.
+    const bool tail_pair = (packed & 8u) != 0u && (tt + tt0) == (P - 1u) / TT;  // wave-uniform
+    // the LATER workgroup of the two (odd group) does both tails: its partner's lines were fetched by the partner's other tiles just before
+    const bool later = (quo & 1u) != 0u;
+    if (tail_pair && !later && tb + 8u < ntb) return;
     const uint32_t bos = packed & 1u, none_v = (packed & 2u) ? 0xFFu : 0u;
     const uint32_t bos_id = (packed >> 8) & 0xFFu;
     const int32_t t0 = static_cast<int32_t>(tt + tt0) * TT;
     const int la = (lane >> 2) & 3, lb = lane & 3;
+    const int pc = (la & 1) ? 3 - lb : lb;  // the lane's piece: reversed in odd a, so that row_half_mirror pairs a with a ^ 1 on the SAME piece
+    const uint32_t second = (tail_pair && pc >= 2) ? 1u : 0u;  // this lane works for the partner tile
+    const uint32_t tbl = later ? tb - 8u * second : tb + 8u * second;  // (an even group without a partner: tb + 8 >= ntb, those lanes find no sequences)
 
     // ---- the spans first (the four lanes of a sequence read the same two words) ----
     int64_t o0[PASSES], o1[PASSES];
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-        const uint32_t b = tb * TB + ps * 64 + (tid >> 2);  // the lane's sequence of this pass
+        const uint32_t b = tbl * TB + ps * 64 + (tid >> 2);  // the lane's sequence of this pass
         o0[ps] = offsets[b < B ? b : B];
         o1[ps] = offsets[b + 1 < B ? b + 1 : B];
     }
@@ -884,8 +896,7 @@ __device__ __forceinline__ void tokens_pb8_body(const uint32_t vblock, const int
     __syncthreads();
 
     // ---- the characters: the piece of every pass in flight together ----
-    const int pc = (la & 1) ? 3 - lb : lb;  // the lane's piece: reversed in odd a, so that row_half_mirror pairs a with a ^ 1 on the SAME piece
-    const int32_t j0 = t0 + 16 * pc - static_cast<int32_t>(bos);  // character index of the piece's first byte (>= -1)
+    const int32_t j0 = t0 + 16 * (pc - 2 * static_cast<int>(second)) - static_cast<int32_t>(bos);  // character index of the piece's first byte (>= -1)
     u32x4u cw[PASSES];
     int32_t Lr[PASSES];
     bool slow_any = false;
@@ -979,8 +990,9 @@ __device__ __forceinline__ void tokens_pb8_body(const uint32_t vblock, const int
         for (int f0 = 0; f0 < TT * PPRN; f0 += kThreads) {
             const int f = f0 + tid;
             const int rr = f / PPRN, piece = f % PPRN;
-            const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
-            const int64_t col = static_cast<int64_t>(tb) * TB + piece * 32;
+            const bool part = tail_pair && (rr & 3) >= 2;  // (paired tail: physical rows of pieces 2 / 3 hold the partner tile's positions 0 .. 31)
+            const int32_t t = t0 + 16 * ((rr & 3) - (part ? 2 : 0)) + (rr >> 2);
+            const int64_t col = static_cast<int64_t>(part ? (later ? tb - 8u : tb + 8u) : tb) * TB + piece * 32;
             const uint2 *src = reinterpret_cast<const uint2 *>(s_t + rr * STRIDE + piece * 32);
             uint32_t o[4];
 #pragma unroll
@@ -999,8 +1011,9 @@ __device__ __forceinline__ void tokens_pb8_body(const uint32_t vblock, const int
         for (int f0 = 0; f0 < TT * PPR; f0 += kThreads) {
             const int f = f0 + tid;
             const int rr = f / PPR, piece = f % PPR;           // physical row rr holds position 16 (rr % 4) + rr / 4
-            const int32_t t = t0 + 16 * (rr & 3) + (rr >> 2);
-            const int64_t col = static_cast<int64_t>(tb) * TB + piece * N;
+            const bool part = tail_pair && (rr & 3) >= 2;      // (paired tail: the partner tile's positions 0 .. 31)
+            const int32_t t = t0 + 16 * ((rr & 3) - (part ? 2 : 0)) + (rr >> 2);
+            const int64_t col = static_cast<int64_t>(part ? (later ? tb - 8u : tb + 8u) : tb) * TB + piece * N;
             if (t < static_cast<int32_t>(P) && col < ncols)
                 store16<NT>(out + (static_cast<int64_t>(t) * pitch + col) * SZ, widen_tokens<SZ, FLT>(s_t + rr * STRIDE + piece * N));
         }
@@ -1478,7 +1491,7 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     // neighbouring tiles share are then merged in ONE L2 -- 65 000 x 1024 int16: 49.6 -> 38.9 us, profiles/r03/pb8_unaligned_rows.txt)
     // (also for 4- / 8-byte elements: with the position tiles of a sequence tile back to back they took 53 / 111 us instead of 51 / 100)
     const bool contig = (pitch * int64_t(bsq_dtype_size(t))) % 64 != 0 || reinterpret_cast<uintptr_t>(out) % 64 != 0 || bsq_dtype_size(t) >= 4;
-    const uint32_t packed = uint32_t(d->bos != 0) | (raw ? 2u : 0u) | (contig ? 4u : 0u) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
+    uint32_t packed = uint32_t(d->bos != 0) | (raw ? 2u : 0u) | (contig ? 4u : 0u) | (bos_id << 8) | ((at_len & 0xFFu) << 16) | ((fill & 0xFFu) << 24);
     const bool nt = nontemporal_stores() && !raw;  // the raw matrix is re-read by the expansion right away
     // one tile shape: 256 sequences x 64 positions (512 x 64 and 512 x 32 were built and measured slower:
     // profiles/r03/pb8_coalesced_ab.txt, pb8_512x32_tile_lost.txt)
@@ -1495,6 +1508,9 @@ bsq_status launch_tokens_pb8(const bsq_desc *d, const uint8_t *chars, const int6
     uint32_t magic = 0, shift = 0, pow2 = 0;
     div_constants((contig || ua) ? uint32_t((ntb + 7) / 8) : uint32_t(ntt), &magic, &shift, &pow2);  // the divisor of the block index
     if (pow2) magic = 0;  // the kernel shifts (magic 0 marks a power of two)
+    // paired tail (see the kernel): the last position tile holds 1 ... 32 positions, the aligned class-pinned form, more than one group of 8 sequence
+    // tiles (knob "tokens_pb8_pair" = 1: never)
+    if (!contig && !ua && P % TT != 0 && P % TT <= 32 && ntb > 8 && tuning().tokens_pb8_pair != 1) packed |= 8u;
 #define BSQ_PB8U(NTV, LKV, SZV, FLTV, UAV)                                                                                             \
     hipLaunchKernelGGL((k_tokens_pb8_fast<NTV, 256, LKV, SZV, FLTV, UAV>), dim3(unsigned(blocks)), dim3(kThreads), 0, s, offsets, chars,  \
                        static_cast<uint8_t *>(out), pitch, uint32_t(B), uint32_t(P), uint32_t(ntb), uint32_t(ntt), magic, shift,    \

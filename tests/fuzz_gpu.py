@@ -49,6 +49,7 @@ def run(budget=120.0, seed=1):
         capi.check(lib.bsq_tuning_set(b"expand_rows1", int(rng.choice([0, 0, 1, 2]))))
         capi.check(lib.bsq_tuning_set(b"raw_nibbles", int(rng.choice([0, 1, 2, 2]))))
         capi.check(lib.bsq_tuning_set(b"two_pass_slice_mb", int(rng.choice([0, 0, 1, -1]))))
+        capi.check(lib.bsq_tuning_set(b"tokens_pb8_pair", int(rng.choice([0, 0, 1]))))
         tok, ora = bsq.Tokenizer(key, eos, bos, pad), O.OracleTokenizer(key, eos, bos, pad)
         shift = int(rng.integers(0, 4))  # misaligned device views of the inputs
         dch = torch.from_numpy(np.concatenate([np.zeros(shift, np.uint8), chars])).to(dev)[shift:]
@@ -182,7 +183,7 @@ def run(budget=120.0, seed=1):
         n += 1
     torch.cuda.synchronize()
     capi.check(lib.bsq_fused_status(None))  # no token wave of a fused augmentation launch gave up waiting
-    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"augment_fused", b"bcl_path", b"tokenize_tb", b"host_pieces", b"expand_rows1", b"raw_nibbles", b"two_pass_slice_mb", b"gather_small"):
+    for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"augment_fused", b"bcl_path", b"tokenize_tb", b"host_pieces", b"expand_rows1", b"raw_nibbles", b"two_pass_slice_mb", b"gather_small", b"tokens_pb8_pair"):
         capi.check(lib.bsq_tuning_set(name, 0))
     return n
 
