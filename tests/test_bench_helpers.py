@@ -180,6 +180,14 @@ def test_driver_line_is_compact_and_round_trips(bench, tmp_path, monkeypatch, ca
     bad["roofline"]["frac_of_copy_mix"] = float("nan")
     bad["configs"]["cfg2"]["ms_per_step"] = float("inf")
     assert "NaN" not in bench.compact_line(bad) and "Infinity" not in bench.compact_line(bad)
+    # an N > 1 run has no configs / cpu_baseline / e2e / loader (rank 0 prints the job's line): the same function, nothing missing that the contract names
+    multi = {k: v for k, v in json.loads(json.dumps(full)).items() if k not in ("configs", "cpu_baseline", "e2e", "sustained", "loader")}
+    multi["n_gpus"] = 8
+    multi["config"]["rccl_world_size"] = 8
+    multi["gather"] = {"rccl_world_size": 8, "rccl_version": "2.26.6", "forms": {"all_gather": {"ms": 1.5}, "direct_root": {"ms": 0.9}}}
+    line8 = json.loads(bench.compact_line(multi))
+    assert line8["n_gpus"] == 8 and line8["config"]["rccl_world_size"] == 8 and line8["roofline"]["frac"] > 0 and "cpu_baseline" not in line8
+    assert line8["gather"]["ms"] == {"all_gather": 1.5, "direct_root": 0.9} and line8["gather"]["rccl_world_size"] == 8
     # emit(): stdout is exactly that one line; the full object goes to bench_full.json
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     bench.emit(full)
