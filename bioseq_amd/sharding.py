@@ -513,7 +513,8 @@ def _raise_too_long(tokenizer, length, padlen, onehot):
 
 
 class _DeviceSlot:
-    """Streams of one entry of `devices` (a device may appear more than once: every entry gets its own pair)."""
+    """What one entry of `devices` owns (a device may appear more than once: every entry gets its own set): a copy stream, an encode stream,
+    two events that are re-recorded every call, and a device input buffer (rebased offsets | characters) that is kept between calls."""
 
     def __init__(self, device):
         import torch
@@ -522,31 +523,50 @@ class _DeviceSlot:
             self.copy = torch.cuda.Stream()
             self.encode = torch.cuda.Stream()
             self.uploaded = torch.cuda.Event()
+            self.encoded = torch.cuda.Event()
+        self.buf = None
+        self.used = False
+        self.keep = None  # the caller's pinned arrays of the last call (an asynchronous copy may still be reading them)
+
+    def input_buffer(self, nbytes):
+        import torch
+        if self.buf is None or self.buf.numel() < nbytes:
+            with torch.cuda.device(self.device):
+                self.buf = torch.empty(max(int(nbytes * 1.25) + 4096, 1 << 16), dtype=torch.uint8, device=self.device)
+            self.used = False  # (a fresh allocation: nothing in flight reads it)
+        return self.buf
 
 
 _slots = {}
 
 
 class _PinnedRing:
-    """Pinned host buffers of `encode_on_devices`, kept between calls (a fresh 35-MB hipHostMalloc per call costs ~0.4 ms): two of each kind
-    take turns, and a buffer is reused only after the uploads that last read it have completed (events; normally long past)."""
+    """Pinned host buffers of `encode_on_devices`, kept between calls (a fresh 35-MB hipHostMalloc per call costs ~0.4 ms): two take turns, and a
+    buffer is refilled only after the uploads that last read it have completed (one event per device entry, re-recorded every use)."""
 
     def __init__(self):
-        self.bufs = {}
+        self.turn = 0
+        self.slots = [None, None]
 
-    def get(self, kind, nbytes, dtype):
+    def get(self, nbytes):
         import torch
-        turn = self.bufs.setdefault(kind, {"i": 0, "slots": [None, None]})
-        turn["i"] ^= 1
-        slot = turn["slots"][turn["i"]]
-        item = torch.empty(0, dtype=dtype).element_size()
-        if slot is None or slot["t"].numel() * item < nbytes:
-            cap = max(int(nbytes * 1.25) + 4096, 1 << 16)
-            slot = turn["slots"][turn["i"]] = {"t": torch.empty((cap + item - 1) // item, dtype=dtype, pin_memory=True), "events": []}
-        for ev in slot["events"]:
-            ev.synchronize()
-        slot["events"] = []
-        return slot["t"], slot["events"]
+        self.turn ^= 1
+        slot = self.slots[self.turn]
+        if slot is None or slot["t"].numel() < nbytes:
+            slot = self.slots[self.turn] = {"t": torch.empty(max(int(nbytes * 1.25) + 4096, 1 << 16), dtype=torch.uint8, pin_memory=True), "events": {}, "live": []}
+        for key in slot["live"]:
+            slot["events"][key].synchronize()
+        slot["live"] = []
+        return slot
+
+    @staticmethod
+    def event(slot, key):
+        import torch
+        ev = slot["events"].get(key)
+        if ev is None:
+            ev = slot["events"][key] = torch.cuda.Event()
+        slot["live"].append(key)
+        return ev
 
 
 _pinned = _PinnedRing()
@@ -592,9 +612,17 @@ def _encode_on_devices(tokenizer, batch, padlen, destchar, devices, op, batch_fi
     if not devs or any(d.type != "cuda" for d in devs):
         raise ValueError("encode_on_devices needs a non-empty list of HIP devices")
     devs = [torch.device("cuda", torch.cuda.current_device() if d.index is None else d.index) for d in devs]
-    scan = None
+    lib = capi.load()
+    desc = capi.make_desc(tokenizer.key, tokenizer.includes_eos(), tokenizer.includes_bos(), tokenizer.is_padded())
+    C = int(tokenizer.alphabet_size())
+    dt = ctypes.c_int(0)
+    capi.check(lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt)))
+    tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt.value]
+    seq_first = (op == "onehot" and layout == "tbc") or (op == "tokenize" and not batch_first)
+    G = len(devs)
+    scan = user_chars = None
     if isinstance(batch, tuple) and len(batch) == 2 and not isinstance(batch[0], (str, bytes, bytearray)):
-        chars, offsets = pack_once(tokenizer, batch, padlen, nthreads, onehot=(op == "onehot"))  # already packed: pinned as it is / after one copy
+        user_chars, offsets = pack_once(tokenizer, batch, padlen, nthreads, onehot=(op == "onehot"))  # already packed: pinned as it is / after one copy
     else:
         # ONE scan under the GIL (pointer + length of every item, the offsets); the bytes are packed into pinned memory SLICE BY SLICE below,
         # device g's slice on its way over PCIe while device g + 1's is being packed
@@ -604,40 +632,42 @@ def _encode_on_devices(tokenizer, batch, padlen, destchar, devices, op, batch_fi
         offsets = torch.from_numpy(scan.offsets)
         if scan.bad >= 0:
             _raise_too_long(tokenizer, int(offsets[scan.bad + 1] - offsets[scan.bad]), padlen, op == "onehot")
-        chars, chars_events = _pinned.get("chars", int(offsets[-1]) + 16, torch.uint8)
-        chars_np = chars.numpy()
     B = int(offsets.shape[0]) - 1
-    G = len(devs)
-    lib = capi.load()
-    desc = capi.make_desc(tokenizer.key, tokenizer.includes_eos(), tokenizer.includes_bos(), tokenizer.is_padded())
-    C = int(tokenizer.alphabet_size())
-    dt = ctypes.c_int(0)
-    capi.check(lib.bsq_dtype_from_destchar(destchar.encode(), ctypes.byref(dt)))
-    tdt = {0: torch.int8, 1: torch.int16, 2: torch.int32, 3: torch.int64, 4: torch.float32, 5: torch.float64}[dt.value]
-    seq_first = (op == "onehot" and layout == "tbc") or (op == "tokenize" and not batch_first)
+    o_np = offsets.numpy()
+    total = int(o_np[-1])
+    # ONE pinned buffer per call (two take turns between calls): every device's REBASED offsets (device g: entries [b0 + g, b1 + g + 1)), then the characters
+    off_bytes = ((B + G) * 8 + 63) // 64 * 64
+    ring = _pinned.get(off_bytes + (total + 16 if scan is not None else 0))
+    pin_np = ring["t"].numpy()
+    r_np = pin_np[:(B + G) * 8].view(np.int64)
+    reb = ring["t"][:(B + G) * 8].view(torch.int64)
+    if scan is not None:
+        chars = ring["t"][off_bytes:off_bytes + total + 16]
+        chars_np = pin_np[off_bytes:off_bytes + total + 16]
+    else:
+        chars = user_chars
+    bounds = [shard_bounds(B, G, g) for g in range(G)]
+    for g, (b0, b1) in enumerate(bounds):
+        np.subtract(o_np[b0:b1 + 1], o_np[b0], out=r_np[b0 + g:b1 + g + 1])
 
     def shape_of(n):
         if op == "tokenize":
             return (n, padlen) if batch_first else (padlen, n)
         return (padlen, n, C) if layout == "tbc" else (n, C, padlen)
 
-    # every device's rebased offsets in ONE pinned buffer (device g: entries [b0 + g, b1 + g + 1))
-    bounds = [shard_bounds(B, G, g) for g in range(G)]
-    reb, reb_events = _pinned.get("offsets", (B + G) * 8, torch.int64)
-    o_np, r_np = offsets.numpy(), reb.numpy()
-    for g, (b0, b1) in enumerate(bounds):
-        np.subtract(o_np[b0:b1 + 1], o_np[b0], out=r_np[b0 + g:b1 + g + 1])
     full = None
     root_dev = None
+    root_ready = None
     if root is not None:
         root_dev = torch.device(root)
         root_dev = torch.device("cuda", torch.cuda.current_device() if root_dev.index is None else root_dev.index)
-        with torch.cuda.device(root_dev):
+        with capi.on_device(root_dev):
             full = torch.empty(shape_of(B), dtype=tdt, device=root_dev)
             root_ready = torch.cuda.Event()
             root_ready.record(torch.cuda.current_stream())  # (the allocator may hand out memory that this stream's queued work still uses)
         for d in devs:
             capi.check(lib.bsq_enable_peer_access(d.index, root_dev.index))
+    set_stream = torch.cuda.set_stream  # (cheaper than entering a `torch.cuda.stream` context twice per device)
     outs, slots = [], []
     for g, dev in enumerate(devs):
         b0, b1 = bounds[g]
@@ -649,20 +679,23 @@ def _encode_on_devices(tokenizer, batch, padlen, destchar, devices, op, batch_fi
         slots.append(slot)
         if scan is not None and nb > 0:
             scan.pack(b0, b1, chars_np)  # this device's characters (the pool's threads copy; the GIL stays held: the items must not change)
-        with torch.cuda.device(dev):
-            with torch.cuda.stream(slot.copy):
-                # (+16 spare bytes ride along when the buffer has them: the kernels' unaligned 16-byte loads stay inside the allocation)
-                d_chars = chars[c0:min(c1 + 16, chars.numel())].to(dev, non_blocking=True)
-                d_offs = reb[b0 + g:b1 + g + 1].to(dev, non_blocking=True)
+        nchar = min(c1 + 16, chars.numel()) - c0  # (+16 spare bytes ride along when the buffer has them: the kernels' unaligned 16-byte loads stay inside)
+        dof_bytes = ((nb + 1) * 8 + 255) // 256 * 256
+        buf = slot.input_buffer(dof_bytes + nchar + 16)
+        d_offs = buf[:(nb + 1) * 8].view(torch.int64)
+        d_chars = buf[dof_bytes:dof_bytes + nchar]
+        with capi.on_device(dev):
+            back = torch.cuda.current_stream()
+            try:
+                set_stream(slot.copy)
+                if slot.used:
+                    slot.copy.wait_event(slot.encoded)  # the previous call's kernels have read this slot's device buffer
+                d_chars.copy_(chars[c0:c0 + nchar], non_blocking=True)
+                d_offs.copy_(reb[b0 + g:b1 + g + 1], non_blocking=True)
                 slot.uploaded.record(slot.copy)
-                done = torch.cuda.Event()
-                done.record(slot.copy)  # (a per-call event: the pinned buffers may be refilled once these copies have completed)
-                reb_events.append(done)
-                if scan is not None:
-                    chars_events.append(done)
-            with torch.cuda.stream(slot.encode):
+                _PinnedRing.event(ring, g).record(slot.copy)  # the pinned buffer may be refilled once these copies have completed
+                set_stream(slot.encode)
                 slot.encode.wait_event(slot.uploaded)
-                d_chars.record_stream(slot.encode), d_offs.record_stream(slot.encode)
                 if full is None:
                     out = torch.empty(shape_of(nb), dtype=tdt, device=dev)
                     dst, pitch = out, nb
@@ -682,18 +715,20 @@ def _encode_on_devices(tokenizer, batch, padlen, destchar, devices, op, batch_fi
                     else:
                         st = lib.bsq_onehot_block_device(*a, None, nb, padlen, dt, dst.data_ptr(), pitch, stream)
                     capi.check(st)
-                outs.append(out)
-    # hand-over: every device's CURRENT stream waits for that device's encode stream (events only; the host never blocks)
-    for g, dev in enumerate(devs):
-        with torch.cuda.device(dev):
-            cur = torch.cuda.current_stream()
-            cur.wait_stream(slots[g].encode)
-            if outs[g] is not None:
-                outs[g].record_stream(cur)
+                slot.encoded.record(slot.encode)
+                slot.used = True
+                slot.keep = user_chars
+                # hand-over: this device's CURRENT stream waits for its encode stream (an event; the host never blocks)
+                back.wait_event(slot.encoded)
+                if out is not None:
+                    out.record_stream(back)
+            finally:
+                set_stream(back)
+        outs.append(out)
     if full is not None:
-        with torch.cuda.device(root_dev):
+        with capi.on_device(root_dev):
             cur = torch.cuda.current_stream()
             for g in range(G):  # the root's stream waits for every device's stores
-                cur.wait_stream(slots[g].encode)
+                cur.wait_event(slots[g].encoded)
         return full
     return outs
