@@ -34,7 +34,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 `cold.two_streams` (token workloads): the same cold batches with two streams taking turns -- consecutive batches are
                 independent, and only a caller knows that; a side figure (host clock), never `frac` or `value`.
                 `<w>_shard8` (cfg3, cfg4f, cfg4b, cfg5aug): rank 0's sharding.shard_bounds share of the workload's batch split over 8
-                ranks -- the per-GPU term of the 1/2/4/8 strong-scaling curve, measured on this one GPU -- as a tensor of its own
+                ranks -- the per-GPU term of the 1/2/4/8 strong-scaling curve, measured on this one GPU (token and cfg4 shards on fresh
+                shards like their full-size workloads, the looped figure beside them) -- as a tensor of its own
                 (checked against reference-made folds) and written straight into a whole-batch root tensor (`into_root`: a column
                 block at the root's pitch for seq-first layouts; also at the middle rank's offset), with
                 predicted_strong_scaling_efficiency = t(full batch) / (8 * t(shard)).  `--shard-of N` does the same for --workload.
@@ -749,7 +750,9 @@ def run_shard(name, world, lib, dev, stream, steps, warmup, full_ms=None, full_c
     if full_ms:
         res["full_batch_ms_per_step"] = full_ms
         res["predicted_strong_scaling_efficiency"] = full_ms / (world * loop_ms)
-    if op in ("tokenize", "augment+tokenize"):
+    if op in ("tokenize", "augment+tokenize") or name in COLD_ONEHOT:
+        # (round 6: the cfg4 one-hot shards too -- like their full-size workloads: a shard's 20 MB of reads stay cache-resident between the steps of a
+        #  loop over ONE shard, which a rank of a real job never sees; the looped figure stays beside it)
         cold = cold_regime(b, steps, 0.25, stream)
         res["cold"] = cold
         res["frac_cache_resident"], res["ms_per_step_cache_resident"] = res["frac"], res["ms_per_step"]
