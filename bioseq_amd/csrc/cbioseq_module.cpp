@@ -1280,6 +1280,22 @@ struct ListScan {
     int nthreads = 1;
 };
 
+// devices=[...] of Tokenizer.batch_tokenize / batch_onehot_encode (keyword-only; not in the reference): the same validation, in the same
+// order, as the one-device call, then sharding.encode_on_devices -- one host pack, every device its slice.  Without device= the list of
+// per-device shards comes back; with device= (the root) one whole-batch tensor there, written by every device over peer access.
+static py::object on_devices(const Tokenizer &t, const py::sequence &batch, py::ssize_t padlen, const std::string &dt, int nthreads,
+                             const py::object &mask, const py::object &device, const py::object &devices, const char *op, bool batch_first,
+                             const std::string &layout) {
+    const py::object self = py::cast(&t, py::return_value_policy::reference);  // (the registered wrapper of this instance)
+    const bool bcl = Tokenizer::parse_layout(layout);
+    (void)parse_dtype(dt);
+    t.check_padlen(padlen);
+    if (!mask.is_none()) throw std::invalid_argument("devices= does not take a mask: encode the masked batch per device (device=), or drop the mask");
+    return py::module_::import("bioseq_amd.sharding")
+        .attr("encode_on_devices")(self, batch, padlen, dt, py::arg("devices") = devices, py::arg("op") = op, py::arg("batch_first") = batch_first,
+                                   py::arg("layout") = bcl ? "bcl" : "tbc", py::arg("root") = device, py::arg("nthreads") = nthreads <= 1 ? 0 : nthreads);
+}
+
 PYBIND11_MODULE(cbioseq, m) {
     m.doc() = "bioseq_amd.cbioseq: MI355X-native drop-in for the reference's cbioseq tokenizer module";
     m.attr("abi_version") = bsq_abi_version();
@@ -1415,24 +1431,41 @@ PYBIND11_MODULE(cbioseq, m) {
     py::class_<Tokenizer>(m, "Tokenizer")
         .def(py::init<std::string, bool, bool, bool>(), py::arg("key"), py::arg("eos") = false,
              py::arg("bos") = false, py::arg("padchar") = false)
-        .def("batch_tokenize", &Tokenizer::batch_tokenize, py::arg("batch"), py::arg("padlen") = -1,
+        .def("batch_tokenize",
+             [](const Tokenizer &t, py::sequence batch, py::ssize_t padlen, const std::string &dt, bool batch_first, int nthreads,
+                const py::object &device, const py::object &devices) -> py::object {
+                 if (devices.is_none()) return t.batch_tokenize(batch, padlen, dt, batch_first, nthreads, device);
+                 return on_devices(t, batch, padlen, dt, nthreads, py::none(), device, devices, "tokenize", batch_first, "tbc");
+             },
+             py::arg("batch"), py::arg("padlen") = -1,
              py::arg("destchar") = "B", py::arg("batch_first") = false, py::arg("nthreads") = 1, py::kw_only(),
-             py::arg("device") = py::none(),
+             py::arg("device") = py::none(), py::arg("devices") = py::none(),
              "Token matrix of a list of sequences -- (padlen, B), or (B, padlen) with batch_first -- as the reference's\n"
              "Tokenizer.batch_tokenize (src/tokenize.cpp:82-98, tokenize.h:381-485); device= keeps the result on the GPU.\n\n"
              "nthreads: in the reference the OpenMP team of the encode loop; here the encode runs on the GPU and the value governs the\n"
              "host scan + pack only.  nthreads > 1 is honoured as given.  The signature default 1 CANNOT be told from an explicit 1:\n"
              "both defer to the module policy -- set_host_threads(n) / BSQ_HOST_THREADS, where 0 (the initial value) means one thread\n"
              "below 8192 items and up to 16 above.  A caller that needs a strictly serial host path whatever the batch size\n"
-             "(DataLoader workers, cgroup-limited jobs) calls set_host_threads(1) once.")
-        .def("batch_onehot_encode", &Tokenizer::batch_onehot_encode, py::arg("batch"), py::arg("padlen") = -1,
+             "(DataLoader workers, cgroup-limited jobs) calls set_host_threads(1) once.\n\n"
+             "devices=[...] (keyword-only; not in the reference): the batch is sharded by sequence over these HIP devices from this one\n"
+             "process -- one host pack, every device uploads and encodes its slice (sharding.encode_on_devices); returns the list of\n"
+             "per-device shards, or with device= (the root) one whole-batch tensor there.")
+        .def("batch_onehot_encode",
+             [](const Tokenizer &t, py::sequence batch, py::ssize_t padlen, const std::string &dt, int nthreads, const py::object &mask,
+                const py::object &device, const std::string &layout, const py::object &devices) -> py::object {
+                 if (devices.is_none()) return t.batch_onehot_encode(batch, padlen, dt, nthreads, mask, device, layout);
+                 return on_devices(t, batch, padlen, dt, nthreads, mask, device, devices, "onehot", false, layout);
+             },
+             py::arg("batch"), py::arg("padlen") = -1,
              py::arg("destchar") = "B", py::arg("nthreads") = 1, py::arg("mask") = py::none(), py::kw_only(),
-             py::arg("device") = py::none(), py::arg("layout") = "tbc",
+             py::arg("device") = py::none(), py::arg("layout") = "tbc", py::arg("devices") = py::none(),
              "One-hot tensor (padlen, B, C) of a list of sequences, as the reference's Tokenizer.batch_onehot_encode\n"
              "(src/tokenize.cpp:65-81, tokenize.h:283-371); device= keeps the result on the GPU, layout='bcl' writes (B, C, padlen).\n\n"
              "nthreads: the host scan + pack only (the encode runs on the GPU).  nthreads > 1 is honoured as given; the signature\n"
              "default 1 cannot be told from an explicit 1 and defers to the module policy (set_host_threads / BSQ_HOST_THREADS; 0 =\n"
-             "one thread below 8192 items, up to 16 above).  For a strictly serial host path call set_host_threads(1).")
+             "one thread below 8192 items, up to 16 above).  For a strictly serial host path call set_host_threads(1).\n\n"
+             "devices=[...] (keyword-only; not in the reference): sharded by sequence over these HIP devices from this one process\n"
+             "(sharding.encode_on_devices): the list of per-device shards, or with device= one whole-batch tensor there; no mask.")
         .def("tokenize_packed",
              [](const Tokenizer &t, const py::object &chars, const py::object &offsets, py::ssize_t padlen,
                 const std::string &dt, bool batch_first, const py::object &device, bool validate) {

@@ -138,3 +138,43 @@ def test_facade_devices_keyword(gpu, bsq, oracle):
         assert gotb[g].cpu().numpy().tobytes() == np.ascontiguousarray(want[:, b0:b1].transpose(1, 0, 2)).tobytes()
     with pytest.raises(ValueError):
         bsq.onehot_encode(tok, seqs, to_pytorch=True, devices=devs)   # padlen must be explicit
+
+
+def test_tokenizer_devices_keyword(gpu, bsq, oracle):
+    """Tokenizer.batch_tokenize / batch_onehot_encode(..., devices=[...]) (keyword-only, beside device=): the per-device shards of the
+    reference call's result cut by sequence; with device= (the root) the whole-batch tensor there; a mask is refused, and the checks of
+    the one-device call (padlen, layout, destchar, an item that is too long) come in the same order with the same text"""
+    import torch
+    from bioseq_amd import sharding
+    seqs, _, _ = _seqs(17, 1501, 0, 94)
+    tok, ora = bsq.Tokenizer("PROTEIN", 1, 1, 1), oracle.OracleTokenizer("PROTEIN", 1, 1, 1)
+    devs = _devices(3)
+    wt = ora.batch_tokenize(seqs, padlen=96)
+    wo = ora.batch_onehot_encode(seqs, padlen=96, destchar="f")
+    gt = tok.batch_tokenize(seqs, padlen=96, devices=devs)
+    gtb = tok.batch_tokenize(seqs, 96, "B", True, devices=devs)
+    go = tok.batch_onehot_encode(seqs, padlen=96, destchar="f", devices=devs)
+    gob = tok.batch_onehot_encode(seqs, padlen=96, destchar="f", devices=devs, layout="bcl")
+    for g in range(3):
+        b0, b1 = sharding.shard_bounds(len(seqs), 3, g)
+        assert gt[g].cpu().numpy().tobytes() == np.ascontiguousarray(wt[:, b0:b1]).tobytes()
+        assert gtb[g].cpu().numpy().tobytes() == np.ascontiguousarray(wt[:, b0:b1].T).tobytes()
+        assert go[g].cpu().numpy().tobytes() == np.ascontiguousarray(wo[:, b0:b1]).tobytes()
+        assert gob[g].cpu().numpy().tobytes() == np.ascontiguousarray(wo[:, b0:b1].transpose(1, 2, 0)).tobytes()
+    whole = tok.batch_tokenize(seqs, padlen=96, device="cuda:0", devices=devs)
+    assert isinstance(whole, torch.Tensor) and whole.cpu().numpy().tobytes() == wt.tobytes()
+    whole = tok.batch_onehot_encode(seqs, padlen=96, destchar="f", device="cuda:0", devices=devs)
+    assert whole.cpu().numpy().tobytes() == wo.tobytes()
+    # nthreads > 1 reaches the host pack as given
+    gt2 = tok.batch_tokenize(seqs, padlen=96, nthreads=4, devices=devs)
+    assert all(a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes() for a, b in zip(gt, gt2))
+    with pytest.raises(ValueError, match="padlen"):
+        tok.batch_tokenize(seqs, devices=devs)
+    with pytest.raises(ValueError, match="mask"):
+        tok.batch_onehot_encode(seqs, padlen=96, mask=[1] * len(seqs), devices=devs)
+    with pytest.raises(ValueError, match="layout"):
+        tok.batch_onehot_encode(seqs, padlen=96, layout="lbc", devices=devs)
+    with pytest.raises(RuntimeError):
+        tok.batch_tokenize(seqs, padlen=40, devices=devs)          # (tokenize.h:456-459: runtime_error)
+    with pytest.raises(ValueError):
+        tok.batch_onehot_encode(seqs, padlen=40, devices=devs)     # (tokenize.h:359-362: invalid_argument)

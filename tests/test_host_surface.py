@@ -225,3 +225,21 @@ def test_piece_hint_arithmetic_without_a_device():
         assert lib.bsq_stage_piece_hint(65536, 35 << 20, 80, ctypes.c_void_p(1 << 30), None, ctypes.byref(head)) == -1  # whole-batch path asked for
     finally:
         capi.check(lib.bsq_tuning_set(b"host_pieces", 0))
+
+
+def test_devices_keyword_checks_come_before_any_device_work(bsq):
+    """Tokenizer.batch_tokenize / batch_onehot_encode(..., devices=[...]): the argument checks of the one-device call (padlen, layout,
+    destchar) run first with the same text, a mask is refused, and a device list without HIP devices is a ValueError -- all without a GPU"""
+    tok = bsq.Tokenizer("DNA", 1, 1, 1)
+    with pytest.raises(ValueError, match="requires padlen"):
+        tok.batch_tokenize(["ACGT"], devices=["cuda:0"])
+    with pytest.raises(ValueError, match="layout must be"):
+        tok.batch_onehot_encode(["ACGT"], padlen=8, layout="x", devices=["cuda:0"])
+    with pytest.raises(Exception):
+        tok.batch_onehot_encode(["ACGT"], padlen=8, destchar="?", devices=["cuda:0"])
+    with pytest.raises(ValueError, match="mask"):
+        tok.batch_onehot_encode(["ACGT"], padlen=8, mask=[1], devices=["cuda:0"])
+    with pytest.raises(ValueError, match="HIP devices"):
+        tok.batch_tokenize(["ACGT"], padlen=8, devices=["cpu"])
+    with pytest.raises(ValueError, match="HIP devices"):
+        tok.batch_onehot_encode(["ACGT"], padlen=8, devices=[])
