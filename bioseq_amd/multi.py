@@ -51,6 +51,10 @@ def _prepare(tokenizer, batches, padlen, destchar, batch_first, outs):
                 raise ValueError("outs[%d] must be a contiguous %s tensor of shape %r on %s" % (i, tdt, shape, dev))
         else:
             out = torch.empty(shape, dtype=tdt, device=dev)
+        if chars.numel() == 0 and B > 0:
+            # every sequence of this batch is empty: torch hands out a null data_ptr for a tensor without elements, which the augmentation entry
+            # points refuse for B > 0 (include/bsq.h) -- no kernel reads a character of an empty sequence, so any valid address will do
+            chars = torch.zeros(16, dtype=torch.uint8, device=dev)
         keep.append((chars, offsets))
         results.append(out)
         arr[i].chars, arr[i].offsets, arr[i].B, arr[i].out = chars.data_ptr(), offsets.data_ptr(), B, out.data_ptr()

@@ -180,6 +180,8 @@ def run(budget=120.0, seed=1):
                 assert g.tobytes() == (np.ascontiguousarray(e.transpose(1, 2, 0)) if bf else e).tobytes(), ("list -> numpy onehot", bf)
         except AssertionError as ex:
             raise AssertionError("MISMATCH %s %r" % (ex, desc))
+        except Exception as ex:  # (an entry point that REFUSES a valid configuration is a finding too: name the configuration)
+            raise AssertionError("ERROR %s: %s %r (configuration %d of seed %d)" % (type(ex).__name__, ex, desc, n, seed)) from ex
         n += 1
     torch.cuda.synchronize()
     capi.check(lib.bsq_fused_status(None))  # no token wave of a fused augmentation launch gave up waiting

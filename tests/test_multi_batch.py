@@ -261,3 +261,29 @@ def test_python_surface_of_the_multi_batch_calls(gpu, bsq, oracle):
     long_o[-1] += 300   # ... and one sequence that no longer fits
     with pytest.raises(RuntimeError, match="seq len \\+ bos \\+ eos > padlen"):
         multi.tokenize_packed_multi(tok, [dev[0], (torch.from_numpy(long_c).to(gpu), torch.from_numpy(long_o).to(gpu))], P, "B", True)
+
+
+def test_a_batch_of_empty_sequences_among_the_batches(gpu, bsq, oracle):
+    """a batch whose sequences are ALL empty has no characters: torch's data_ptr() of such a tensor is null, and the augmentation entry
+    points refuse a null `chars` for B > 0 -- the Python surface must still take it (found by the randomised harness, round 6)"""
+    import torch
+    from bioseq_amd import multi
+    tok, ora = bsq.Tokenizer("SEB8", 1, 1, 1), oracle.OracleTokenizer("SEB8", 1, 1, 1)
+    P = 128
+    c, o = _batch(77, 192, 1, P - 2)
+    none_c, none_o = np.zeros(0, np.uint8), np.zeros(65, np.int64)
+    host = [(c, o), (none_c, none_o), (c, o)]
+    dev = [(torch.from_numpy(c_).to(gpu), torch.from_numpy(o_).to(gpu)) for c_, o_ in host]
+    assert dev[1][0].data_ptr() == 0 or dev[1][0].numel() == 0
+    for bf in (True, False):
+        got = multi.tokenize_packed_multi(tok, dev, P, "b", bf)
+        for (c_, o_), g in zip(host, got):
+            assert g.cpu().numpy().tobytes() == ora.tokenize_packed(c_, o_, P, "b", bf).tobytes()
+    work = [(c_.clone(), o_) for c_, o_ in dev]
+    got = multi.augment_tokenize_packed_multi(tok, work, P, "b", True, chain_len=1, augment_frac=1.0, seeds=[1, 2, 3])
+    torch.cuda.synchronize()
+    assert got[1].cpu().numpy().tobytes() == ora.tokenize_packed(none_c, none_o, P, "b", True).tobytes()
+    for k in (0, 2):   # one mutation per (non-empty) sequence, tokens of the mutated characters
+        mutated = work[k][0].cpu().numpy()
+        assert got[k].cpu().numpy().tobytes() == ora.tokenize_packed(mutated, o, P, "b", True).tobytes()
+        assert 0 < int((mutated != c).sum()) <= 192
