@@ -16,6 +16,7 @@ def run(budget=120.0, seed=1):
     ALPH = [synth.DIRTY, synth.AA, "ACGT", "ACGTNacgtn", synth.DIRTY + "".join(chr(c) for c in range(33, 64))]
     dev = torch.device("cuda:0")
     n = 0
+    ran = {"multi-batch": 0, "gather": 0, "encode_on_devices": 0, "device decode": 0, "loader epoch": 0, "host lists": 0}
     t_end = time.time() + budget
     while time.time() < t_end:
         key = KEYS[rng.integers(len(KEYS))]
@@ -101,6 +102,7 @@ def run(budget=120.0, seed=1):
                 assert torch.equal(a1, a2) and u64(t1.cpu().numpy()).tobytes() == u64(t2.cpu().numpy()).tobytes(), ("augment+tokenize", cl, fr, bf)
             if d in "bh" and rng.random() < 0.3:  # round 6: the batch cut into 1 ... 10 pieces, all of them in ONE multi-batch call (multi kernels
                 from bioseq_amd import multi            # where every piece qualifies, single launches otherwise; empty pieces allowed)
+                ran["multi-batch"] += 1
                 cuts = sorted([0, B] + [int(x) for x in rng.integers(0, B + 1, int(rng.integers(0, 10)))])
                 if rng.random() < 0.5:  # multiples of 64 sequences: what the (P,B) multi kernel takes
                     cuts = sorted(set([0, B] + [c // 64 * 64 for c in cuts]))
@@ -123,6 +125,7 @@ def run(budget=120.0, seed=1):
                         assert torch.equal(c1, c2) and (w is None or torch.equal(w, g)), ("multi augment + tokens", cuts)
             if rng.random() < 0.15:  # round 6: index batches of every size class of the gather (one launch <= 4096, two beyond, three under the knob)
                 nidx = int(rng.choice([1, 100, 4096, 4097, 9000, 20000, 66000]))
+                ran["gather"] += 1
                 idx = rng.integers(0, B, size=nidx).astype(np.int64)
                 capi.check(lib.bsq_tuning_set(b"gather_small", int(rng.choice([0, 0, 1]))))
                 lens_ = np.diff(offs)
@@ -140,6 +143,7 @@ def run(budget=120.0, seed=1):
                 assert (hc[:cap] == chars[pos]).all() and (hc[cap:] == 0xEE).all(), ("gather characters", nidx)
             if B <= 20001 and rng.random() < 0.12:  # round 6: ONE process, several device entries (stream pairs of this GPU): shards and a root tensor
                 from bioseq_amd import sharding
+                ran["encode_on_devices"] += 1
                 seqs = synth.unpack(chars, offs)
                 G = int(rng.integers(1, 6))
                 devs = ["cuda:0"] * G
@@ -155,7 +159,46 @@ def run(budget=120.0, seed=1):
                 ax = (0 if bf else 1) if op == "tokenize" else (0 if lay == "bcl" else 1)
                 cat = np.concatenate([u64(x.cpu().numpy()) for x in shards], axis=ax)
                 assert np.ascontiguousarray(cat).tobytes() == want.tobytes(), ("encode_on_devices shards", op, lay, bf, G)
+            if d in "bhiq" and B * P <= 2_000_000 and rng.random() < 0.1:  # device decode (any strides) == the host decode of the same tokens
+                ran["device decode"] += 1
+                ed = ora.tokenize_packed(chars, offs, P, d, bf)
+                ed = ed if d != "q" else ed.view(np.int64)
+                dt_ = torch.from_numpy(ed).to(dev)
+                assert tok.decode_tokens(dt_) == tok.decode_tokens(ed), ("decode on the device", bf)
+                assert tok.decode_tokens(dt_.T) == tok.decode_tokens(np.ascontiguousarray(ed.T)), ("decode on the device, transposed view", bf)
+                if ed.shape[1] > 1:
+                    assert tok.decode_tokens(dt_[:, ::2]) == tok.decode_tokens(np.ascontiguousarray(ed[:, ::2])), ("decode on the device, strided view", bf)
+            if 2 <= B <= 5000 and int(np.diff(offs).max()) + eos + bos >= 1 and rng.random() < 0.08:
+                # a loader epoch out of a FlatFile resident in HBM: any batch size, shuffled or not, drop_last, groups of batches, prefetch
+                import tempfile
+                ran["loader epoch"] += 1
+                from bioseq_amd.flatfile import FlatFile, write_flatfile
+                from bioseq_amd.loaders import FlatFileDataset
+                seqs = synth.unpack(chars, offs)
+                with tempfile.TemporaryDirectory() as td:
+                    ff = FlatFile(write_flatfile(seqs, os.path.join(td, "s.ff")))
+                    bs = int(rng.choice([1, 7, 64, 100, 256, 1000]))
+                    bs = max(bs, -(-B // 150))  # (at most 150 batches per epoch: every one is read back and checked)
+                    cnn = rng.random() < 0.3 and bs * (int(np.diff(offs).max()) + 2) * tok.alphabet_size() * 4 <= (64 << 20)
+                    tdt = "q" if (key == "BYTES" or rng.random() < 0.5) else "b"
+                    ds = FlatFileDataset(ff, tok, cnn=cnn, device=dev, token_dtype=tdt)
+                    PP = ds.max_seq_len
+                    shuffle, drop_last = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+                    grp, pf, gs = int(rng.integers(1, 6)), int(rng.choice([0, 0, 1, 3])), int(rng.integers(1 << 30))
+                    perm = (torch.randperm(B, device=dev, generator=torch.Generator(device=dev).manual_seed(gs)).cpu().tolist() if shuffle else list(range(B)))
+                    k = 0
+                    for batch in ds.batches(bs, shuffle=shuffle, drop_last=drop_last, generator=torch.Generator(device=dev).manual_seed(gs), prefetch=pf, group=grp):
+                        part = [seqs[i] for i in perm[k * bs:(k + 1) * bs]]
+                        if cnn:
+                            want = np.ascontiguousarray(ora.batch_onehot_encode(part, padlen=PP, destchar="f").transpose(1, 2, 0))
+                        else:
+                            want = ora.batch_tokenize(part, padlen=PP, destchar=tdt, batch_first=True)
+                        assert batch.cpu().numpy().tobytes() == want.tobytes(), ("loader epoch", cnn, tdt, bs, shuffle, drop_last, grp, pf, k)
+                        k += 1
+                    assert k == (B // bs if drop_last else -(-B // bs)), ("loader epoch: number of batches", bs, drop_last, grp, pf, k)
+                    del ds, ff
             if B * P < 400_000:  # host entry points (list of bytes -> numpy)
+                ran["host lists"] += 1
                 seqs = synth.unpack(chars, offs)
                 ml = None if mask is None else [mask[offs[i]:offs[i + 1]].copy() for i in range(B)]
                 g = tok.batch_onehot_encode(seqs, padlen=P, destchar=d, mask=ml)
@@ -187,15 +230,16 @@ def run(budget=120.0, seed=1):
     capi.check(lib.bsq_fused_status(None))  # no token wave of a fused augmentation launch gave up waiting
     for name in (b"onehot_path", b"tokenize_path", b"tile_order", b"tokens8_lookup", b"tokens8", b"tokens8_fast", b"raw_mode", b"tokens_pb8", b"augment_fused", b"bcl_path", b"tokenize_tb", b"host_pieces", b"expand_rows1", b"raw_nibbles", b"two_pass_slice_mb", b"gather_small", b"tokens_pb8_pair"):
         capi.check(lib.bsq_tuning_set(name, 0))
-    return n
+    return n, ran
 
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     try:
-        n = run(budget, seed)
+        n, ran = run(budget, seed)
     except AssertionError as ex:
         print(ex, flush=True)
         sys.exit(1)
     print("fuzz ok: %d random configurations, %.0f s, all bit-exact vs the oracle" % (n, budget))
+    print("  of which also: " + ", ".join("%s %d" % kv for kv in ran.items()))

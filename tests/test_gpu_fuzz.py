@@ -13,5 +13,5 @@ def test_random_configurations_bit_exact(gpu):
     spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tests", "fuzz_gpu.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    n = fz.run(budget=20.0, seed=2024)
-    assert n > 100
+    n, ran = fz.run(budget=20.0, seed=2024)
+    assert n > 40 and ran["host lists"] > 0   # (60-100 configurations in 20 s, by box)
