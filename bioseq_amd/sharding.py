@@ -531,6 +531,11 @@ class _DeviceSlot:
     def input_buffer(self, nbytes):
         import torch
         if self.buf is None or self.buf.numel() < nbytes:
+            if self.buf is not None:
+                # the buffer being dropped may still be read by the previous call's copies / kernels, and it was allocated on whatever stream
+                # was current THEN: tell the allocator, or it could hand the block to that stream's next allocation at once
+                self.buf.record_stream(self.copy)
+                self.buf.record_stream(self.encode)
             with torch.cuda.device(self.device):
                 self.buf = torch.empty(max(int(nbytes * 1.25) + 4096, 1 << 16), dtype=torch.uint8, device=self.device)
             self.used = False  # (a fresh allocation: nothing in flight reads it)
