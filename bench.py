@@ -1121,13 +1121,34 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if os.environ.get("BSQ_BENCH_SHARE_GPU") else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tiny timing reductions live
+    backend_note = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # RCCL
+            # RCCL carries the barrier and the tiny timing reductions only -- the path shards by sequence, there is no data-path collective -- so
+            # a box whose RCCL does not come up must not cost the scaling curve: the same run then goes on over gloo, and the line says so
+            try:
+                dist.init_process_group("nccl", device_id=dev)  # RCCL
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce of ones over %d ranks returned %r" % (world, probe.item()))
+            except Exception as ex:  # noqa: BLE001 (whatever RCCL / the HIP runtime raise)
+                if args.gather:
+                    raise  # (the gather figures ARE RCCL traffic: nothing to report without it)
+                backend_note = "nccl failed (%s: %s); barrier + timing reductions over gloo" % (type(ex).__name__, str(ex).splitlines()[0][:120] if str(ex) else "")
+                print("bench.py rank %d: %s" % (rank, backend_note), file=sys.stderr, flush=True)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tiny timing reductions live
 
     cfg_name, op, destchar, batch_first = WORKLOADS[args.workload]
     cfg = synth.CONFIGS[cfg_name]
@@ -1351,7 +1372,7 @@ def main():
                              "(sharding.shard_bounds; rank 0 holds %d)" % (n_job, world, n)),
                 "job_sequences": n_job,
                 "rccl_world_size": dist.get_world_size() if world > 1 else 1,
-                "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)"},
+                "backend": (backend + (" (RCCL)" if backend == "nccl" else "") + (": " + backend_note if backend_note else "")) if world > 1 else "none (single process)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "frac_wall": algo_bytes / (wall_max / args.steps) / 1e9 / HBM_PEAK_GBPS,  # from ms_per_step (host clock)

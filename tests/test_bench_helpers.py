@@ -185,7 +185,10 @@ def test_driver_line_is_compact_and_round_trips(bench, tmp_path, monkeypatch, ca
     multi["n_gpus"] = 8
     multi["config"]["rccl_world_size"] = 8
     multi["gather"] = {"rccl_world_size": 8, "rccl_version": "2.26.6", "forms": {"all_gather": {"ms": 1.5}, "direct_root": {"ms": 0.9}}}
+    multi["config"]["backend"] = "gloo: nccl failed (DistBackendError: NCCL error in: ... unhandled system error); barrier + timing reductions over gloo"
+    assert len(bench.compact_line(multi).encode()) < 4096
     line8 = json.loads(bench.compact_line(multi))
+    assert line8["config"]["backend"].startswith("gloo: nccl failed")   # (a run that went on without RCCL says so in the line)
     assert line8["n_gpus"] == 8 and line8["config"]["rccl_world_size"] == 8 and line8["roofline"]["frac"] > 0 and "cpu_baseline" not in line8
     assert line8["gather"]["ms"] == {"all_gather": 1.5, "direct_root": 0.9} and line8["gather"]["rccl_world_size"] == 8
     # emit(): stdout is exactly that one line; the full object goes to bench_full.json
