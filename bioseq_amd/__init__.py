@@ -62,7 +62,9 @@ def onehot_encode(tokenizer, seqbatch, padlen=-1, destchar='B', batch_first=Fals
     list of per-device shards comes back, what a ``nn.DataParallel``-style consumer (training/cnnpretrain.py:85-94) feeds its replicas.
     """
     single = isinstance(seqbatch, (str, bytes))
-    if devices is not None and to_pytorch and not single:
+    if devices is not None and (single or not to_pytorch):
+        raise ValueError("devices= shards a BATCH over HIP devices and returns device tensors: pass a list of sequences and to_pytorch=True")
+    if devices is not None:
         if padlen is None or padlen <= 0:
             raise ValueError("devices= needs an explicit padlen")
         shards = sharding.encode_on_devices(tokenizer, seqbatch, padlen, destchar, devices=devices, op="onehot")

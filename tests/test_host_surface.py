@@ -243,3 +243,17 @@ def test_devices_keyword_checks_come_before_any_device_work(bsq):
         tok.batch_tokenize(["ACGT"], padlen=8, devices=["cpu"])
     with pytest.raises(ValueError, match="HIP devices"):
         tok.batch_onehot_encode(["ACGT"], padlen=8, devices=[])
+
+
+def test_facade_devices_keyword_needs_a_batch_and_to_pytorch(bsq):
+    """`onehot_encode(..., devices=[...])` / `f_encode(..., devices=[...])` return per-device tensors: without `to_pytorch=True`, or for a single
+    sequence, the keyword would have been ignored silently -- it is a ValueError instead (before any device work)"""
+    tok = bsq.Tokenizer("DNA", 1, 1, 1)
+    with pytest.raises(ValueError, match="to_pytorch=True"):
+        bsq.onehot_encode(tok, ["ACGT"], padlen=8, devices=["cuda:0"])
+    with pytest.raises(ValueError, match="to_pytorch=True"):
+        bsq.onehot_encode(tok, "ACGT", padlen=8, to_pytorch=True, devices=["cuda:0"])
+    with pytest.raises(ValueError, match="to_pytorch=True"):
+        bsq.f_encode(["ACGT"], key="DNA", padlen=8, devices=["cuda:0"])
+    with pytest.raises(ValueError, match="explicit padlen"):
+        bsq.onehot_encode(tok, ["ACGT"], to_pytorch=True, devices=["cuda:0"])
