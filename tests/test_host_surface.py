@@ -257,3 +257,22 @@ def test_facade_devices_keyword_needs_a_batch_and_to_pytorch(bsq):
         bsq.f_encode(["ACGT"], key="DNA", padlen=8, devices=["cuda:0"])
     with pytest.raises(ValueError, match="explicit padlen"):
         bsq.onehot_encode(tok, ["ACGT"], to_pytorch=True, devices=["cuda:0"])
+
+
+def test_alphabet_keys_and_release_staging_without_a_device(bsq):
+    """`cbioseq.alphabet_keys()` = the keys of the reference's CAMAP (src/alphabet.h:198-222) as the golden dump has them; `release_staging()`
+    (frees the pinned ring and the device staging areas) is harmless before any batch was staged, repeatedly, and from several threads"""
+    import json
+    import threading
+    from bioseq_amd import cbioseq
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alphabets.json")))
+    assert sorted(cbioseq.alphabet_keys()) == sorted(golden["keys"])
+    for k in cbioseq.alphabet_keys():
+        assert bsq.Tokenizer(k).key == k
+    cbioseq.release_staging()
+    cbioseq.release_staging()
+    ts = [threading.Thread(target=cbioseq.release_staging) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()

@@ -86,3 +86,43 @@ def test_a_list_that_outgrows_the_staging_estimate_falls_back(gpu, bsq, oracle, 
     got = tok.batch_tokenize(short, padlen=P2, batch_first=True, device=gpu if to_device else None)
     got = got.cpu().numpy() if to_device else got
     assert got.tobytes() == exp.tobytes()
+
+
+def test_release_staging_between_calls(gpu, bsq, oracle):
+    """`cbioseq.release_staging()` gives the pinned ring and the device staging areas back (a long-lived process that is done with a phase of
+    list -> device calls); the next call of every host form builds them again and is exact -- small and staged-in-pieces batches, numpy and
+    device results, also while another thread is encoding"""
+    import threading
+    from bioseq_amd import cbioseq, synth
+    tok, ora = bsq.Tokenizer("PROTEIN", 1, 1, 1), oracle.OracleTokenizer("PROTEIN", 1, 1, 1)
+    P = 96
+    small = synth.unpack(*synth.synth_packed(41, 300, 0, P - 2, synth.AA))
+    big = synth.unpack(*synth.synth_packed(42, 40000, 0, P - 2, synth.AA))     # >= 16384 items: the staged path in pieces
+    want = {id(small): (ora.batch_tokenize(small, padlen=P, batch_first=True), ora.batch_onehot_encode(small, padlen=P, destchar="f")),
+            id(big): (ora.batch_tokenize(big, padlen=P, batch_first=True), ora.batch_onehot_encode(big, padlen=P, destchar="f"))}
+
+    def check(seqs):
+        wt, wo = want[id(seqs)]
+        assert tok.batch_tokenize(seqs, padlen=P, batch_first=True).tobytes() == wt.tobytes()
+        assert tok.batch_tokenize(seqs, padlen=P, batch_first=True, device=gpu).cpu().numpy().tobytes() == wt.tobytes()
+        assert tok.batch_onehot_encode(seqs, padlen=P, destchar="f", device=gpu).cpu().numpy().tobytes() == wo.tobytes()
+
+    for _ in range(2):
+        check(small), check(big)
+        cbioseq.release_staging()
+        cbioseq.release_staging()
+    errors = []
+
+    def worker():
+        try:
+            for _ in range(3):
+                check(big)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+    t = threading.Thread(target=worker)
+    t.start()
+    for _ in range(20):
+        cbioseq.release_staging()   # waits for a staged batch in flight, never tears its buffers away
+    t.join()
+    assert not errors, errors
+    check(small)
