@@ -1,7 +1,7 @@
 """Build container only (needs oracle/_ref, the reference compiled in place): the FASTX -> FlatFile differential of tests/test_flatfile.py
-on as many random adversarial texts as asked for.   python scripts/probes/cpu_stress_fastx.py 20000 777"""
+on as many random adversarial texts as asked for.   python tests/stress/cpu_stress_fastx.py 20000 777"""
 import gzip, os, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/stress/ -> repo root
 sys.path.insert(0, ROOT)
 import numpy as np
 import bioseq_amd

@@ -1,7 +1,7 @@
 """Build container only (needs oracle/_ref): the C oracle against the reference's own C++ on random batches -- every key, flag combination, dtype,
-layout, masks, dirty alphabets (never bytes >= 0x80 or BYTES as int8: SURVEY 8c).   python scripts/probes/cpu_stress_oracle.py 1500 99"""
+layout, masks, dirty alphabets (never bytes >= 0x80 or BYTES as int8: SURVEY 8c).   python tests/stress/cpu_stress_oracle.py 1500 99"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/stress/ -> repo root
 sys.path.insert(0, ROOT)
 import numpy as np
 from bioseq_amd import synth

@@ -1,7 +1,7 @@
 """Build container only (needs oracle/_ref): the product's HOST paths that need no device -- single-sequence `onehot_encode` (tokenize.h:188-216) and
-`decode_tokens` (tokenize.h:131-183) -- against the reference's own C++ on random inputs.   python scripts/probes/cpu_stress_single_decode.py 3000 5"""
+`decode_tokens` (tokenize.h:131-183) -- against the reference's own C++ on random inputs.   python tests/stress/cpu_stress_single_decode.py 3000 5"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/stress/ -> repo root
 sys.path.insert(0, ROOT)
 import numpy as np
 import bioseq_amd as bsq
